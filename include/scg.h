@@ -1,0 +1,217 @@
+/*
+ * scg.h -- C ABI of libscg.so, the MI355X-native barcode counting engine.
+ *
+ * This is the drop-in boundary for screenCounter's hot path.  Every entry point below replaces
+ * one function of the reference (paths relative to the reference checkout):
+ *
+ *   scg_count_single_barcodes        <- count_single_barcodes()        src/count_single_barcodes.cpp:28-50
+ *   scg_count_combo_barcodes_single  <- count_combo_barcodes_single()  src/count_combo_barcodes_single.cpp:39-70
+ *   scg_count_dual_barcodes          <- count_dual_barcodes()          src/count_dual_barcodes.cpp:74-117
+ *   scg_match_barcodes               <- match_barcodes()               src/match_barcodes.cpp:6-37
+ *
+ * i.e. the three functions R reaches through .Call("_screenCounter_count_*") in
+ * src/RcppExports.cpp:54-121, minus the Rcpp types.  INTEGRATION.md shows the ~60-line Rcpp shim
+ * that forwards the unchanged R/RcppExports.R wrappers to these symbols.
+ *
+ * The plan/batch functions further down expose the same engine on reads that are already
+ * resident in HBM (what kaori::process_single_end_data / process_paired_end_data,
+ * inst/include/kaori/process_data.hpp:105-190 and :224-340, hand to a handler one chunk at a
+ * time).  They are what the tests, bench.py and the multi-GPU driver call.
+ *
+ * Conventions
+ *   - plain C: pointers and sizes only; nothing throws across the boundary.
+ *   - every function returns SCG_OK (0) or an SCG_ERR_* code and, on error, writes a
+ *     NUL-terminated message into err[0..errcap) (err may be NULL).  The Rcpp shim turns a
+ *     non-zero return into Rcpp::stop(err), which is what END_RCPP does with the reference's
+ *     std::runtime_error (src/RcppExports.cpp).
+ *   - inputs are borrowed for the duration of the call; outputs are caller-allocated where the
+ *     size is known in advance, otherwise malloc'd by the library and released with scg_free.
+ *   - barcode pools are arrays of NUL-terminated strings (R CHARSXPs are NUL-terminated); the
+ *     library enforces "all the same length" itself like format_pointers() (src/utils.cpp:5-23).
+ *   - strand: 0 = forward, 1 = reverse, 2 = both (src/utils.cpp:33-41).
+ *   - counters are 32-bit like the reference's (SingleBarcodeSingleEnd.hpp:132-133).
+ *   - no CPU fallback exists: without a usable HIP device the counting functions fail with
+ *     SCG_ERR_DEVICE.
+ */
+#ifndef SCG_H
+#define SCG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SCG_OK 0
+#define SCG_ERR_INVALID 1     /* the reference would have thrown std::runtime_error on these inputs */
+#define SCG_ERR_IO 2          /* file cannot be opened / FASTQ format error */
+#define SCG_ERR_DEVICE 3      /* HIP error or no device */
+#define SCG_ERR_UNSUPPORTED 4 /* valid for the reference but outside this engine's domain */
+
+/* Library version string, e.g. "scg 0.1.0 (gfx950)". */
+const char* scg_version(void);
+
+/* Number of visible HIP devices (0 when there is none; never fails). */
+int scg_device_count(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * File-level entry points: what the Rcpp shim binds.
+ * ------------------------------------------------------------------------------------------- */
+
+/* countSingleBarcodes hot path.  Replaces src/count_single_barcodes.cpp:28-50.
+ * counts_out[n_pool] and *total_out mirror List(IntegerVector counts, int total). */
+int scg_count_single_barcodes(const char* path, const char* constant, int strand,
+                              const char* const* pool, int32_t n_pool,
+                              int mismatches, int use_first, int nthreads,
+                              int32_t* counts_out, int32_t* total_out,
+                              char* err, size_t errcap);
+
+/* countComboBarcodes hot path (two variable regions).  Replaces
+ * src/count_combo_barcodes_single.cpp:39-70 + count_combinations<2> (src/utils.h:14-45).
+ * On success *indices_out is a malloc'd 2 x K column-major matrix of 0-based pool indices whose
+ * columns are sorted by (first, second), *freq_out the K frequencies; release both with scg_free. */
+int scg_count_combo_barcodes_single(const char* path, const char* constant, int strand,
+                                    const char* const* pool0, int32_t n_pool0,
+                                    const char* const* pool1, int32_t n_pool1,
+                                    int mismatches, int use_first, int nthreads,
+                                    int32_t** indices_out, int32_t** freq_out, int64_t* k_out,
+                                    int32_t* total_out, char* err, size_t errcap);
+
+/* countDualBarcodes hot path, paired-end.  Replaces src/count_dual_barcodes.cpp:74-117
+ * (non-diagnostic branch :38-51; diagnostics != 0 is reported as SCG_ERR_UNSUPPORTED).
+ * pool1[i] / pool2[i] form valid pair i; counts_out has n_pool entries. */
+int scg_count_dual_barcodes(const char* path1, const char* constant1, int reverse1, int mismatches1,
+                            const char* const* pool1,
+                            const char* path2, const char* constant2, int reverse2, int mismatches2,
+                            const char* const* pool2, int32_t n_pool,
+                            int randomized, int use_first, int diagnostics, int nthreads,
+                            int32_t* counts_out, int32_t* total_out,
+                            char* err, size_t errcap);
+
+/* matchBarcodes.  Replaces src/match_barcodes.cpp:6-37.  index_out[i] is the 0-based index of the
+ * unique best choice within `substitutions` mismatches or -1 (R: NA); mismatches_out likewise. */
+int scg_match_barcodes(const char* const* sequences, int32_t n_sequences,
+                       const char* const* choices, int32_t n_choices,
+                       int substitutions, int reverse,
+                       int32_t* index_out, int32_t* mismatches_out,
+                       char* err, size_t errcap);
+
+void scg_free(void* p);
+
+/* ---------------------------------------------------------------------------------------------
+ * FASTQ staging (host).  Replaces kaori::FastqReader (inst/include/kaori/FastqReader.hpp:42-110)
+ * over byteme::SomeFileReader (inst/include/byteme/SomeFileReader.hpp:31-44): gzip is detected by
+ * its magic bytes; sequences are returned concatenated with n_reads + 1 byte offsets, names and
+ * qualities dropped (use_names = false on this path).  Release with scg_free.
+ * ------------------------------------------------------------------------------------------- */
+int scg_parse_fastq(const char* path, char** seqs_out, uint64_t** offsets_out, int64_t* n_reads_out,
+                    char* err, size_t errcap);
+
+/* ---------------------------------------------------------------------------------------------
+ * Plans: a compiled (template, library, options) bound to one device, reusable across batches.
+ * Replaces the construction of kaori::SingleBarcodeSingleEnd / CombinatorialBarcodesSingleEnd /
+ * DualBarcodesPairedEnd (handlers/*.hpp) including all of their argument checks.
+ * device < 0 selects $SCG_DEVICE or, failing that, the current HIP device.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct scg_plan scg_plan;
+
+int scg_plan_single(scg_plan** plan_out, const char* constant, int strand,
+                    const char* const* pool, int32_t n_pool, int mismatches, int use_first,
+                    int device, char* err, size_t errcap);
+
+int scg_plan_combo(scg_plan** plan_out, const char* constant, int strand,
+                   const char* const* pool0, int32_t n_pool0,
+                   const char* const* pool1, int32_t n_pool1,
+                   int mismatches, int use_first,
+                   int device, char* err, size_t errcap);
+
+int scg_plan_dual(scg_plan** plan_out,
+                  const char* constant1, int reverse1, int mismatches1, const char* const* pool1,
+                  const char* constant2, int reverse2, int mismatches2, const char* const* pool2,
+                  int32_t n_pool, int randomized, int use_first,
+                  int device, char* err, size_t errcap);
+
+void scg_plan_destroy(scg_plan* plan);
+
+/* Number of int32 counters the plan accumulates into: n_pool (single, dual) or
+ * n_pool0 * n_pool1 (combo; dense histogram, cell = first * n_pool1 + second). */
+int64_t scg_plan_num_counters(const scg_plan* plan);
+
+/* Device pointer to those counters (for an RCCL all-reduce across ranks) and, optionally, a
+ * caller-owned replacement (e.g. a torch int32 tensor); d_counters = NULL restores the plan's own. */
+int32_t* scg_plan_device_counters(scg_plan* plan);
+int scg_plan_bind_counters(scg_plan* plan, int32_t* d_counters, char* err, size_t errcap);
+
+/* Zero the counters and the read total (asynchronous on `stream`, a hipStream_t or NULL). */
+int scg_plan_reset(scg_plan* plan, void* stream, char* err, size_t errcap);
+
+/* Count one batch of single-end reads resident in device memory (single and combo plans).
+ *   d_seqs     concatenated read bytes (ASCII, any case; anything but ACGT is "other")
+ *   d_offsets  n_reads + 1 byte offsets into d_seqs, or NULL when every read has fixed_len bytes
+ * Asynchronous on `stream`; accumulates into the plan's counters.  One step of the hot path. */
+int scg_count_batch(scg_plan* plan, const char* d_seqs, const uint32_t* d_offsets, int32_t fixed_len,
+                    int64_t n_reads, void* stream, char* err, size_t errcap);
+
+/* Same for read pairs (dual plans); pair i is (read i of batch 1, read i of batch 2). */
+int scg_count_batch_paired(scg_plan* plan,
+                           const char* d_seqs1, const uint32_t* d_offsets1, int32_t fixed_len1,
+                           const char* d_seqs2, const uint32_t* d_offsets2, int32_t fixed_len2,
+                           int64_t n_pairs, void* stream, char* err, size_t errcap);
+
+/* Synchronise `stream` and copy the counters (num_counters int32) and the number of reads seen
+ * so far to the host.  Either output may be NULL. */
+int scg_plan_read(scg_plan* plan, int32_t* counts_out, int64_t* total_out, void* stream,
+                  char* err, size_t errcap);
+
+/* Combo plans: sorted run-length form of a dense histogram (host-side, pure function):
+ * cells[n0*n1] -> malloc'd 2 x K indices + K frequencies, as scg_count_combo_barcodes_single. */
+int scg_combo_compact(const int32_t* cells, int32_t n_pool0, int32_t n_pool1,
+                      int32_t** indices_out, int32_t** freq_out, int64_t* k_out,
+                      char* err, size_t errcap);
+
+/* Average duration in milliseconds of the counting kernel launches issued through this plan
+ * since the last scg_plan_reset, measured with HIP events recorded on the launch stream around
+ * each launch when profiling is switched on.  Used by bench.py for the roofline figure. */
+int scg_plan_set_profiling(scg_plan* plan, int enabled);
+int scg_plan_kernel_stats(scg_plan* plan, double* total_ms_out, int64_t* launches_out,
+                          char* err, size_t errcap);
+
+/* ---------------------------------------------------------------------------------------------
+ * Synthetic reads (bench / tests): fills device memory with fixed-length reads following
+ * a construct (template with its variable regions drawn from the pools)
+ * at a uniform offset in random sequence, substitutions, Ns, junk reads and optional reverse
+ * complement.  Counter-based RNG (splitmix64) keyed by (seed, read index): any shard can be
+ * regenerated anywhere.  pools are device arrays of n_pool * len ASCII bytes.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct scg_synth_spec {
+    uint64_t seed;
+    int64_t first_read;      /* global index of read 0 of this buffer (for sharding) */
+    int32_t read_len;
+    int32_t template_len;
+    const char* d_template;  /* device: template_len bytes, '-' at variable positions */
+    int32_t n_regions;       /* 1 or 2 */
+    int32_t region_start[2];
+    int32_t region_len[2];
+    const char* d_pool[2];   /* device: n_pool[r] * region_len[r] ASCII bytes */
+    int32_t n_pool[2];
+    /* index choice: independent uniform per region (pair_index NULL), or one uniform draw k over
+     * n_pairs rows of d_pair_index (int32 [n_pairs][2]) -- mate 1 uses column 0, mate 2 column 1;
+     * region_of_mate selects which column this buffer's single region takes. */
+    const int32_t* d_pair_index;
+    int32_t n_pairs;
+    int32_t pair_column;
+    float p_invalid_pair;    /* dual only: draw both columns independently with this probability */
+    float p_sub;             /* per-base substitution to a different base */
+    float p_n;               /* per-base replacement by 'N' */
+    float p_junk;            /* read carries no construct */
+    float p_reverse;         /* read is reverse-complemented */
+} scg_synth_spec;
+
+int scg_synth_reads(const scg_synth_spec* spec, char* d_seqs_out, int64_t n_reads, void* stream,
+                    char* err, size_t errcap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCG_H */

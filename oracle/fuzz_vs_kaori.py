@@ -1,0 +1,285 @@
+#!/usr/bin/env python3
+"""Randomised cross-check: C restatement (liboracle.so) vs the real kaori (_ref/libkaori_ref.so).
+
+Runs only where oracle/_ref was built (this container).  Not a pytest file: it is the
+tool used to pin the restatement before trusting it; tests/test_oracle_golden.py replays a
+committed subset (tests/golden/) without needing the reference.
+
+    python oracle/fuzz_vs_kaori.py [--iters 300] [--seed 1]
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import random
+import sys
+import tempfile
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle.pyoracle import KaoriRef, Oracle, OracleError, write_fastq  # noqa: E402
+
+BASES = "ACGT"
+COMP = {"A": "T", "C": "G", "G": "C", "T": "A", "N": "N", "a": "t", "c": "g", "g": "c", "t": "a", "n": "n"}
+IUPAC = "RYSWKMBDHVN"
+
+
+def rc(s: str) -> str:
+    return "".join(COMP.get(c, "N") for c in reversed(s))
+
+
+def rand_seq(rng: random.Random, n: int, alphabet: str = BASES) -> str:
+    return "".join(rng.choice(alphabet) for _ in range(n))
+
+
+def mutate(rng: random.Random, s: str, p_sub: float, p_n: float, p_lower: float) -> str:
+    out = []
+    for c in s:
+        if rng.random() < p_sub:
+            c = rng.choice([b for b in BASES if b != c.upper()])
+        if rng.random() < p_n:
+            c = rng.choice("NnRX.")  # any non-ACGT byte is "other" to the scanner
+        if rng.random() < p_lower:
+            c = c.lower()
+        out.append(c)
+    return "".join(out)
+
+
+def make_pool(rng: random.Random, n: int, length: int, alphabet: str, min_dist: int = 1, iupac_rate: float = 0.0):
+    """distinct sequences with pairwise Hamming distance >= min_dist (on the concrete bases)"""
+    pool: list[str] = []
+    tries = 0
+    while len(pool) < n and tries < 20000:
+        tries += 1
+        s = rand_seq(rng, length, alphabet)
+        if all(sum(a != b for a, b in zip(s, t)) >= min_dist for t in pool):
+            pool.append(s)
+    if iupac_rate > 0:
+        pool = ["".join(rng.choice(IUPAC) if rng.random() < iupac_rate else c for c in s) for s in pool]
+    return pool
+
+
+def make_template(rng: random.Random, nvar: int, var_lens: list[int], flank_lo: int, flank_hi: int) -> str:
+    parts = [rand_seq(rng, rng.randint(flank_lo, flank_hi))]
+    for v in range(nvar):
+        parts.append("-" * var_lens[v])
+        lo = max(flank_lo, 1) if v < nvar - 1 else flank_lo  # keep regions separate
+        parts.append(rand_seq(rng, rng.randint(lo, flank_hi)))
+    t = "".join(parts)
+    if rng.random() < 0.2:
+        t = t.lower()
+    return t
+
+
+def fill_template(template: str, inserts: list[str]) -> str:
+    out = []
+    it = iter(inserts)
+    i = 0
+    while i < len(template):
+        if template[i] == "-":
+            j = i
+            while j < len(template) and template[j] == "-":
+                j += 1
+            out.append(next(it))
+            i = j
+        else:
+            out.append(template[i].upper())
+            i += 1
+    return "".join(out)
+
+
+def concrete(rng: random.Random, s: str) -> str:
+    """pick one concrete expansion of an IUPAC library string"""
+    table = {"R": "AG", "Y": "CT", "S": "CG", "W": "AT", "K": "GT", "M": "AC", "B": "CGT", "D": "AGT", "H": "ACT", "V": "ACG", "N": "ACGT"}
+    return "".join(rng.choice(table[c]) if c in table else c for c in s.upper())
+
+
+def make_reads(rng, template, pools, n, strand, p_sub, p_n, p_lower, p_junk, pad_hi, valid_pairs=None):
+    reads = []
+    for _ in range(n):
+        if rng.random() < p_junk:
+            reads.append(rand_seq(rng, rng.randint(0, len(template) + pad_hi)))
+            continue
+        if valid_pairs is not None:
+            raise AssertionError
+        ins = [concrete(rng, rng.choice(p)) for p in pools]
+        core = fill_template(template, ins)
+        core = mutate(rng, core, p_sub, p_n, p_lower)
+        read = rand_seq(rng, rng.randint(0, pad_hi)) + core + rand_seq(rng, rng.randint(0, pad_hi))
+        if rng.random() < 0.1:  # two constructs in one read
+            ins2 = [concrete(rng, rng.choice(p)) for p in pools]
+            read += rand_seq(rng, rng.randint(0, 3)) + mutate(rng, fill_template(template, ins2), p_sub, p_n, p_lower)
+        if strand == 1 or (strand == 2 and rng.random() < 0.5):
+            read = rc(read)
+        reads.append(read)
+    return reads
+
+
+def fuzz_single(rng, ora, ref, tmpdir, it):
+    vlen = rng.choice([3, 4, 6, 8, 10, 20, 33])
+    alphabet = rng.choice(["AC", "ACG", BASES, BASES])
+    npool = rng.choice([1, 2, 5, 20, 100])
+    pool = make_pool(rng, npool, vlen, alphabet, min_dist=1, iupac_rate=rng.choice([0, 0, 0.05]))
+    template = make_template(rng, 1, [vlen], rng.choice([0, 1, 3]), rng.choice([4, 8, 12, 40]))
+    strand = rng.choice([0, 1, 2])
+    mm = rng.choice([0, 1, 1, 2, 3])
+    first = rng.random() < 0.5
+    reads = make_reads(rng, template, [pool], rng.choice([1, 30, 200]), strand, rng.choice([0, 0.02, 0.08]), rng.choice([0, 0.01, 0.05]),
+                       rng.choice([0, 0.3]), 0.1, rng.choice([0, 5, 30]))
+    fq = os.path.join(tmpdir, f"s{it}.fastq")
+    write_fastq(fq, reads, gz=rng.random() < 0.2)
+    try:
+        exp = ref.count_single(fq, template, strand, pool, mm, first, nthreads=rng.choice([1, 3]))
+    except OracleError as e:
+        try:
+            ora.count_single(reads, template, strand, pool, mm, first)
+        except OracleError:
+            return "both-error"
+        raise AssertionError(f"kaori errored ({e}) but oracle did not: {template} {pool}")
+    got = ora.count_single(reads, template, strand, pool, mm, first)
+    assert got[1] == exp[1], (got[1], exp[1])
+    if not np.array_equal(got[0], exp[0]):
+        raise AssertionError(f"single mismatch: tmpl={template} strand={strand} mm={mm} first={first}\npool={pool}\nreads={reads}\nexp={exp[0]}\ngot={got[0]}")
+    return "ok"
+
+
+def fuzz_combo(rng, ora, ref, tmpdir, it):
+    v0, v1 = rng.choice([3, 5, 8, 14]), rng.choice([3, 6, 14])
+    alphabet = rng.choice(["AC", BASES, BASES])
+    p0 = make_pool(rng, rng.choice([1, 4, 30]), v0, alphabet, iupac_rate=rng.choice([0, 0, 0.05]))
+    p1 = make_pool(rng, rng.choice([1, 4, 30]), v1, alphabet, iupac_rate=rng.choice([0, 0, 0.05]))
+    template = make_template(rng, 2, [v0, v1], rng.choice([0, 1, 3]), rng.choice([4, 8, 12]))
+    strand = rng.choice([0, 1, 2])
+    mm = rng.choice([0, 1, 2, 3])
+    first = rng.random() < 0.5
+    reads = make_reads(rng, template, [p0, p1], rng.choice([1, 30, 200]), strand, rng.choice([0, 0.03, 0.08]), rng.choice([0, 0.02]),
+                       rng.choice([0, 0.3]), 0.1, rng.choice([0, 5, 30]))
+    fq = os.path.join(tmpdir, f"c{it}.fastq")
+    write_fastq(fq, reads)
+    try:
+        exp = ref.count_combo(fq, template, strand, p0, p1, mm, first, nthreads=rng.choice([1, 3]))
+    except OracleError as e:
+        try:
+            ora.count_combo(reads, template, strand, p0, p1, mm, first)
+        except OracleError:
+            return "both-error"
+        raise AssertionError(f"kaori errored ({e}) but oracle did not")
+    got = ora.count_combo(reads, template, strand, p0, p1, mm, first)
+    ok = got[2] == exp[2] and np.array_equal(got[0], exp[0]) and np.array_equal(got[1], exp[1])
+    if not ok:
+        raise AssertionError(f"combo mismatch: tmpl={template} strand={strand} mm={mm} first={first}\np0={p0}\np1={p1}\nreads={reads}\nexp={exp}\ngot={got}")
+    return "ok"
+
+
+def fuzz_dual(rng, ora, ref, tmpdir, it, hazard_free=True):
+    l1, l2 = rng.choice([4, 6, 9, 12]), rng.choice([4, 7, 12])
+    mm1, mm2 = rng.choice([0, 1, 2]), rng.choice([0, 1, 2])
+    d1 = 2 * mm1 + 1 if hazard_free else 1
+    d2 = 2 * mm2 + 1 if hazard_free else 1
+    u1 = make_pool(rng, rng.choice([1, 3, 8]), l1, BASES, min_dist=d1)
+    u2 = make_pool(rng, rng.choice([1, 3, 8]), l2, BASES, min_dist=d2)
+    allpairs = [(a, b) for a in u1 for b in u2]
+    rng.shuffle(allpairs)
+    pairs = allpairs[: rng.randint(1, len(allpairs))]
+    pool1 = [a for a, _ in pairs]
+    pool2 = [b for _, b in pairs]
+    t1 = make_template(rng, 1, [l1], rng.choice([0, 2, 4]), rng.choice([4, 8]))
+    t2 = make_template(rng, 1, [l2], rng.choice([0, 2, 4]), rng.choice([4, 8]))
+    rev1, rev2 = rng.random() < 0.3, rng.random() < 0.3
+    randomized = rng.random() < 0.4
+    first = rng.random() < 0.5
+    n = rng.choice([1, 30, 150])
+    r1s, r2s = [], []
+    p_sub, p_n = rng.choice([0, 0.03, 0.08]), rng.choice([0, 0.02])
+    for _ in range(n):
+        u = rng.random()
+        if u < 0.1:
+            a, b = rand_seq(rng, rng.randint(0, 30)), rand_seq(rng, rng.randint(0, 30))
+        else:
+            if u < 0.8:
+                x, y = rng.choice(pairs)
+            else:
+                x, y = rng.choice(u1), rng.choice(u2)
+            a = fill_template(t1, [x])
+            b = fill_template(t2, [y])
+            a = mutate(rng, a, p_sub, p_n, 0.05)
+            b = mutate(rng, b, p_sub, p_n, 0.05)
+            pad = rng.choice([0, 4, 20])
+            a = rand_seq(rng, rng.randint(0, pad)) + a + rand_seq(rng, rng.randint(0, pad))
+            b = rand_seq(rng, rng.randint(0, pad)) + b + rand_seq(rng, rng.randint(0, pad))
+            if rng.random() < 0.1:
+                x2, _ = rng.choice(pairs)
+                a += mutate(rng, fill_template(t1, [x2]), p_sub, p_n, 0.0)
+            if rev1:
+                a = rc(a)
+            if rev2:
+                b = rc(b)
+            if randomized and rng.random() < 0.5:
+                a, b = b, a
+        r1s.append(a)
+        r2s.append(b)
+    fq1 = os.path.join(tmpdir, f"d{it}_1.fastq")
+    fq2 = os.path.join(tmpdir, f"d{it}_2.fastq")
+    write_fastq(fq1, r1s)
+    write_fastq(fq2, r2s)
+    exp = ref.count_dual(fq1, t1, rev1, mm1, pool1, fq2, t2, rev2, mm2, pool2, randomized, first, nthreads=1)
+    got = ora.count_dual(r1s, r2s, t1, rev1, mm1, pool1, t2, rev2, mm2, pool2, randomized, first)
+    ok = got[1] == exp[1] and np.array_equal(got[0], exp[0])
+    if not ok:
+        if not hazard_free:
+            return "hazard-diff"
+        raise AssertionError(f"dual mismatch: t1={t1} t2={t2} rev=({rev1},{rev2}) mm=({mm1},{mm2}) rand={randomized} first={first}\n"
+                             f"pool1={pool1}\npool2={pool2}\nr1={r1s}\nr2={r2s}\nexp={exp}\ngot={got}")
+    return "ok"
+
+
+def fuzz_match(rng, ora, ref):
+    vlen = rng.choice([3, 5, 8, 12])
+    alphabet = rng.choice(["AC", BASES])
+    pool = make_pool(rng, rng.choice([1, 4, 30]), vlen, alphabet, iupac_rate=rng.choice([0, 0.1]))
+    seqs = []
+    for _ in range(40):
+        s = concrete(rng, rng.choice(pool))
+        seqs.append(mutate(rng, s, 0.15, 0.03, 0.1))
+    subs = rng.choice([0, 1, 2, 3])
+    rev = rng.random() < 0.5
+    try:
+        exp = ref.match_barcodes(seqs, pool, subs, rev)
+    except OracleError:
+        try:
+            ora.match_barcodes(seqs, pool, subs, rev)
+        except OracleError:
+            return "both-error"
+        raise
+    got = ora.match_barcodes(seqs, pool, subs, rev)
+    if not (np.array_equal(got[0], exp[0]) and np.array_equal(got[1], exp[1])):
+        raise AssertionError(f"match mismatch pool={pool} seqs={seqs} subs={subs} rev={rev}\nexp={exp}\ngot={got}")
+    return "ok"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=300)
+    ap.add_argument("--seed", type=int, default=1)
+    args = ap.parse_args()
+    ora, ref = Oracle(), KaoriRef()
+    rng = random.Random(args.seed)
+    tally: dict[str, int] = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for it in range(args.iters):
+            for name, fn in (("single", lambda: fuzz_single(rng, ora, ref, tmp, it)),
+                             ("combo", lambda: fuzz_combo(rng, ora, ref, tmp, it)),
+                             ("dual", lambda: fuzz_dual(rng, ora, ref, tmp, it, True)),
+                             ("dual-hazard", lambda: fuzz_dual(rng, ora, ref, tmp, it, False)),
+                             ("match", lambda: fuzz_match(rng, ora, ref))):
+                res = fn()
+                tally[f"{name}:{res}"] = tally.get(f"{name}:{res}", 0) + 1
+            for f in os.listdir(tmp):
+                os.unlink(os.path.join(tmp, f))
+    for k in sorted(tally):
+        print(f"{k:28s} {tally[k]}")
+
+
+if __name__ == "__main__":
+    main()

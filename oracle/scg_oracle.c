@@ -1,0 +1,795 @@
+/*
+ * scg_oracle.c -- CPU restatement of the screenCounter/kaori barcode-counting hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product path (screencounter_amd/, include/)
+ * may include, link, import or execute this file.  It is used by tests/, by
+ * __graft_entry__.smoke() and by bench.py's cpu_baseline leg, and there only as the
+ * checker, never as the thing measured as "the framework" or shipped.
+ *
+ * Parity status: PINNED.  This restatement is checked (tests/test_oracle_golden.py)
+ * against (i) the hand-written known-answer vectors of the reference's own R tests
+ * (tests/testthat/test-single.R, test-matchBarcodes.R, test-dual.R, test-combo-single.R)
+ * and (ii) golden outputs produced by the real kaori v1.1.1 headers compiled from
+ * /root/reference by oracle/Makefile into oracle/_ref/ (generator: oracle/gen_golden.py,
+ * fixtures: tests/golden/).
+ *
+ * Style: deliberately brute force.  No tries, no caches, no rolling hashes -- each function
+ * states WHAT the reference computes, citing the reference file:line
+ * it restates, in the most obviously-correct form that still finishes in seconds at test
+ * sizes.  All paths below are relative to /root/reference/inst/include/kaori/ unless noted.
+ */
+#include <stdint.h>
+#include <stddef.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include <ctype.h>
+#include <zlib.h>
+
+#define SCGO_MISSING (-1)   /* MismatchTrie.hpp:47  STATUS_MISSING   */
+#define SCGO_AMBIG   (-2)   /* MismatchTrie.hpp:52  STATUS_AMBIGUOUS */
+
+/* ------------------------------------------------------------------------------------------
+ * Errors: every entry point returns 0 on success, non-zero + message on failure (the
+ * reference throws std::runtime_error; src/RcppExports.cpp END_RCPP turns that into R stop()).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct { char *buf; size_t cap; } errbuf;
+
+static int fail(errbuf *e, const char *fmt, ...) {
+    if (e && e->buf && e->cap) {
+        va_list ap; va_start(ap, fmt);
+        vsnprintf(e->buf, e->cap, fmt, ap);
+        va_end(ap);
+    }
+    return 1;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Bases.  utils.hpp:122-133 (is_standard_base), :140-161 (add_base_to_hash): A/C/G/T in either
+ * case are the only "standard" read bases; everything else is "other".
+ * ---------------------------------------------------------------------------------------- */
+static int base_code(char c) {
+    switch (c) {
+        case 'A': case 'a': return 0;
+        case 'C': case 'c': return 1;
+        case 'G': case 'g': return 2;
+        case 'T': case 't': return 3;
+        default: return -1;
+    }
+}
+
+/* IUPAC set of a LIBRARY base as a 4-bit mask (A=1,C=2,G=4,T=8).
+ * MismatchTrie.hpp:163-188 (expansion of each code), utils.hpp:41-120 (codes accepted by
+ * complement_base<true,true>).  Returns 0 for an unknown character. */
+static int iupac_set(char c) {
+    switch (toupper((unsigned char)c)) {
+        case 'A': return 1;  case 'C': return 2;  case 'G': return 4;  case 'T': return 8;
+        case 'R': return 1|4;   /* A,G */
+        case 'Y': return 2|8;   /* C,T */
+        case 'S': return 2|4;   /* C,G */
+        case 'W': return 1|8;   /* A,T */
+        case 'K': return 4|8;   /* G,T */
+        case 'M': return 1|2;   /* A,C */
+        case 'B': return 2|4|8; case 'D': return 1|4|8;
+        case 'H': return 1|2|8; case 'V': return 1|2|4;
+        case 'N': return 15;
+        default: return 0;
+    }
+}
+
+/* Complement of a set: A<->T, C<->G (utils.hpp:41-120 in set form). */
+static int set_complement(int s) {
+    return ((s & 1) << 3) | ((s & 2) << 1) | ((s & 4) >> 1) | ((s & 8) >> 3);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Template.  ScanTemplate.hpp:53-95 (constructor), :277-297 (variable regions).
+ * ---------------------------------------------------------------------------------------- */
+#define SCGO_MAX_TEMPLATE 256     /* src/count_single_barcodes.cpp:37-47 */
+#define SCGO_MAX_REGIONS  SCGO_MAX_TEMPLATE
+
+typedef struct {
+    int len;
+    int fwd, rev;                       /* strands searched: utils.hpp:33-39 */
+    int8_t fconst[SCGO_MAX_TEMPLATE];   /* base code at constant positions, -1 at variable ones */
+    int8_t rconst[SCGO_MAX_TEMPLATE];   /* same for the reverse-complemented template */
+    int nreg;
+    int fstart[SCGO_MAX_REGIONS], fend[SCGO_MAX_REGIONS];  /* forward variable regions */
+    int rstart[SCGO_MAX_REGIONS], rend[SCGO_MAX_REGIONS];  /* regions on the RC'd template */
+} tmpl_t;
+
+/* strand: 0 = forward, 1 = reverse, 2 = both (src/utils.cpp:33-41). */
+static int tmpl_init(tmpl_t *t, const char *s, int len, int strand, errbuf *e) {
+    if (len > SCGO_MAX_TEMPLATE) {
+        /* src/count_single_barcodes.cpp:46 */
+        return fail(e, "lacking compile-time support for constant regions longer than 256 bp");
+    }
+    memset(t, 0, sizeof(*t));
+    t->len = len;
+    t->fwd = (strand == 0 || strand == 2);
+    t->rev = (strand == 1 || strand == 2);
+    for (int i = 0; i < len; ++i) {
+        if (s[i] == '-') {
+            t->fconst[i] = -1;
+            t->rconst[len - 1 - i] = -1;
+        } else {
+            int c = base_code(s[i]);
+            if (c < 0) {
+                /* utils.hpp:156-158 / :117 */
+                return fail(e, "unknown base '%c'", s[i]);
+            }
+            t->fconst[i] = (int8_t)c;
+            t->rconst[len - 1 - i] = (int8_t)(3 - c);   /* complement: A<->T, C<->G */
+        }
+    }
+    /* maximal runs of '-' (ScanTemplate.hpp:287-297) */
+    t->nreg = 0;
+    for (int i = 0; i < len; ++i) {
+        if (t->fconst[i] < 0) {
+            if (t->nreg && t->fend[t->nreg - 1] == i) {
+                t->fend[t->nreg - 1] = i + 1;
+            } else {
+                t->fstart[t->nreg] = i; t->fend[t->nreg] = i + 1; ++t->nreg;
+            }
+        }
+    }
+    /* the same runs seen on the reverse-complemented template, ordered by start there
+     * (ScanTemplate.hpp:82-94): forward region k=[s,e) becomes [len-e, len-s), order reversed. */
+    for (int k = 0; k < t->nreg; ++k) {
+        int src = t->nreg - 1 - k;
+        t->rstart[k] = len - t->fend[src];
+        t->rend[k]   = len - t->fstart[src];
+    }
+    return 0;
+}
+
+/* Number of constant-region mismatches of the template placed at read[p..p+len).
+ * ScanTemplate.hpp:233-252: a non-ACGT read byte is one mismatch at a constant position and
+ * free at a variable position (mask). */
+static int const_mm(const tmpl_t *t, const char *read, int p, int reverse) {
+    const int8_t *ref = reverse ? t->rconst : t->fconst;
+    int mm = 0;
+    for (int i = 0; i < t->len; ++i) {
+        if (ref[i] >= 0 && base_code(read[p + i]) != ref[i]) ++mm;
+    }
+    return mm;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Library of known barcodes: BarcodeSearch.hpp:23-60 (fill_library), MismatchTrie.hpp:93-205
+ * (add, with IUPAC expansion and DuplicateAction::ERROR).
+ * Stored as 4 bit-planes per entry: plane c has bit p set iff base c is allowed at position p.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    int n, len, words;     /* words = ceil(len/64) */
+    uint64_t *planes;      /* [n][4][words] */
+} lib_t;
+
+static void lib_free(lib_t *L) { free(L->planes); L->planes = NULL; }
+
+static uint64_t *lib_plane(const lib_t *L, int i, int c) {
+    return L->planes + ((size_t)i * 4 + c) * L->words;
+}
+
+/* Duplicate detection.  With DuplicateAction::ERROR (SingleBarcodeSingleEnd.hpp:50;
+ * never overridden in src/) two entries that share one concrete expansion make the
+ * constructor throw (MismatchTrie.hpp:104-123).  We enumerate expansions explicitly. */
+typedef struct { char *s; int idx; } expn_t;
+static int g_cmp_len;
+static int expn_cmp(const void *a, const void *b) {
+    const expn_t *x = (const expn_t *)a, *y = (const expn_t *)b;
+    int c = memcmp(x->s, y->s, g_cmp_len);
+    if (c) return c;
+    return (x->idx > y->idx) - (x->idx < y->idx);
+}
+
+static int check_duplicates(const int8_t *sets, int n, int len, errbuf *e) {
+    /* count expansions */
+    double total = 0;
+    for (int i = 0; i < n; ++i) {
+        double m = 1;
+        for (int p = 0; p < len; ++p) m *= __builtin_popcount(sets[(size_t)i * len + p]);
+        total += m;
+    }
+    if (total > 2e7) return fail(e, "oracle: too many IUPAC expansions (%.0f)", total);
+    size_t tot = (size_t)total;
+    if (tot == 0) return 0;
+    char *arena = (char *)malloc(tot * (size_t)(len ? len : 1));
+    expn_t *xs = (expn_t *)malloc(tot * sizeof(expn_t));
+    if (!arena || !xs) { free(arena); free(xs); return fail(e, "oracle: out of memory"); }
+    size_t k = 0;
+    static const char B[4] = {'A', 'C', 'G', 'T'};
+    int *choice = (int *)malloc(sizeof(int) * (len + 1));
+    for (int i = 0; i < n; ++i) {
+        const int8_t *s = sets + (size_t)i * len;
+        /* odometer over the allowed bases at every position */
+        for (int p = 0; p < len; ++p) { int c = 0; while (!((s[p] >> c) & 1)) ++c; choice[p] = c; }
+        for (;;) {
+            char *dst = arena + k * len;
+            for (int p = 0; p < len; ++p) dst[p] = B[choice[p]];
+            xs[k].s = dst; xs[k].idx = i; ++k;
+            int p = len - 1;
+            for (; p >= 0; --p) {
+                int c = choice[p] + 1;
+                while (c < 4 && !((s[p] >> c) & 1)) ++c;
+                if (c < 4) { choice[p] = c; break; }
+                c = 0; while (!((s[p] >> c) & 1)) ++c; choice[p] = c;
+            }
+            if (p < 0) break;
+        }
+    }
+    free(choice);
+    g_cmp_len = len;
+    qsort(xs, k, sizeof(expn_t), expn_cmp);
+    /* The reference throws on the first collision met in insertion order: the smallest
+     * later index b, and for it the lexicographically first colliding expansion. */
+    int best_a = -1, best_b = -1; const char *best_s = NULL;
+    for (size_t i = 1; i < k; ++i) {
+        if (memcmp(xs[i].s, xs[i - 1].s, len) == 0 && xs[i].idx != xs[i - 1].idx) {
+            /* first of the run is the owner; the second distinct index is the thrower */
+            size_t j = i - 1;
+            while (j > 0 && memcmp(xs[j - 1].s, xs[i].s, len) == 0) --j;
+            int a = xs[j].idx, b = -1;
+            for (size_t m = j; m < k && memcmp(xs[m].s, xs[i].s, len) == 0; ++m) {
+                if (xs[m].idx != a) { b = xs[m].idx; break; }
+            }
+            if (b >= 0 && (best_b < 0 || b < best_b ||
+                           (b == best_b && memcmp(xs[i].s, best_s, len) < 0))) {
+                best_a = a; best_b = b; best_s = xs[i].s;
+            }
+        }
+    }
+    int rc = 0;
+    if (best_b >= 0) {
+        /* MismatchTrie.hpp:119-122 */
+        rc = fail(e, "duplicate sequences detected (%d, %d) when constructing the trie",
+                  best_a + 1, best_b + 1);
+    }
+    free(arena); free(xs);
+    return rc;
+}
+
+/* Build from per-position sets (already strand-adjusted). */
+static int lib_from_sets(lib_t *L, const int8_t *sets, int n, int len, errbuf *e) {
+    L->n = n; L->len = len; L->words = (len + 63) / 64; if (L->words == 0) L->words = 1;
+    L->planes = (uint64_t *)calloc((size_t)n * 4 * L->words + 1, sizeof(uint64_t));
+    if (!L->planes) return fail(e, "oracle: out of memory");
+    for (int i = 0; i < n; ++i) {
+        for (int p = 0; p < len; ++p) {
+            int s = sets[(size_t)i * len + p];
+            for (int c = 0; c < 4; ++c) {
+                if ((s >> c) & 1) lib_plane(L, i, c)[p >> 6] |= (uint64_t)1 << (p & 63);
+            }
+        }
+    }
+    return check_duplicates(sets, n, len, e);
+}
+
+/* Convert a pool of NUL-terminated strings into per-position sets; all must share one length
+ * (src/utils.cpp:5-23).  reverse => reverse complement each barcode (BarcodeSearch.hpp:36-43). */
+static int pool_to_sets(const char *const *pool, int n, int reverse, int8_t **out, int *len_out, errbuf *e) {
+    int len = n ? (int)strlen(pool[0]) : 0;
+    for (int i = 1; i < n; ++i) {
+        if ((int)strlen(pool[i]) != len) {
+            return fail(e, "variable regions should all have the same length (%d)", len);
+        }
+    }
+    int8_t *sets = (int8_t *)malloc((size_t)n * (len ? len : 1) + 1);
+    if (!sets) return fail(e, "oracle: out of memory");
+    for (int i = 0; i < n; ++i) {
+        for (int p = 0; p < len; ++p) {
+            int s = iupac_set(pool[i][p]);
+            if (!s) {
+                free(sets);
+                /* MismatchTrie.hpp:187 / utils.hpp:117 */
+                return fail(e, "unknown base '%c' detected when constructing the trie", pool[i][p]);
+            }
+            if (!reverse) sets[(size_t)i * len + p] = (int8_t)s;
+            else sets[(size_t)i * len + (len - 1 - p)] = (int8_t)set_complement(s);
+        }
+    }
+    *out = sets; *len_out = len;
+    return 0;
+}
+
+static int lib_init(lib_t *L, const char *const *pool, int n, int reverse, errbuf *e) {
+    int8_t *sets; int len;
+    int rc = pool_to_sets(pool, n, reverse, &sets, &len, e);
+    if (rc) { L->planes = NULL; return rc; }
+    rc = lib_from_sets(L, sets, n, len, e);
+    free(sets);
+    if (rc) lib_free(L);
+    return rc;
+}
+
+/* One-hot planes of a query taken from a read; non-ACGT bytes set no plane and therefore
+ * mismatch every library base (MismatchTrie.hpp:452-453). */
+static void query_planes(const char *q, int len, int words, uint64_t *qp /* [4][words] */) {
+    memset(qp, 0, sizeof(uint64_t) * 4 * words);
+    for (int p = 0; p < len; ++p) {
+        int c = base_code(q[p]);
+        if (c >= 0) qp[c * words + (p >> 6)] |= (uint64_t)1 << (p & 63);
+    }
+}
+
+static int entry_distance(const lib_t *L, int i, const uint64_t *qp, int from, int to) {
+    /* Hamming distance restricted to positions [from, to). */
+    int matched = 0;
+    for (int w = 0; w < L->words; ++w) {
+        uint64_t m = 0;
+        for (int c = 0; c < 4; ++c) m |= lib_plane(L, i, c)[w] & qp[c * L->words + w];
+        /* restrict to [from,to) */
+        int lo = w * 64, hi = lo + 64;
+        int a = from > lo ? from : lo, b = to < hi ? to : hi;
+        if (a >= b) continue;
+        uint64_t mask = (b - a == 64) ? ~(uint64_t)0 : ((((uint64_t)1 << (b - a)) - 1) << (a - lo));
+        matched += __builtin_popcountll(m & mask);
+    }
+    return (to - from) - matched;
+}
+
+/* match(q, cap): unique nearest entry within Hamming distance cap.
+ * MismatchTrie.hpp:446-501 (AnyMismatches::search), :266-343 (tie => STATUS_AMBIGUOUS),
+ * BarcodeSearch.hpp:243-251.  Caches there are semantics-neutral. */
+static void lib_match(const lib_t *L, const char *q, int cap, int *index, int *mm) {
+    uint64_t qp[4 * 4];
+    uint64_t *qpp = qp, *heap = NULL;
+    if (L->words > 4) { heap = (uint64_t *)malloc(sizeof(uint64_t) * 4 * L->words); qpp = heap; }
+    query_planes(q, L->len, L->words, qpp);
+    int best = cap + 1, idx = SCGO_MISSING;
+    for (int i = 0; i < L->n; ++i) {
+        int d = entry_distance(L, i, qpp, 0, L->len);
+        if (d < best) { best = d; idx = i; }
+        else if (d == best && d <= cap) { idx = SCGO_AMBIG; }
+    }
+    free(heap);
+    *index = idx; *mm = best;
+}
+
+/* seg_match(q1||q2, (cap1,cap2)): among entries within BOTH per-segment caps take the minimum
+ * total; tie => ambiguous.  MismatchTrie.hpp:577-660 (SegmentedMismatches<2>::search).
+ * Cache-free definition. */
+static void lib_seg_match(const lib_t *L, int len1, const char *q, int cap1, int cap2, int *index, int *total) {
+    uint64_t qp[4 * 4];
+    uint64_t *qpp = qp, *heap = NULL;
+    if (L->words > 4) { heap = (uint64_t *)malloc(sizeof(uint64_t) * 4 * L->words); qpp = heap; }
+    query_planes(q, L->len, L->words, qpp);
+    int best = cap1 + cap2 + 1, idx = SCGO_MISSING;
+    for (int i = 0; i < L->n; ++i) {
+        int d1 = entry_distance(L, i, qpp, 0, len1);
+        if (d1 > cap1) continue;
+        int d2 = entry_distance(L, i, qpp, len1, L->len);
+        if (d2 > cap2) continue;
+        int d = d1 + d2;
+        if (d < best) { best = d; idx = i; }
+        else if (d == best) { idx = SCGO_AMBIG; }
+    }
+    free(heap);
+    *index = idx; *total = best;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * matchBarcodes: src/match_barcodes.cpp:6-37.  index is 0-based here, -1 where R reports NA.
+ * ---------------------------------------------------------------------------------------- */
+int scgo_match_barcodes(const char *const *sequences, int nseq, const char *const *choices, int nchoices,
+                        int substitutions, int reverse, int32_t *index_out, int32_t *mm_out,
+                        char *err, size_t errcap) {
+    errbuf e = {err, errcap};
+    lib_t L;
+    if (lib_init(&L, choices, nchoices, reverse, &e)) return 1;
+    for (int i = 0; i < nseq; ++i) {
+        if ((int)strlen(sequences[i]) != L.len) {
+            lib_free(&L);
+            return fail(&e, "variable regions should all have the same length (%d)", L.len);
+        }
+        int idx, mm;
+        lib_match(&L, sequences[i], substitutions, &idx, &mm);
+        index_out[i] = idx >= 0 ? idx : -1;
+        mm_out[i] = idx >= 0 ? mm : -1;
+    }
+    lib_free(&L);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * countSingleBarcodes hot path.
+ *   src/count_single_barcodes.cpp:28-50, handlers/SingleBarcodeSingleEnd.hpp:93-104,
+ *   SimpleSingleMatch.hpp:61-97 (constructor checks), :200-245 (search_first), :259-306 (search_best).
+ * Reads arrive pre-parsed: concatenated bytes + n_reads+1 offsets (process_data.hpp:19-68).
+ * ---------------------------------------------------------------------------------------- */
+int scgo_count_single(const char *seqs, const uint64_t *offsets, int64_t n_reads,
+                      const char *tmpl, int tmpl_len, int strand,
+                      const char *const *pool, int n_pool, int max_mm, int use_first,
+                      int32_t *counts /* n_pool, zeroed here */, int32_t *total,
+                      char *err, size_t errcap) {
+    errbuf e = {err, errcap};
+    tmpl_t T;
+    if (tmpl_init(&T, tmpl, tmpl_len, strand, &e)) return 1;
+    if (T.nreg != 1) return fail(&e, "expected one variable region in the constant template");
+    int plen = n_pool ? (int)strlen(pool[0]) : 0;
+    /* equal-length check first (src/utils.cpp:15-17 runs before the handler is built) */
+    for (int i = 1; i < n_pool; ++i) {
+        if ((int)strlen(pool[i]) != plen)
+            return fail(&e, "variable regions should all have the same length (%d)", plen);
+    }
+    int vlen = T.fend[0] - T.fstart[0];
+    if (vlen != plen) {
+        return fail(&e, "length of barcode_pool sequences (%d) should be the same as the barcode_pool region (%d)", plen, vlen);
+    }
+    lib_t F = {0}, R = {0};
+    if (T.fwd && lib_init(&F, pool, n_pool, 0, &e)) return 1;
+    if (T.rev && lib_init(&R, pool, n_pool, 1, &e)) { lib_free(&F); return 1; }
+
+    memset(counts, 0, sizeof(int32_t) * (size_t)n_pool);
+    int32_t tot = 0;
+    for (int64_t r = 0; r < n_reads; ++r) {
+        const char *read = seqs + offsets[r];
+        int n = (int)(offsets[r + 1] - offsets[r]);
+        int found = 0, index = -1;
+        int best = max_mm + 1;
+        for (int p = 0; p + T.len <= n; ++p) {       /* ScanTemplate.hpp:153, :195-212 */
+            int stop = 0;
+            for (int s = 0; s < 2 && !stop; ++s) {   /* forward before reverse: SimpleSingleMatch.hpp:229-241 */
+                if (s == 0 ? !T.fwd : !T.rev) continue;
+                int c = const_mm(&T, read, p, s);
+                if (c > max_mm) continue;            /* has_match(): SimpleSingleMatch.hpp:169-171 */
+                const char *q = read + p + (s ? T.rstart[0] : T.fstart[0]);
+                int idx, d;
+                lib_match(s ? &R : &F, q, max_mm - c, &idx, &d);
+                if (idx < 0) continue;
+                int tmm = c + d;
+                if (use_first) {                     /* :207-224 */
+                    if (tmm > max_mm) continue;
+                    found = 1; index = idx; stop = 1;
+                } else {                             /* :265-289 */
+                    if (tmm == best) {
+                        if (index != idx) { found = 0; index = -1; }
+                    } else if (tmm < best) {
+                        found = 1; best = tmm; index = idx;
+                    }
+                }
+            }
+            if (stop) break;
+        }
+        if (found) ++counts[index];
+        ++tot;
+    }
+    *total = tot;
+    lib_free(&F); lib_free(&R);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * countComboBarcodes hot path (V = 2 in screenCounter: src/count_combo_barcodes_single.cpp:44-46).
+ *   handlers/CombinatorialBarcodesSingleEnd.hpp:70-117 (ctor), :149-186 (find_match),
+ *   :197-217 (process_first), :219-258 (process_best).
+ * Emits the matched tuples in read order into tuples[2*k], k < n_tuples; sort + run-length
+ * encoding (utils.hpp:173-198, src/utils.h:14-45) is scgo_combo_rle below.
+ * ---------------------------------------------------------------------------------------- */
+#define SCGO_V 2
+
+static int combo_find(const tmpl_t *T, const lib_t *libs /* [V], in scan order for this strand */,
+                      const char *read, int p, int reverse, int c, int max_mm, int32_t *temp, int *total_out) {
+    int obs = c;
+    for (int r = 0; r < SCGO_V; ++r) {
+        const char *q = read + p + (reverse ? T->rstart[r] : T->fstart[r]);
+        int idx, d;
+        lib_match(&libs[r], q, max_mm - obs, &idx, &d);          /* :168 */
+        if (idx < 0) return 0;
+        obs += d;
+        if (obs > max_mm) return 0;                               /* :173-176 */
+        if (reverse) temp[SCGO_V - 1 - r] = idx; else temp[r] = idx;   /* :178-182 */
+    }
+    *total_out = obs;
+    return 1;
+}
+
+int scgo_count_combo(const char *seqs, const uint64_t *offsets, int64_t n_reads,
+                     const char *tmpl, int tmpl_len, int strand,
+                     const char *const *pool0, int n0, const char *const *pool1, int n1,
+                     int max_mm, int use_first,
+                     int32_t *tuples /* capacity 2*n_reads */, int64_t *n_tuples, int32_t *total,
+                     char *err, size_t errcap) {
+    errbuf e = {err, errcap};
+    tmpl_t T;
+    if (tmpl_init(&T, tmpl, tmpl_len, strand, &e)) return 1;
+    const char *const *pools[SCGO_V] = {pool0, pool1};
+    int ns[SCGO_V] = {n0, n1};
+    int plen[SCGO_V];
+    for (int v = 0; v < SCGO_V; ++v) {
+        plen[v] = ns[v] ? (int)strlen(pools[v][0]) : 0;
+        for (int i = 1; i < ns[v]; ++i) {
+            if ((int)strlen(pools[v][i]) != plen[v])
+                return fail(&e, "variable regions should all have the same length (%d)", plen[v]);
+        }
+    }
+    if (T.nreg != SCGO_V) return fail(&e, "expected %d variable regions in the constant template", SCGO_V);
+    for (int v = 0; v < SCGO_V; ++v) {
+        int rlen = T.fend[v] - T.fstart[v];
+        if (rlen != plen[v]) {
+            return fail(&e, "length of variable region %d (%d) should be the same as its sequences (%d)", v + 1, rlen, plen[v]);
+        }
+    }
+    lib_t F[SCGO_V], R[SCGO_V];
+    memset(F, 0, sizeof(F)); memset(R, 0, sizeof(R));
+    int rc = 0;
+    if (T.fwd) for (int v = 0; v < SCGO_V && !rc; ++v) rc = lib_init(&F[v], pools[v], ns[v], 0, &e);
+    /* reverse scan order uses the pools back to front (:111-116) */
+    if (T.rev) for (int v = 0; v < SCGO_V && !rc; ++v) rc = lib_init(&R[v], pools[SCGO_V - 1 - v], ns[SCGO_V - 1 - v], 1, &e);
+    if (rc) { for (int v = 0; v < SCGO_V; ++v) { lib_free(&F[v]); lib_free(&R[v]); } return 1; }
+
+    int64_t nt = 0; int32_t tot = 0;
+    for (int64_t r = 0; r < n_reads; ++r) {
+        const char *read = seqs + offsets[r];
+        int n = (int)(offsets[r + 1] - offsets[r]);
+        int found = 0, best = max_mm + 1;
+        int32_t best_id[SCGO_V] = {0, 0}, temp[SCGO_V];
+        for (int p = 0; p + T.len <= n; ++p) {
+            int stop = 0;
+            for (int s = 0; s < 2 && !stop; ++s) {
+                if (s == 0 ? !T.fwd : !T.rev) continue;
+                int c = const_mm(&T, read, p, s);
+                if (c > max_mm) continue;                        /* :203, :210 */
+                int tmm;
+                if (!combo_find(&T, s ? R : F, read, p, s, c, max_mm, temp, &tmm)) continue;
+                if (use_first) {                                 /* :204-214 */
+                    found = 1; memcpy(best_id, temp, sizeof(temp)); stop = 1;
+                } else if (tmm <= best) {                        /* :225-241 */
+                    if (tmm == best) {
+                        if (memcmp(best_id, temp, sizeof(temp)) != 0) found = 0;
+                    } else {
+                        found = 1; best = tmm; memcpy(best_id, temp, sizeof(temp));
+                    }
+                }
+            }
+            if (stop) break;
+        }
+        if (found) { tuples[2 * nt] = best_id[0]; tuples[2 * nt + 1] = best_id[1]; ++nt; }
+        ++tot;
+    }
+    *n_tuples = nt; *total = tot;
+    for (int v = 0; v < SCGO_V; ++v) { lib_free(&F[v]); lib_free(&R[v]); }
+    return 0;
+}
+
+static int tuple_cmp(const void *a, const void *b) {
+    const int32_t *x = (const int32_t *)a, *y = (const int32_t *)b;
+    if (x[0] != y[0]) return (x[0] > y[0]) - (x[0] < y[0]);
+    return (x[1] > y[1]) - (x[1] < y[1]);
+}
+
+/* Sort by (first, second) and run-length encode in place: utils.hpp:173-198 + src/utils.h:14-45.
+ * On return tuples[0..2K) holds the K distinct tuples (column-major 2xK), freq[0..K) their counts. */
+int64_t scgo_combo_rle(int32_t *tuples, int64_t n_tuples, int32_t *freq) {
+    qsort(tuples, (size_t)n_tuples, 2 * sizeof(int32_t), tuple_cmp);
+    int64_t k = 0;
+    for (int64_t i = 0; i < n_tuples; ++i) {
+        if (k && tuples[2 * (k - 1)] == tuples[2 * i] && tuples[2 * (k - 1) + 1] == tuples[2 * i + 1]) {
+            ++freq[k - 1];
+        } else {
+            tuples[2 * k] = tuples[2 * i]; tuples[2 * k + 1] = tuples[2 * i + 1];
+            freq[k] = 1; ++k;
+        }
+    }
+    return k;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * countDualBarcodes hot path, non-diagnostic branch (src/count_dual_barcodes.cpp:38-51).
+ *   handlers/DualBarcodesPairedEnd.hpp:92-179 (ctor), :228-256 (inner_process),
+ *   :258-308 (process_first), :310-347 (process_best), :353-381 (process, randomized).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct { int pos; int mm; } hit_t;
+
+/* All positions of one mate whose constant mismatches are within max_mm on the configured
+ * strand, in order (inner_process called to exhaustion). */
+static int mate_hits(const tmpl_t *T, int reverse, int max_mm, const char *read, int n, hit_t *hits) {
+    int k = 0;
+    for (int p = 0; p + T->len <= n; ++p) {
+        int c = const_mm(T, read, p, reverse);
+        if (c <= max_mm) { hits[k].pos = p; hits[k].mm = c; ++k; }
+    }
+    return k;
+}
+
+typedef struct {
+    tmpl_t T1, T2;
+    int rev1, rev2, mm1, mm2, len1, len2;
+    lib_t L;    /* concatenated X1||X2 */
+} dual_t;
+
+/* One orientation: template 1 against `a`, template 2 against `b`. */
+static int dual_first(const dual_t *D, const char *a, int na, const char *b, int nb, hit_t *h1, hit_t *h2, char *comb) {
+    int k1 = mate_hits(&D->T1, D->rev1, D->mm1, a, na, h1);
+    if (!k1) return -1;
+    int k2 = mate_hits(&D->T2, D->rev2, D->mm2, b, nb, h2);
+    if (!k2) return -1;                                   /* :293-295 */
+    int o1 = D->rev1 ? D->T1.rstart[0] : D->T1.fstart[0];
+    int o2 = D->rev2 ? D->T2.rstart[0] : D->T2.fstart[0];
+    for (int i = 0; i < k1; ++i) {                        /* :283 */
+        memcpy(comb, a + h1[i].pos + o1, D->len1);
+        for (int j = 0; j < k2; ++j) {                    /* :288-292, :299-303 */
+            memcpy(comb + D->len1, b + h2[j].pos + o2, D->len2);
+            int idx, tot;
+            lib_seg_match(&D->L, D->len1, comb, D->mm1 - h1[i].mm, D->mm2 - h2[j].mm, &idx, &tot);   /* :268 */
+            if (idx >= 0) return idx;
+        }
+    }
+    return -1;
+}
+
+static void dual_best(const dual_t *D, const char *a, int na, const char *b, int nb, hit_t *h1, hit_t *h2, char *comb,
+                      int *chosen_out, int *best_out) {
+    int chosen = -1, best = D->mm1 + D->mm2 + 1;          /* :320-321 */
+    int k2 = mate_hits(&D->T2, D->rev2, D->mm2, b, nb, h2);
+    if (k2) {
+        int k1 = mate_hits(&D->T1, D->rev1, D->mm1, a, na, h1);
+        int o1 = D->rev1 ? D->T1.rstart[0] : D->T1.fstart[0];
+        int o2 = D->rev2 ? D->T2.rstart[0] : D->T2.fstart[0];
+        for (int i = 0; i < k1; ++i) {
+            memcpy(comb, a + h1[i].pos + o1, D->len1);
+            for (int j = 0; j < k2; ++j) {
+                memcpy(comb + D->len1, b + h2[j].pos + o2, D->len2);
+                int idx, tot;
+                lib_seg_match(&D->L, D->len1, comb, D->mm1 - h1[i].mm, D->mm2 - h2[j].mm, &idx, &tot);
+                if (idx >= 0) {                           /* :333-341 */
+                    int cur = tot + h1[i].mm + h2[j].mm;
+                    if (cur < best) { chosen = idx; best = cur; }
+                    else if (cur == best && chosen != idx) { chosen = -1; }
+                }
+            }
+        }
+    }
+    *chosen_out = chosen; *best_out = best;
+}
+
+int scgo_count_dual(const char *seqs1, const uint64_t *offs1, const char *seqs2, const uint64_t *offs2, int64_t n_pairs,
+                    const char *tmpl1, int tmpl_len1, int reverse1, int mm1, const char *const *pool1,
+                    const char *tmpl2, int tmpl_len2, int reverse2, int mm2, const char *const *pool2,
+                    int n_pool, int randomized, int use_first,
+                    int32_t *counts /* n_pool */, int32_t *total, char *err, size_t errcap) {
+    errbuf e = {err, errcap};
+    dual_t D;
+    memset(&D, 0, sizeof(D));
+    int8_t *s1 = NULL, *s2 = NULL;
+    /* src/count_dual_barcodes.cpp:93-97: both pools formatted (equal-length check) first */
+    if (pool_to_sets(pool1, n_pool, reverse1, &s1, &D.len1, &e)) return 1;
+    if (pool_to_sets(pool2, n_pool, reverse2, &s2, &D.len2, &e)) { free(s1); return 1; }
+    int rc = 0;
+    if (!rc) rc = tmpl_init(&D.T1, tmpl1, tmpl_len1, reverse1 ? 1 : 0, &e);
+    if (!rc) rc = tmpl_init(&D.T2, tmpl2, tmpl_len2, reverse2 ? 1 : 0, &e);
+    if (!rc && D.T1.nreg != 1) rc = fail(&e, "expected one variable region in the first constant template");
+    if (!rc && D.T1.fend[0] - D.T1.fstart[0] != D.len1)
+        rc = fail(&e, "length of variable sequences (%d) should be the same as the variable region (%d)", D.len1, D.T1.fend[0] - D.T1.fstart[0]);
+    if (!rc && D.T2.nreg != 1) rc = fail(&e, "expected one variable region in the second constant template");
+    if (!rc && D.T2.fend[0] - D.T2.fstart[0] != D.len2)
+        rc = fail(&e, "length of variable sequences (%d) should be the same as the variable region (%d)", D.len2, D.T2.fend[0] - D.T2.fstart[0]);
+    if (rc) { free(s1); free(s2); return 1; }
+    D.rev1 = reverse1 != 0; D.rev2 = reverse2 != 0; D.mm1 = mm1; D.mm2 = mm2;
+
+    int clen = D.len1 + D.len2;
+    int8_t *sc = (int8_t *)malloc((size_t)n_pool * (clen ? clen : 1) + 1);
+    for (int i = 0; i < n_pool; ++i) {                    /* :142-164 */
+        memcpy(sc + (size_t)i * clen, s1 + (size_t)i * D.len1, D.len1);
+        memcpy(sc + (size_t)i * clen + D.len1, s2 + (size_t)i * D.len2, D.len2);
+    }
+    free(s1); free(s2);
+    rc = lib_from_sets(&D.L, sc, n_pool, clen, &e);
+    free(sc);
+    if (rc) { lib_free(&D.L); return 1; }
+
+    /* hit buffers sized by the longest read */
+    uint64_t maxlen = 1;
+    for (int64_t r = 0; r < n_pairs; ++r) {
+        uint64_t a = offs1[r + 1] - offs1[r], b = offs2[r + 1] - offs2[r];
+        if (a > maxlen) maxlen = a;
+        if (b > maxlen) maxlen = b;
+    }
+    hit_t *h1 = (hit_t *)malloc(sizeof(hit_t) * (maxlen + 1)), *h2 = (hit_t *)malloc(sizeof(hit_t) * (maxlen + 1));
+    char *comb = (char *)malloc((size_t)clen + 1);
+
+    memset(counts, 0, sizeof(int32_t) * (size_t)n_pool);
+    int32_t tot = 0;
+    for (int64_t r = 0; r < n_pairs; ++r) {
+        const char *a = seqs1 + offs1[r]; int na = (int)(offs1[r + 1] - offs1[r]);
+        const char *b = seqs2 + offs2[r]; int nb = (int)(offs2[r + 1] - offs2[r]);
+        if (use_first) {                                  /* :356-360 */
+            int idx = dual_first(&D, a, na, b, nb, h1, h2, comb);
+            if (idx < 0 && randomized) idx = dual_first(&D, b, nb, a, na, h1, h2, comb);
+            if (idx >= 0) ++counts[idx];
+        } else {                                          /* :362-376 */
+            int c1, b1;
+            dual_best(&D, a, na, b, nb, h1, h2, comb, &c1, &b1);
+            if (randomized) {
+                int c2, b2;
+                dual_best(&D, b, nb, a, na, h1, h2, comb, &c2, &b2);
+                if (c1 < 0 || b1 > b2) { c1 = c2; b1 = b2; }
+                else if (b1 == b2 && c1 != c2) { c1 = -1; }
+            }
+            if (c1 >= 0) ++counts[c1];
+        }
+        ++tot;
+    }
+    *total = tot;
+    free(h1); free(h2); free(comb);
+    lib_free(&D.L);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * FASTQ records: FastqReader.hpp:42-110 over byteme::PerByte.
+ * zlib's gzread() passes plain files through untouched, which covers
+ * byteme/SomeFileReader.hpp:31-44 (gzip chosen by magic bytes 1f 8b, else raw).
+ * The caller frees *seqs_out / *offsets_out with scgo_free.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct { gzFile f; unsigned char buf[65536]; int n, i; int eof; } bytesrc;
+
+static int src_fill(bytesrc *s) {
+    if (s->eof) return 0;
+    int got = gzread(s->f, s->buf, sizeof(s->buf));
+    if (got <= 0) { s->eof = 1; s->n = s->i = 0; return 0; }
+    s->n = got; s->i = 0;
+    return 1;
+}
+/* PerByte semantics: valid()/get() on the current byte, advance() moves on. */
+static int src_valid(bytesrc *s) { return s->i < s->n; }
+static char src_get(bytesrc *s) { return (char)s->buf[s->i]; }
+static int src_advance(bytesrc *s) { ++s->i; if (s->i < s->n) return 1; return src_fill(s); }
+
+void scgo_free(void *p) { free(p); }
+
+int scgo_parse_fastq(const char *path, char **seqs_out, uint64_t **offsets_out, int64_t *n_reads_out,
+                     char *err, size_t errcap) {
+    errbuf e = {err, errcap};
+    bytesrc *s = (bytesrc *)calloc(1, sizeof(bytesrc));
+    s->f = gzopen(path, "rb");
+    if (!s->f) { free(s); return fail(&e, "failed to open file at '%s'", path); }
+    src_fill(s);
+
+    size_t scap = 1 << 20, slen = 0, ocap = 1 << 16; int64_t n = 0;
+    char *seqs = (char *)malloc(scap);
+    uint64_t *offs = (uint64_t *)malloc(ocap * sizeof(uint64_t));
+    offs[0] = 0;
+    int okay = src_valid(s);                    /* FastqReader.hpp:32 */
+    int line = 0, rc = 0;
+#define ADVANCE_OR_FAIL() do { if (!src_advance(s)) { rc = fail(&e, "premature end of the file at line %d", line + 1); goto done; } } while (0)
+    while (okay) {
+        int init_line = line;
+        char v = src_get(s);
+        if (v != '@') { rc = fail(&e, "read name should start with '@' (starting line %d)", init_line + 1); goto done; }
+        ADVANCE_OR_FAIL(); v = src_get(s);
+        while (!isspace((unsigned char)v)) { ADVANCE_OR_FAIL(); v = src_get(s); }
+        while (v != '\n') { ADVANCE_OR_FAIL(); v = src_get(s); }
+        ++line;
+        size_t start = slen;
+        ADVANCE_OR_FAIL(); v = src_get(s);
+        while (v != '+') {
+            if (v != '\n') {
+                if (slen + 1 > scap) { scap *= 2; seqs = (char *)realloc(seqs, scap); }
+                seqs[slen++] = v;
+            }
+            ADVANCE_OR_FAIL(); v = src_get(s);
+        }
+        ++line;
+        ADVANCE_OR_FAIL(); v = src_get(s);
+        while (v != '\n') { ADVANCE_OR_FAIL(); v = src_get(s); }
+        ++line;
+        size_t qual = 0, seqlen = slen - start;
+        okay = 0;
+        while (src_advance(s)) {
+            v = src_get(s);
+            if (v != '\n') ++qual;
+            else if (qual >= seqlen) { okay = src_advance(s); break; }
+        }
+        if (qual != seqlen) { rc = fail(&e, "non-equal lengths for quality and sequence strings (starting line %d)", init_line + 1); goto done; }
+        ++line;
+        if ((size_t)n + 2 > ocap) { ocap *= 2; offs = (uint64_t *)realloc(offs, ocap * sizeof(uint64_t)); }
+        offs[++n] = slen;
+    }
+done:
+    gzclose(s->f); free(s);
+    if (rc) { free(seqs); free(offs); return rc; }
+    *seqs_out = seqs; *offsets_out = offs; *n_reads_out = n;
+    return 0;
+}
