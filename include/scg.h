@@ -111,7 +111,7 @@ int scg_parse_fastq(const char* path, char** seqs_out, uint64_t** offsets_out, i
 /* ---------------------------------------------------------------------------------------------
  * Plans: a compiled (template, library, options) bound to one device, reusable across batches.
  * Replaces the construction of kaori::SingleBarcodeSingleEnd / CombinatorialBarcodesSingleEnd /
- * DualBarcodesPairedEnd (handlers/*.hpp) including all of their argument checks.
+ * DualBarcodesPairedEnd (inst/include/kaori/handlers/) including all of their argument checks.
  * device < 0 selects $SCG_DEVICE or, failing that, the current HIP device.
  * ------------------------------------------------------------------------------------------- */
 typedef struct scg_plan scg_plan;

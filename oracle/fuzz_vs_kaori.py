@@ -20,100 +20,8 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle.pyoracle import KaoriRef, Oracle, OracleError, write_fastq  # noqa: E402
 
-BASES = "ACGT"
-COMP = {"A": "T", "C": "G", "G": "C", "T": "A", "N": "N", "a": "t", "c": "g", "g": "c", "t": "a", "n": "n"}
-IUPAC = "RYSWKMBDHVN"
-
-
-def rc(s: str) -> str:
-    return "".join(COMP.get(c, "N") for c in reversed(s))
-
-
-def rand_seq(rng: random.Random, n: int, alphabet: str = BASES) -> str:
-    return "".join(rng.choice(alphabet) for _ in range(n))
-
-
-def mutate(rng: random.Random, s: str, p_sub: float, p_n: float, p_lower: float) -> str:
-    out = []
-    for c in s:
-        if rng.random() < p_sub:
-            c = rng.choice([b for b in BASES if b != c.upper()])
-        if rng.random() < p_n:
-            c = rng.choice("NnRX.")  # any non-ACGT byte is "other" to the scanner
-        if rng.random() < p_lower:
-            c = c.lower()
-        out.append(c)
-    return "".join(out)
-
-
-def make_pool(rng: random.Random, n: int, length: int, alphabet: str, min_dist: int = 1, iupac_rate: float = 0.0):
-    """distinct sequences with pairwise Hamming distance >= min_dist (on the concrete bases)"""
-    pool: list[str] = []
-    tries = 0
-    while len(pool) < n and tries < 20000:
-        tries += 1
-        s = rand_seq(rng, length, alphabet)
-        if all(sum(a != b for a, b in zip(s, t)) >= min_dist for t in pool):
-            pool.append(s)
-    if iupac_rate > 0:
-        pool = ["".join(rng.choice(IUPAC) if rng.random() < iupac_rate else c for c in s) for s in pool]
-    return pool
-
-
-def make_template(rng: random.Random, nvar: int, var_lens: list[int], flank_lo: int, flank_hi: int) -> str:
-    parts = [rand_seq(rng, rng.randint(flank_lo, flank_hi))]
-    for v in range(nvar):
-        parts.append("-" * var_lens[v])
-        lo = max(flank_lo, 1) if v < nvar - 1 else flank_lo  # keep regions separate
-        parts.append(rand_seq(rng, rng.randint(lo, flank_hi)))
-    t = "".join(parts)
-    if rng.random() < 0.2:
-        t = t.lower()
-    return t
-
-
-def fill_template(template: str, inserts: list[str]) -> str:
-    out = []
-    it = iter(inserts)
-    i = 0
-    while i < len(template):
-        if template[i] == "-":
-            j = i
-            while j < len(template) and template[j] == "-":
-                j += 1
-            out.append(next(it))
-            i = j
-        else:
-            out.append(template[i].upper())
-            i += 1
-    return "".join(out)
-
-
-def concrete(rng: random.Random, s: str) -> str:
-    """pick one concrete expansion of an IUPAC library string"""
-    table = {"R": "AG", "Y": "CT", "S": "CG", "W": "AT", "K": "GT", "M": "AC", "B": "CGT", "D": "AGT", "H": "ACT", "V": "ACG", "N": "ACGT"}
-    return "".join(rng.choice(table[c]) if c in table else c for c in s.upper())
-
-
-def make_reads(rng, template, pools, n, strand, p_sub, p_n, p_lower, p_junk, pad_hi, valid_pairs=None):
-    reads = []
-    for _ in range(n):
-        if rng.random() < p_junk:
-            reads.append(rand_seq(rng, rng.randint(0, len(template) + pad_hi)))
-            continue
-        if valid_pairs is not None:
-            raise AssertionError
-        ins = [concrete(rng, rng.choice(p)) for p in pools]
-        core = fill_template(template, ins)
-        core = mutate(rng, core, p_sub, p_n, p_lower)
-        read = rand_seq(rng, rng.randint(0, pad_hi)) + core + rand_seq(rng, rng.randint(0, pad_hi))
-        if rng.random() < 0.1:  # two constructs in one read
-            ins2 = [concrete(rng, rng.choice(p)) for p in pools]
-            read += rand_seq(rng, rng.randint(0, 3)) + mutate(rng, fill_template(template, ins2), p_sub, p_n, p_lower)
-        if strand == 1 or (strand == 2 and rng.random() < 0.5):
-            read = rc(read)
-        reads.append(read)
-    return reads
+from tests.gen import (BASES, concrete, fill_template, make_pool, make_reads, make_template, mutate,  # noqa: E402
+                       rand_seq, rc)
 
 
 def fuzz_single(rng, ora, ref, tmpdir, it):

@@ -1,0 +1,19 @@
+"""screencounter_amd -- MI355X-native barcode counting engine behind screenCounter's hot path.
+
+Package contents (only what the path needs):
+  csrc/      HIP kernels (gfx950) + host runtime + the C ABI of include/scg.h -> libscg.so
+  _lib.py    ctypes binding of libscg.so (fails loudly when the library is missing)
+  engine.py  Plan objects over device-resident read batches
+  api.py     mirrors of the reference's Rcpp-level and R-level entry points for this path
+  synth.py   synthetic workloads of SURVEY.md section 8(d) (device-side generator)
+  parallel.py  read-sharded multi-GPU driver (torch.distributed over RCCL)
+"""
+from ._lib import ScgError, load  # noqa: F401
+from .api import (  # noqa: F401
+    count_single_barcodes, count_combo_barcodes_single, count_dual_barcodes, match_barcodes, parse_fastq,
+    countSingleBarcodes, countComboBarcodes, countDualBarcodes, matchBarcodes,
+    matrixOfSingleBarcodes, matrixOfComboBarcodes, matrixOfDualBarcodes, combineComboCounts, parseBarcodeTemplate,
+)
+from .engine import Plan, combo_compact, upload_reads  # noqa: F401
+
+__version__ = "0.1.0"

@@ -1,0 +1,316 @@
+"""Host-side mirror of the reference's operator interface for the hot path.
+
+Two layers, same names and argument meaning as the reference so that tests read like its own:
+
+* Rcpp level (R/RcppExports.R:4-26 of the reference): ``count_single_barcodes``,
+  ``count_combo_barcodes_single``, ``count_dual_barcodes``, ``match_barcodes`` -- positional
+  arguments and return tuples identical to the ``Rcpp::List`` the reference returns
+  (0-based indices, int32 counts, scalar total).
+* R level: ``countSingleBarcodes`` (R/countSingleBarcodes.R:82-105), ``countComboBarcodes``
+  (R/countComboBarcodes.R:87-124), ``countDualBarcodes`` (R/countDualBarcodes.R:118-160) and
+  ``matchBarcodes`` (R/matchBarcodes.R) -- template construction from flanks, ``N`` -> ``-``,
+  strand names, 1-based indices, and the ``matrixOf*`` multi-file wrappers.  R's
+  DataFrame/SummarizedExperiment become plain dataclasses with the same column names.
+
+Everything is computed by libscg on the GPU; errors the reference raises as R errors surface
+as ``ScgError``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import ScgError, check, cstr_array, errbuf
+
+_STRAND = {"original": 0, "reverse": 1, "both": 2}
+
+
+# =============================================================================================
+# Rcpp level
+# =============================================================================================
+def count_single_barcodes(path: str, constant: str, strand: int, pool: Sequence[str], mismatches: int,
+                          use_first: bool, nthreads: int = 1):
+    """src/count_single_barcodes.cpp:28-50 -> (counts int32[len(pool)], total)."""
+    L = _lib.load()
+    counts = np.zeros(max(len(pool), 1), dtype=np.int32)
+    total = C.c_int32(0)
+    err = errbuf()
+    parr, _keep = cstr_array(pool)
+    check(L.scg_count_single_barcodes(os.fspath(path).encode(), constant.encode(), int(strand), parr, len(pool),
+                                      int(mismatches), int(bool(use_first)), int(nthreads),
+                                      counts.ctypes.data_as(_lib.i32_p), C.byref(total), err, _lib.ERRCAP), err)
+    return counts[:len(pool)].copy(), int(total.value)
+
+
+def count_combo_barcodes_single(path: str, constant: str, strand: int, pool: Sequence[Sequence[str]], mismatches: int,
+                                use_first: bool, nthreads: int = 1):
+    """src/count_combo_barcodes_single.cpp:39-70 -> (indices int32[2, K] 0-based, freq int32[K], total)."""
+    if len(pool) != 2:
+        # src/count_combo_barcodes_single.cpp:44-46
+        raise ScgError(_lib.SCG_ERR_INVALID, "currently expecting only 2 variable regions for single-end combinatorial barcodes")
+    L = _lib.load()
+    idx_p = _lib.i32_p()
+    freq_p = _lib.i32_p()
+    k = C.c_int64(0)
+    total = C.c_int32(0)
+    err = errbuf()
+    p0, _k0 = cstr_array(pool[0])
+    p1, _k1 = cstr_array(pool[1])
+    check(L.scg_count_combo_barcodes_single(os.fspath(path).encode(), constant.encode(), int(strand), p0, len(pool[0]), p1, len(pool[1]),
+                                            int(mismatches), int(bool(use_first)), int(nthreads),
+                                            C.byref(idx_p), C.byref(freq_p), C.byref(k), C.byref(total), err, _lib.ERRCAP), err)
+    K = int(k.value)
+    try:
+        idx = np.ctypeslib.as_array(idx_p, shape=(max(2 * K, 1),))[:2 * K].reshape(K, 2).T.copy()
+        freq = np.ctypeslib.as_array(freq_p, shape=(max(K, 1),))[:K].copy()
+    finally:
+        L.scg_free(idx_p)
+        L.scg_free(freq_p)
+    return idx.astype(np.int32), freq.astype(np.int32), int(total.value)
+
+
+def count_dual_barcodes(path1: str, constant1: str, reverse1: bool, mismatches1: int, pool1: Sequence[str],
+                        path2: str, constant2: str, reverse2: bool, mismatches2: int, pool2: Sequence[str],
+                        randomized: bool, use_first: bool, diagnostics: bool = False, nthreads: int = 1):
+    """src/count_dual_barcodes.cpp:74-117 (non-diagnostic branch) -> (counts int32[n pairs], total)."""
+    if len(pool1) != len(pool2):
+        # kaori/handlers/DualBarcodesPairedEnd.hpp:106-109
+        raise ScgError(_lib.SCG_ERR_INVALID, "both barcode pools should be of the same length")
+    L = _lib.load()
+    counts = np.zeros(max(len(pool1), 1), dtype=np.int32)
+    total = C.c_int32(0)
+    err = errbuf()
+    p1, _k1 = cstr_array(pool1)
+    p2, _k2 = cstr_array(pool2)
+    check(L.scg_count_dual_barcodes(os.fspath(path1).encode(), constant1.encode(), int(bool(reverse1)), int(mismatches1), p1,
+                                    os.fspath(path2).encode(), constant2.encode(), int(bool(reverse2)), int(mismatches2), p2,
+                                    len(pool1), int(bool(randomized)), int(bool(use_first)), int(bool(diagnostics)), int(nthreads),
+                                    counts.ctypes.data_as(_lib.i32_p), C.byref(total), err, _lib.ERRCAP), err)
+    return counts[:len(pool1)].copy(), int(total.value)
+
+
+def match_barcodes(sequences: Sequence[str], choices: Sequence[str], substitutions: int = 0, reverse: bool = False):
+    """src/match_barcodes.cpp:6-37 -> (index int32[n] 0-based with -1 for NA, mismatches int32[n] with -1 for NA)."""
+    L = _lib.load()
+    n = len(sequences)
+    idx = np.zeros(max(n, 1), dtype=np.int32)
+    mm = np.zeros(max(n, 1), dtype=np.int32)
+    err = errbuf()
+    sa, _k = cstr_array(sequences)
+    ca, _k2 = cstr_array(choices)
+    check(L.scg_match_barcodes(sa, n, ca, len(choices), int(substitutions), int(bool(reverse)),
+                               idx.ctypes.data_as(_lib.i32_p), mm.ctypes.data_as(_lib.i32_p), err, _lib.ERRCAP), err)
+    return idx[:n].copy(), mm[:n].copy()
+
+
+def parse_fastq(path: str):
+    """kaori/FastqReader.hpp:42-110 -> (uint8 sequence bytes, uint64 offsets[n + 1])."""
+    L = _lib.load()
+    seqs_p = C.c_void_p()
+    offs_p = C.c_void_p()
+    n = C.c_int64(0)
+    err = errbuf()
+    check(L.scg_parse_fastq(os.fspath(path).encode(), C.byref(seqs_p), C.byref(offs_p), C.byref(n), err, _lib.ERRCAP), err)
+    try:
+        offs = np.ctypeslib.as_array(C.cast(offs_p, C.POINTER(C.c_uint64)), shape=(n.value + 1,)).copy()
+        nb = int(offs[-1])
+        seqs = np.ctypeslib.as_array(C.cast(seqs_p, C.POINTER(C.c_uint8)), shape=(max(nb, 1),))[:nb].copy()
+    finally:
+        L.scg_free(seqs_p)
+        L.scg_free(offs_p)
+    return seqs, offs
+
+
+# =============================================================================================
+# R level
+# =============================================================================================
+@dataclass
+class BarcodeCounts:
+    """countSingleBarcodes(): DataFrame(choices, counts) + metadata$nreads."""
+    choices: List[str]
+    counts: np.ndarray
+    nreads: int
+
+
+@dataclass
+class ComboCounts:
+    """countComboBarcodes(): DataFrame(combinations = DataFrame(first, second), counts) + metadata$nreads.
+    `first`/`second` hold 1-based indices (indices=True) or the barcode sequences."""
+    names: List[str]
+    combinations: Dict[str, list]
+    counts: np.ndarray
+    nreads: int
+
+
+@dataclass
+class DualCounts:
+    """countDualBarcodes(): `choices` with a counts column + metadata$npairs."""
+    choices: Dict[str, List[str]]
+    counts: np.ndarray
+    npairs: int
+
+
+@dataclass
+class CountMatrix:
+    """matrixOf*(): SummarizedExperiment(counts; rowData; colData)."""
+    counts: np.ndarray                 # rows x files
+    row_data: Dict[str, list]
+    col_data: Dict[str, list]
+    rownames: Optional[List[str]] = None
+    colnames: Optional[List[str]] = None
+    metadata: dict = field(default_factory=dict)
+
+
+def _strand_code(strand: str) -> int:
+    if strand not in _STRAND:
+        raise ValueError("'strand' should be one of 'both', 'original', 'reverse'")
+    return _STRAND[strand]
+
+
+def countSingleBarcodes(fastq: str, choices: Sequence[str], flank5: str = "", flank3: str = "", template: Optional[str] = None,
+                        substitutions: int = 0, find_best: bool = False, strand: str = "both", num_threads: int = 1) -> BarcodeCounts:
+    """R/countSingleBarcodes.R:82-105."""
+    choices = list(choices)
+    if template is not None:
+        template = template.replace("N", "-")                       # :93
+    else:
+        template = flank5 + "-" * (len(choices[0]) if choices else 0) + flank3   # :95-97
+    counts, total = count_single_barcodes(fastq, template, _strand_code(strand), choices, substitutions, not find_best, num_threads)
+    return BarcodeCounts(choices=choices, counts=counts, nreads=total)
+
+
+def matrixOfSingleBarcodes(files: Sequence[str], choices: Sequence[str], withDimnames: bool = True, **kwargs) -> CountMatrix:
+    """R/countSingleBarcodes.R:112-126 (files are processed one after another on the GPU)."""
+    out = [countSingleBarcodes(f, choices, **kwargs) for f in files]
+    mat = np.stack([o.counts for o in out], axis=1) if out else np.zeros((len(choices), 0), dtype=np.int32)
+    se = CountMatrix(counts=mat, row_data={"choices": list(choices)},
+                     col_data={"paths": list(files), "nreads": [o.nreads for o in out], "nmapped": mat.sum(axis=0).astype(np.int64).tolist()})
+    if withDimnames:
+        se.rownames = list(choices)
+        se.colnames = [os.path.basename(f) for f in files]
+    return se
+
+
+def parseBarcodeTemplate(template: str):
+    """R/parseBarcodeTemplate.R:29-44: positions (1-based) and lengths of the N runs, and the constant pieces."""
+    pos, lens = [], []
+    for m in re.finditer(r"N+", template):
+        pos.append(m.start() + 1)
+        lens.append(m.end() - m.start())
+    constants = re.split(r"N+", template)
+    return {"variable": {"pos": pos, "len": lens}, "constant": constants}
+
+
+def countComboBarcodes(fastq: str, template: str, choices, substitutions: int = 0, find_best: bool = False,
+                       strand: str = "both", num_threads: int = 1, indices: bool = False) -> ComboCounts:
+    """R/countComboBarcodes.R:87-124.  `choices` is a list of two pools or a dict name -> pool."""
+    if isinstance(choices, dict):
+        names = list(choices.keys())
+        pools = [list(v) for v in choices.values()]
+    else:
+        names = ["first", "second"]
+        pools = [list(v) for v in choices]
+    parsed = parseBarcodeTemplate(template)
+    n_len = parsed["variable"]["len"]
+    nvariables = len(n_len)
+    if nvariables != 2:                                             # :105-107
+        raise ScgError(_lib.SCG_ERR_INVALID, f"'length(choices)={nvariables}' is not currently supported")
+    if nvariables != len(pools):                                    # :108-110
+        raise ScgError(_lib.SCG_ERR_INVALID, "'length(choices)' is not equal to the number of variable regions in 'template'")
+    for i in range(nvariables):                                     # :111-115
+        if not all(len(s) == n_len[i] for s in pools[i]):
+            raise ScgError(_lib.SCG_ERR_INVALID, "each column of 'choices' must have same width as variable region in 'template'")
+    idx, freq, total = count_combo_barcodes_single(fastq, template.replace("N", "-"), _strand_code(strand), pools,
+                                                   substitutions, not find_best, num_threads)
+    keys = idx + 1                                                  # :128
+    combos: Dict[str, list] = {}
+    for i, nm in enumerate(names):
+        col = keys[i].tolist()
+        combos[nm] = col if indices else [pools[i][k - 1] for k in col]   # :136-140
+    return ComboCounts(names=names, combinations=combos, counts=freq, nreads=total)
+
+
+def combineComboCounts(*results: ComboCounts):
+    """R/combineComboCounts.R:31-57: union of combinations (sorted), one count column per input."""
+    names = results[0].names if results else ["first", "second"]
+    keys = sorted({tuple(r.combinations[nm][j] for nm in names) for r in results for j in range(len(r.counts))})
+    pos = {k: i for i, k in enumerate(keys)}
+    mat = np.zeros((len(keys), len(results)), dtype=np.int32)
+    for c, r in enumerate(results):
+        for j in range(len(r.counts)):
+            mat[pos[tuple(r.combinations[nm][j] for nm in names)], c] = r.counts[j]
+    combos = {nm: [k[i] for k in keys] for i, nm in enumerate(names)}
+    return combos, mat
+
+
+def matrixOfComboBarcodes(files: Sequence[str], withDimnames: bool = True, **kwargs) -> CountMatrix:
+    """R/countComboBarcodes.R:149-164."""
+    out = [countComboBarcodes(f, **kwargs) for f in files]
+    combos, mat = combineComboCounts(*out)
+    se = CountMatrix(counts=mat, row_data=combos,
+                     col_data={"paths": list(files), "nreads": [o.nreads for o in out], "nmapped": mat.sum(axis=0).astype(np.int64).tolist()})
+    if withDimnames:
+        se.colnames = [os.path.basename(f) for f in files]
+        se.rownames = [f"BARCODE_{i + 1}" for i in range(mat.shape[0])]
+    return se
+
+
+def _rep2(x):
+    if isinstance(x, (str, bytes)) or not hasattr(x, "__len__"):
+        return [x, x]
+    x = list(x)
+    return [x[i % len(x)] for i in range(2)]
+
+
+def countDualBarcodes(fastq: Sequence[str], choices, flank5=None, flank3=None, template=None, substitutions=0,
+                      find_best: bool = False, strand="original", randomized: bool = False, include_invalid: bool = False,
+                      num_threads: int = 1) -> DualCounts:
+    """R/countDualBarcodes.R:118-160.  `choices` is a dict / pair of two equally long columns."""
+    if isinstance(choices, dict):
+        names = list(choices.keys())
+        col1, col2 = [list(v) for v in choices.values()]
+    else:
+        names = ["first", "second"]
+        col1, col2 = list(choices[0]), list(choices[1])
+    if template is not None:                                        # :162-174
+        t = _rep2(template)
+        template1, template2 = re.sub("[nN]", "-", t[0]), re.sub("[nN]", "-", t[1])
+    else:
+        f5, f3 = _rep2(flank5), _rep2(flank3)
+        template1 = f5[0] + "-" * len(col1[0]) + f3[0]
+        template2 = f5[1] + "-" * len(col2[0]) + f3[1]
+    subs = _rep2(substitutions)
+    strands = _rep2(strand)
+    for s in strands:                                               # :176-182
+        if s not in ("original", "reverse"):
+            raise ValueError("'strand' should be one of 'original', 'reverse'")
+    counts, total = count_dual_barcodes(fastq[0], template1, strands[0] == "reverse", int(subs[0]), col1,
+                                        fastq[1], template2, strands[1] == "reverse", int(subs[1]), col2,
+                                        randomized, not find_best, include_invalid, num_threads)
+    return DualCounts(choices={names[0]: col1, names[1]: col2}, counts=counts, npairs=total)
+
+
+def matrixOfDualBarcodes(files: Sequence[Sequence[str]], choices, withDimnames: bool = True, **kwargs) -> CountMatrix:
+    """R/countDualBarcodes.R:205-224 (include.invalid=FALSE)."""
+    out = [countDualBarcodes(f, choices, **kwargs) for f in files]
+    nrow = len(out[0].counts) if out else 0
+    mat = np.stack([o.counts for o in out], axis=1) if out else np.zeros((nrow, 0), dtype=np.int32)
+    se = CountMatrix(counts=mat, row_data=out[0].choices if out else {},
+                     col_data={"paths1": [f[0] for f in files], "paths2": [f[1] for f in files], "npairs": [o.npairs for o in out]})
+    if withDimnames:
+        se.colnames = [os.path.basename(f[0]) for f in files]
+    return se
+
+
+def matchBarcodes(sequences: Sequence[str], choices: Sequence[str], substitutions: int = 0, reverse: bool = False):
+    """R/matchBarcodes.R: 1-based index / mismatches with None for NA."""
+    idx, mm = match_barcodes(sequences, choices, substitutions, reverse)
+    index = [int(i) + 1 if i >= 0 else None for i in idx]
+    mism = [int(m) if i >= 0 else None for i, m in zip(idx, mm)]
+    return {"index": index, "mismatches": mism}

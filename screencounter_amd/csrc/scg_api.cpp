@@ -1,0 +1,733 @@
+// scg_api.cpp -- the C ABI (include/scg.h): plans, batch launches, FASTQ-to-counts pipelines.
+//
+// Host-side counterpart of the reference's Rcpp glue (src/count_single_barcodes.cpp,
+// src/count_combo_barcodes_single.cpp, src/count_dual_barcodes.cpp, src/match_barcodes.cpp) and of
+// its chunked driver (inst/include/kaori/process_data.hpp:105-190, :224-340): instead of handing
+// 100 000-read chunks to std::threads, batches are staged through pinned buffers into HBM on two
+// HIP streams and counted by the kernels of scg_kernels.hip.
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "scg_host.h"
+#include "scg_launch.h"
+
+using scg::Error;
+
+namespace {
+
+#define HIP_CHECK(expr)                                                                              \
+    do {                                                                                             \
+        hipError_t e_ = (expr);                                                                      \
+        if (e_ != hipSuccess) {                                                                      \
+            throw Error(SCG_ERR_DEVICE, std::string(#expr) + " failed: " + hipGetErrorString(e_));   \
+        }                                                                                            \
+    } while (0)
+
+void copy_err(char* err, size_t cap, const char* msg) {
+    if (err && cap) {
+        std::strncpy(err, msg, cap - 1);
+        err[cap - 1] = '\0';
+    }
+}
+
+template<class F>
+int guarded(char* err, size_t cap, F f) {
+    try {
+        f();
+        if (err && cap) err[0] = '\0';
+        return SCG_OK;
+    } catch (const Error& e) {
+        copy_err(err, cap, e.what());
+        return e.code;
+    } catch (const std::bad_alloc&) {
+        copy_err(err, cap, "out of host memory");
+        return SCG_ERR_DEVICE;
+    } catch (const std::exception& e) {
+        copy_err(err, cap, e.what());
+        return SCG_ERR_INVALID;
+    } catch (...) {
+        copy_err(err, cap, "unknown error");
+        return SCG_ERR_INVALID;
+    }
+}
+
+int resolve_device(int device) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        throw Error(SCG_ERR_DEVICE, "no HIP device available: libscg has no CPU fallback");
+    }
+    if (device < 0) {
+        const char* env = std::getenv("SCG_DEVICE");
+        if (env && *env) {
+            device = std::atoi(env);
+        } else {
+            HIP_CHECK(hipGetDevice(&device));
+        }
+    }
+    if (device < 0 || device >= n) {
+        throw Error(SCG_ERR_DEVICE, "HIP device " + std::to_string(device) + " out of range (" + std::to_string(n) + " visible)");
+    }
+    return device;
+}
+
+// Makes `device` current for the calling thread for the lifetime of the guard.
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int device) {
+        HIP_CHECK(hipGetDevice(&prev));
+        if (prev != device) HIP_CHECK(hipSetDevice(device)); else prev = -1;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    DevBuf() {}
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }
+    void release() { if (p) { (void)hipFree(p); p = nullptr; bytes = 0; } }
+    void alloc(size_t n) {
+        release();
+        if (n == 0) n = 16;
+        HIP_CHECK(hipMalloc(&p, n));
+        bytes = n;
+    }
+    void ensure(size_t n) { if (n > bytes) alloc(n + n / 4); }
+    template<class T> void upload(const std::vector<T>& v) {
+        alloc(v.size() * sizeof(T));
+        if (!v.empty()) HIP_CHECK(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    }
+    template<class T> T* as() const { return static_cast<T*>(p); }
+};
+
+struct PinnedBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    PinnedBuf() {}
+    PinnedBuf(const PinnedBuf&) = delete;
+    PinnedBuf& operator=(const PinnedBuf&) = delete;
+    ~PinnedBuf() { if (p) (void)hipHostFree(p); }
+    void ensure(size_t n) {
+        if (n <= bytes) return;
+        if (p) { (void)hipHostFree(p); p = nullptr; }
+        n += n / 4;
+        HIP_CHECK(hipHostMalloc(&p, n, hipHostMallocDefault));
+        bytes = n;
+    }
+    template<class T> T* as() const { return static_cast<T*>(p); }
+};
+
+struct DevTable {
+    DevBuf keys, vals, lkeys, lvals;
+    ScgTable view;
+    void upload(const scg::HostTable& h) {
+        keys.upload(h.keys); vals.upload(h.vals); lkeys.upload(h.list_keys); lvals.upload(h.list_vals);
+        view.keys = keys.as<uint64_t>(); view.vals = vals.as<int32_t>();
+        view.mask = h.mask; view.len = h.len; view.sentinel_val = h.sentinel_val; view.n_entries = h.n_entries;
+        view.list_keys = lkeys.as<uint64_t>(); view.list_vals = lvals.as<int32_t>();
+    }
+};
+
+struct DevPairTable {
+    DevBuf keys, vals, l1, l2, lv;
+    ScgPairTable view;
+    void upload(const scg::HostPairTable& h) {
+        keys.upload(h.keys); vals.upload(h.vals); l1.upload(h.list_key1); l2.upload(h.list_key2); lv.upload(h.list_vals);
+        view.keys = keys.as<uint64_t>(); view.vals = vals.as<int32_t>(); view.mask = h.mask; view.n_entries = h.n_entries;
+        view.list_key1 = l1.as<uint64_t>(); view.list_key2 = l2.as<uint64_t>(); view.list_vals = lv.as<int32_t>();
+    }
+};
+
+} // namespace
+
+// -------------------------------------------------------------------------------------------------
+// Plans
+// -------------------------------------------------------------------------------------------------
+struct scg_plan {
+    enum Kind { SINGLE, COMBO, DUAL } kind = SINGLE;
+    int device = 0;
+
+    // host-compiled pieces (valid before any device work)
+    scg::HostTemplate ht1, ht2;
+    scg::HostTable htab[2];
+    scg::HostPairTable hpairs;
+    int32_t n_pool[2] = {0, 0};
+    int max_mm1 = 0, max_mm2 = 0;
+    bool rev1 = false, rev2 = false, randomized = false, use_first = true;
+
+    // device state
+    DevBuf d_tmpl1, d_tmpl2;
+    DevTable tab[2];
+    DevPairTable pairs;
+    DevBuf own_counters;
+    int32_t* counters = nullptr;
+    int64_t n_counters = 0;
+    int64_t total = 0;
+
+    bool profiling = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t> > events;
+    size_t events_used = 0;
+
+    ~scg_plan() {
+        for (auto& e : events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    }
+
+    void to_device(int dev) {
+        device = resolve_device(dev);
+        DeviceGuard g(device);
+        std::vector<ScgTemplate> t1(1, ht1.t);
+        d_tmpl1.upload(t1);
+        if (kind == DUAL) {
+            std::vector<ScgTemplate> t2(1, ht2.t);
+            d_tmpl2.upload(t2);
+        }
+        tab[0].upload(htab[0]);
+        if (kind != SINGLE) tab[1].upload(htab[1]);
+        if (kind == DUAL) pairs.upload(hpairs);
+        own_counters.alloc(static_cast<size_t>(n_counters) * sizeof(int32_t));
+        counters = own_counters.as<int32_t>();
+        HIP_CHECK(hipMemset(counters, 0, static_cast<size_t>(n_counters) * sizeof(int32_t)));
+        // host copies are no longer needed
+        for (auto& h : htab) { h = scg::HostTable(); }
+        hpairs = scg::HostPairTable();
+    }
+
+    struct Timer {
+        scg_plan* plan; hipStream_t stream; size_t slot = 0; bool on;
+        Timer(scg_plan* p, hipStream_t s) : plan(p), stream(s), on(p->profiling) {
+            if (!on) return;
+            if (plan->events_used == plan->events.size()) {
+                hipEvent_t a, b;
+                HIP_CHECK(hipEventCreate(&a));
+                HIP_CHECK(hipEventCreate(&b));
+                plan->events.emplace_back(a, b);
+            }
+            slot = plan->events_used++;
+            HIP_CHECK(hipEventRecord(plan->events[slot].first, stream));
+        }
+        void stop() { if (on) HIP_CHECK(hipEventRecord(plan->events[slot].second, stream)); }
+    };
+};
+
+namespace {
+
+ScgReads make_reads(const char* d_seqs, const uint32_t* d_offsets, int32_t fixed_len) {
+    ScgReads r;
+    r.seqs = reinterpret_cast<const uint8_t*>(d_seqs);
+    r.offsets = d_offsets;
+    r.fixed_len = fixed_len;
+    return r;
+}
+
+void check_reads_args(const char* d_seqs, const uint32_t* d_offsets, int32_t fixed_len, int64_t n) {
+    if (n < 0) throw Error(SCG_ERR_INVALID, "negative read count");
+    if (n > 0 && !d_seqs && !(d_offsets == nullptr && fixed_len == 0)) throw Error(SCG_ERR_INVALID, "null read buffer");
+    if (!d_offsets && fixed_len < 0) throw Error(SCG_ERR_INVALID, "negative fixed read length");
+}
+
+// ---- host compilation of the three plan kinds (all reference argument checks live here) ----
+
+std::unique_ptr<scg_plan> compile_single(const char* constant, int strand, const char* const* pool, int32_t n_pool,
+                                         int mismatches, int use_first) {
+    if (!constant || (n_pool > 0 && !pool) || n_pool < 0) throw Error(SCG_ERR_INVALID, "null argument");
+    std::unique_ptr<scg_plan> P(new scg_plan);
+    P->kind = scg_plan::SINGLE;
+    int plen = scg::pool_length(pool, n_pool);                 // src/utils.cpp:15-17
+    P->ht1 = scg::parse_template(constant, strand);            // src/count_single_barcodes.cpp:37-47, ScanTemplate.hpp:53-95
+    if (P->ht1.t.nreg != 1) {
+        throw Error(SCG_ERR_INVALID, "expected one variable region in the constant template");   // SimpleSingleMatch.hpp:75-77
+    }
+    int vlen = P->ht1.t.flen[0];
+    if (vlen != plen) {                                        // SimpleSingleMatch.hpp:79-83
+        throw Error(SCG_ERR_INVALID, "length of barcode_pool sequences (" + std::to_string(plen) +
+                    ") should be the same as the barcode_pool region (" + std::to_string(vlen) + ")");
+    }
+    if (mismatches < 0) throw Error(SCG_ERR_INVALID, "negative number of mismatches");
+    P->htab[0] = scg::build_index_table(pool, n_pool, plen);   // BarcodeSearch.hpp:23-60
+    P->n_pool[0] = n_pool;
+    P->n_counters = n_pool;
+    P->max_mm1 = mismatches;
+    P->use_first = use_first != 0;
+    return P;
+}
+
+std::unique_ptr<scg_plan> compile_combo(const char* constant, int strand,
+                                        const char* const* pool0, int32_t n0, const char* const* pool1, int32_t n1,
+                                        int mismatches, int use_first) {
+    if (!constant || (n0 > 0 && !pool0) || (n1 > 0 && !pool1) || n0 < 0 || n1 < 0) throw Error(SCG_ERR_INVALID, "null argument");
+    std::unique_ptr<scg_plan> P(new scg_plan);
+    P->kind = scg_plan::COMBO;
+    int len0 = scg::pool_length(pool0, n0);
+    int len1 = scg::pool_length(pool1, n1);
+    P->ht1 = scg::parse_template(constant, strand);
+    if (P->ht1.t.nreg != 2) {                                  // CombinatorialBarcodesSingleEnd.hpp:79-81
+        throw Error(SCG_ERR_INVALID, "expected 2 variable regions in the constant template");
+    }
+    int lens[2] = {len0, len1};
+    for (int r = 0; r < 2; ++r) {                              // :86-93
+        if (P->ht1.t.flen[r] != lens[r]) {
+            throw Error(SCG_ERR_INVALID, "length of variable region " + std::to_string(r + 1) + " (" + std::to_string(P->ht1.t.flen[r]) +
+                        ") should be the same as its sequences (" + std::to_string(lens[r]) + ")");
+        }
+    }
+    if (mismatches < 0) throw Error(SCG_ERR_INVALID, "negative number of mismatches");
+    P->htab[0] = scg::build_index_table(pool0, n0, len0);
+    P->htab[1] = scg::build_index_table(pool1, n1, len1);
+    P->n_pool[0] = n0; P->n_pool[1] = n1;
+    int64_t cells = static_cast<int64_t>(n0) * static_cast<int64_t>(n1);
+    if (cells > (int64_t(1) << 30)) {
+        throw Error(SCG_ERR_UNSUPPORTED, "combination space larger than 2^30 cells is not supported by the dense histogram");
+    }
+    P->n_counters = cells;
+    P->max_mm1 = mismatches;
+    P->use_first = use_first != 0;
+    return P;
+}
+
+std::unique_ptr<scg_plan> compile_dual(const char* constant1, int reverse1, int mismatches1, const char* const* pool1,
+                                       const char* constant2, int reverse2, int mismatches2, const char* const* pool2,
+                                       int32_t n_pool, int randomized, int use_first) {
+    if (!constant1 || !constant2 || (n_pool > 0 && (!pool1 || !pool2)) || n_pool < 0) throw Error(SCG_ERR_INVALID, "null argument");
+    std::unique_ptr<scg_plan> P(new scg_plan);
+    P->kind = scg_plan::DUAL;
+    int len1 = scg::pool_length(pool1, n_pool);                // src/count_dual_barcodes.cpp:93-97
+    int len2 = scg::pool_length(pool2, n_pool);
+    P->ht1 = scg::parse_template(constant1, reverse1 ? 1 : 0); // DualBarcodesPairedEnd.hpp:99-100
+    P->ht2 = scg::parse_template(constant2, reverse2 ? 1 : 0);
+    if (P->ht1.t.nreg != 1) throw Error(SCG_ERR_INVALID, "expected one variable region in the first constant template");    // :115-117
+    if (P->ht1.t.flen[0] != len1) {                            // :119-122
+        throw Error(SCG_ERR_INVALID, "length of variable sequences (" + std::to_string(len1) + ") should be the same as the variable region (" +
+                    std::to_string(P->ht1.t.flen[0]) + ")");
+    }
+    if (P->ht2.t.nreg != 1) throw Error(SCG_ERR_INVALID, "expected one variable region in the second constant template");   // :128-130
+    if (P->ht2.t.flen[0] != len2) {
+        throw Error(SCG_ERR_INVALID, "length of variable sequences (" + std::to_string(len2) + ") should be the same as the variable region (" +
+                    std::to_string(P->ht2.t.flen[0]) + ")");
+    }
+    if (mismatches1 < 0 || mismatches2 < 0) throw Error(SCG_ERR_INVALID, "negative number of mismatches");
+    std::vector<std::vector<int32_t> > exp1, exp2;
+    std::vector<uint64_t> uk1, uk2;
+    P->htab[0] = scg::build_uid_table(pool1, n_pool, len1, exp1, uk1);
+    P->htab[1] = scg::build_uid_table(pool2, n_pool, len2, exp2, uk2);
+    P->hpairs = scg::build_pair_table(exp1, uk1, exp2, uk2);   // :138-178 (duplicate pairs => error)
+    P->n_pool[0] = P->n_pool[1] = n_pool;
+    P->n_counters = n_pool;
+    P->max_mm1 = mismatches1; P->max_mm2 = mismatches2;
+    P->rev1 = reverse1 != 0; P->rev2 = reverse2 != 0;
+    P->randomized = randomized != 0;
+    P->use_first = use_first != 0;
+    return P;
+}
+
+void launch_batch(scg_plan* P, const ScgReads& R, int64_t n, hipStream_t stream) {
+    scg_plan::Timer timer(P, stream);
+    if (P->kind == scg_plan::SINGLE) {
+        ScgSingleParams sp;
+        sp.tmpl = P->d_tmpl1.as<ScgTemplate>();
+        sp.table = P->tab[0].view;
+        sp.max_mm = P->max_mm1; sp.use_first = P->use_first;
+        sp.fwd = P->ht1.fwd; sp.rev = P->ht1.rev;
+        HIP_CHECK(scg::launch_single(sp, R, n, P->counters, stream));
+    } else {
+        ScgComboParams cp;
+        cp.tmpl = P->d_tmpl1.as<ScgTemplate>();
+        cp.table[0] = P->tab[0].view; cp.table[1] = P->tab[1].view;
+        cp.n_pool[0] = P->n_pool[0]; cp.n_pool[1] = P->n_pool[1];
+        cp.max_mm = P->max_mm1; cp.use_first = P->use_first;
+        cp.fwd = P->ht1.fwd; cp.rev = P->ht1.rev;
+        HIP_CHECK(scg::launch_combo(cp, R, n, P->counters, stream));
+    }
+    timer.stop();
+    P->total += n;
+}
+
+void launch_batch_paired(scg_plan* P, const ScgReads& R1, const ScgReads& R2, int64_t n, hipStream_t stream) {
+    scg_plan::Timer timer(P, stream);
+    ScgDualParams dp;
+    dp.tmpl1 = P->d_tmpl1.as<ScgTemplate>(); dp.tmpl2 = P->d_tmpl2.as<ScgTemplate>();
+    dp.table1 = P->tab[0].view; dp.table2 = P->tab[1].view; dp.pairs = P->pairs.view;
+    dp.rev1 = P->rev1; dp.rev2 = P->rev2; dp.max_mm1 = P->max_mm1; dp.max_mm2 = P->max_mm2;
+    dp.randomized = P->randomized; dp.use_first = P->use_first;
+    HIP_CHECK(scg::launch_dual(dp, R1, R2, n, P->counters, stream));
+    timer.stop();
+    P->total += n;
+}
+
+// ---- FASTQ -> device staging: two slots, each with its own stream, pinned and device buffers ----
+struct Stager {
+    static const int SLOTS = 2;
+    struct Slot {
+        hipStream_t stream = nullptr;
+        PinnedBuf h_seqs[2], h_offs[2];
+        DevBuf d_seqs[2], d_offs[2];
+        bool busy = false;
+    } slot[SLOTS];
+    int next = 0;
+
+    Stager() {
+        for (auto& s : slot) HIP_CHECK(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+    }
+    ~Stager() {
+        for (auto& s : slot) if (s.stream) { (void)hipStreamSynchronize(s.stream); (void)hipStreamDestroy(s.stream); }
+    }
+
+    Slot& acquire() {
+        Slot& s = slot[next];
+        next = (next + 1) % SLOTS;
+        if (s.busy) { HIP_CHECK(hipStreamSynchronize(s.stream)); s.busy = false; }
+        return s;
+    }
+
+    // Copies one host batch into lane `which` of the slot; returns the device view.
+    ScgReads stage(Slot& s, int which, const scg::ReadBatch& b) {
+        size_t nbytes = b.seqs.size();
+        size_t n = static_cast<size_t>(b.size());
+        if (nbytes >= (size_t(1) << 32)) throw Error(SCG_ERR_INVALID, "internal: batch exceeds 4 GiB");
+        s.h_seqs[which].ensure(nbytes + 16);
+        s.h_offs[which].ensure((n + 1) * sizeof(uint32_t));
+        s.d_seqs[which].ensure(nbytes + 16);
+        s.d_offs[which].ensure((n + 1) * sizeof(uint32_t));
+        if (nbytes) std::memcpy(s.h_seqs[which].p, b.seqs.data(), nbytes);
+        uint32_t* ho = s.h_offs[which].as<uint32_t>();
+        for (size_t i = 0; i <= n; ++i) ho[i] = static_cast<uint32_t>(b.offsets[i]);
+        if (nbytes) HIP_CHECK(hipMemcpyAsync(s.d_seqs[which].p, s.h_seqs[which].p, nbytes, hipMemcpyHostToDevice, s.stream));
+        HIP_CHECK(hipMemcpyAsync(s.d_offs[which].p, ho, (n + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, s.stream));
+        return make_reads(s.d_seqs[which].as<char>(), s.d_offs[which].as<uint32_t>(), 0);
+    }
+
+    void drain() {
+        for (auto& s : slot) { HIP_CHECK(hipStreamSynchronize(s.stream)); s.busy = false; }
+    }
+};
+
+const int64_t BATCH_READS = int64_t(1) << 22;
+const int64_t BATCH_BYTES = int64_t(1) << 30;
+
+void read_counters(scg_plan* P, int32_t* counts_out) {
+    if (counts_out && P->n_counters) {
+        HIP_CHECK(hipMemcpy(counts_out, P->counters, static_cast<size_t>(P->n_counters) * sizeof(int32_t), hipMemcpyDeviceToHost));
+    }
+}
+
+void combo_compact(const int32_t* cells, int32_t n0, int32_t n1, int32_t** indices_out, int32_t** freq_out, int64_t* k_out) {
+    int64_t total = static_cast<int64_t>(n0) * n1, k = 0;
+    for (int64_t c = 0; c < total; ++c) k += cells[c] != 0;
+    int32_t* idx = static_cast<int32_t*>(std::malloc(sizeof(int32_t) * static_cast<size_t>(2 * k + 1)));
+    int32_t* freq = static_cast<int32_t*>(std::malloc(sizeof(int32_t) * static_cast<size_t>(k + 1)));
+    if (!idx || !freq) { std::free(idx); std::free(freq); throw std::bad_alloc(); }
+    int64_t j = 0;
+    // cell order = (first, second) lexicographic order = the reference's sorted column order
+    for (int64_t c = 0; c < total; ++c) {
+        if (cells[c]) {
+            idx[2 * j] = static_cast<int32_t>(c / n1);
+            idx[2 * j + 1] = static_cast<int32_t>(c % n1);
+            freq[j] = cells[c];
+            ++j;
+        }
+    }
+    *indices_out = idx; *freq_out = freq; *k_out = k;
+}
+
+} // namespace
+
+// -------------------------------------------------------------------------------------------------
+// C ABI
+// -------------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* scg_version(void) { return "scg 0.1.0 (gfx950)"; }
+
+int scg_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+void scg_free(void* p) { std::free(p); }
+
+int scg_parse_fastq(const char* path, char** seqs_out, uint64_t** offsets_out, int64_t* n_reads_out, char* err, size_t errcap) {
+    return guarded(err, errcap, [&] {
+        if (!path || !seqs_out || !offsets_out || !n_reads_out) throw Error(SCG_ERR_INVALID, "null argument");
+        scg::FastqStream fq(path);
+        scg::ReadBatch all, b;
+        all.clear();
+        while (fq.next_batch(b, BATCH_READS, BATCH_BYTES)) {
+            uint64_t base = all.seqs.size();
+            all.seqs.insert(all.seqs.end(), b.seqs.begin(), b.seqs.end());
+            for (int64_t i = 1; i <= b.size(); ++i) all.offsets.push_back(base + b.offsets[i]);
+        }
+        char* s = static_cast<char*>(std::malloc(all.seqs.size() + 1));
+        uint64_t* o = static_cast<uint64_t*>(std::malloc(sizeof(uint64_t) * all.offsets.size()));
+        if (!s || !o) { std::free(s); std::free(o); throw std::bad_alloc(); }
+        if (!all.seqs.empty()) std::memcpy(s, all.seqs.data(), all.seqs.size());
+        std::memcpy(o, all.offsets.data(), sizeof(uint64_t) * all.offsets.size());
+        *seqs_out = s; *offsets_out = o; *n_reads_out = all.size();
+    });
+}
+
+int scg_plan_single(scg_plan** plan_out, const char* constant, int strand, const char* const* pool, int32_t n_pool,
+                    int mismatches, int use_first, int device, char* err, size_t errcap) {
+    return guarded(err, errcap, [&] {
+        if (!plan_out) throw Error(SCG_ERR_INVALID, "null argument");
+        auto P = compile_single(constant, strand, pool, n_pool, mismatches, use_first);
+        P->to_device(device);
+        *plan_out = P.release();
+    });
+}
+
+int scg_plan_combo(scg_plan** plan_out, const char* constant, int strand, const char* const* pool0, int32_t n_pool0,
+                   const char* const* pool1, int32_t n_pool1, int mismatches, int use_first,
+                   int device, char* err, size_t errcap) {
+    return guarded(err, errcap, [&] {
+        if (!plan_out) throw Error(SCG_ERR_INVALID, "null argument");
+        auto P = compile_combo(constant, strand, pool0, n_pool0, pool1, n_pool1, mismatches, use_first);
+        P->to_device(device);
+        *plan_out = P.release();
+    });
+}
+
+int scg_plan_dual(scg_plan** plan_out, const char* constant1, int reverse1, int mismatches1, const char* const* pool1,
+                  const char* constant2, int reverse2, int mismatches2, const char* const* pool2,
+                  int32_t n_pool, int randomized, int use_first, int device, char* err, size_t errcap) {
+    return guarded(err, errcap, [&] {
+        if (!plan_out) throw Error(SCG_ERR_INVALID, "null argument");
+        auto P = compile_dual(constant1, reverse1, mismatches1, pool1, constant2, reverse2, mismatches2, pool2, n_pool, randomized, use_first);
+        P->to_device(device);
+        *plan_out = P.release();
+    });
+}
+
+void scg_plan_destroy(scg_plan* plan) {
+    if (!plan) return;
+    int prev = -1;
+    if (hipGetDevice(&prev) == hipSuccess && prev != plan->device) (void)hipSetDevice(plan->device); else prev = -1;
+    delete plan;
+    if (prev >= 0) (void)hipSetDevice(prev);
+}
+
+int64_t scg_plan_num_counters(const scg_plan* plan) { return plan ? plan->n_counters : 0; }
+
+int32_t* scg_plan_device_counters(scg_plan* plan) { return plan ? plan->counters : nullptr; }
+
+int scg_plan_bind_counters(scg_plan* plan, int32_t* d_counters, char* err, size_t errcap) {
+    return guarded(err, errcap, [&] {
+        if (!plan) throw Error(SCG_ERR_INVALID, "null plan");
+        plan->counters = d_counters ? d_counters : plan->own_counters.as<int32_t>();
+    });
+}
+
+int scg_plan_reset(scg_plan* plan, void* stream, char* err, size_t errcap) {
+    return guarded(err, errcap, [&] {
+        if (!plan) throw Error(SCG_ERR_INVALID, "null plan");
+        DeviceGuard g(plan->device);
+        HIP_CHECK(hipMemsetAsync(plan->counters, 0, static_cast<size_t>(plan->n_counters) * sizeof(int32_t), static_cast<hipStream_t>(stream)));
+        plan->total = 0;
+        plan->events_used = 0;
+    });
+}
+
+int scg_count_batch(scg_plan* plan, const char* d_seqs, const uint32_t* d_offsets, int32_t fixed_len,
+                    int64_t n_reads, void* stream, char* err, size_t errcap) {
+    return guarded(err, errcap, [&] {
+        if (!plan) throw Error(SCG_ERR_INVALID, "null plan");
+        if (plan->kind == scg_plan::DUAL) throw Error(SCG_ERR_INVALID, "scg_count_batch called on a dual plan; use scg_count_batch_paired");
+        check_reads_args(d_seqs, d_offsets, fixed_len, n_reads);
+        DeviceGuard g(plan->device);
+        launch_batch(plan, make_reads(d_seqs, d_offsets, fixed_len), n_reads, static_cast<hipStream_t>(stream));
+    });
+}
+
+int scg_count_batch_paired(scg_plan* plan, const char* d_seqs1, const uint32_t* d_offsets1, int32_t fixed_len1,
+                           const char* d_seqs2, const uint32_t* d_offsets2, int32_t fixed_len2,
+                           int64_t n_pairs, void* stream, char* err, size_t errcap) {
+    return guarded(err, errcap, [&] {
+        if (!plan) throw Error(SCG_ERR_INVALID, "null plan");
+        if (plan->kind != scg_plan::DUAL) throw Error(SCG_ERR_INVALID, "scg_count_batch_paired needs a dual plan");
+        check_reads_args(d_seqs1, d_offsets1, fixed_len1, n_pairs);
+        check_reads_args(d_seqs2, d_offsets2, fixed_len2, n_pairs);
+        DeviceGuard g(plan->device);
+        launch_batch_paired(plan, make_reads(d_seqs1, d_offsets1, fixed_len1), make_reads(d_seqs2, d_offsets2, fixed_len2),
+                            n_pairs, static_cast<hipStream_t>(stream));
+    });
+}
+
+int scg_plan_read(scg_plan* plan, int32_t* counts_out, int64_t* total_out, void* stream, char* err, size_t errcap) {
+    return guarded(err, errcap, [&] {
+        if (!plan) throw Error(SCG_ERR_INVALID, "null plan");
+        DeviceGuard g(plan->device);
+        HIP_CHECK(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+        read_counters(plan, counts_out);
+        if (total_out) *total_out = plan->total;
+    });
+}
+
+int scg_combo_compact(const int32_t* cells, int32_t n_pool0, int32_t n_pool1,
+                      int32_t** indices_out, int32_t** freq_out, int64_t* k_out, char* err, size_t errcap) {
+    return guarded(err, errcap, [&] {
+        if (!cells || !indices_out || !freq_out || !k_out) throw Error(SCG_ERR_INVALID, "null argument");
+        combo_compact(cells, n_pool0, n_pool1, indices_out, freq_out, k_out);
+    });
+}
+
+int scg_plan_set_profiling(scg_plan* plan, int enabled) {
+    if (!plan) return SCG_ERR_INVALID;
+    plan->profiling = enabled != 0;
+    return SCG_OK;
+}
+
+int scg_plan_kernel_stats(scg_plan* plan, double* total_ms_out, int64_t* launches_out, char* err, size_t errcap) {
+    return guarded(err, errcap, [&] {
+        if (!plan) throw Error(SCG_ERR_INVALID, "null plan");
+        DeviceGuard g(plan->device);
+        double ms = 0;
+        for (size_t i = 0; i < plan->events_used; ++i) {
+            HIP_CHECK(hipEventSynchronize(plan->events[i].second));
+            float t = 0;
+            HIP_CHECK(hipEventElapsedTime(&t, plan->events[i].first, plan->events[i].second));
+            ms += t;
+        }
+        if (total_ms_out) *total_ms_out = ms;
+        if (launches_out) *launches_out = static_cast<int64_t>(plan->events_used);
+    });
+}
+
+// ---- file-level entry points -------------------------------------------------------------------
+
+int scg_count_single_barcodes(const char* path, const char* constant, int strand, const char* const* pool, int32_t n_pool,
+                              int mismatches, int use_first, int nthreads, int32_t* counts_out, int32_t* total_out,
+                              char* err, size_t errcap) {
+    (void)nthreads;
+    return guarded(err, errcap, [&] {
+        if (!path || !counts_out || !total_out) throw Error(SCG_ERR_INVALID, "null argument");
+        scg::FastqStream fq(path);                                           // src/count_single_barcodes.cpp:30
+        auto P = compile_single(constant, strand, pool, n_pool, mismatches, use_first);   // :31-47
+        P->to_device(-1);
+        DeviceGuard g(P->device);
+        Stager st;
+        scg::ReadBatch b;
+        while (fq.next_batch(b, BATCH_READS, BATCH_BYTES)) {
+            auto& s = st.acquire();
+            ScgReads R = st.stage(s, 0, b);
+            launch_batch(P.get(), R, b.size(), s.stream);
+            s.busy = true;
+        }
+        st.drain();
+        read_counters(P.get(), counts_out);
+        *total_out = static_cast<int32_t>(P->total);
+    });
+}
+
+int scg_count_combo_barcodes_single(const char* path, const char* constant, int strand,
+                                    const char* const* pool0, int32_t n_pool0, const char* const* pool1, int32_t n_pool1,
+                                    int mismatches, int use_first, int nthreads,
+                                    int32_t** indices_out, int32_t** freq_out, int64_t* k_out, int32_t* total_out,
+                                    char* err, size_t errcap) {
+    (void)nthreads;
+    return guarded(err, errcap, [&] {
+        if (!path || !indices_out || !freq_out || !k_out || !total_out) throw Error(SCG_ERR_INVALID, "null argument");
+        scg::FastqStream fq(path);
+        auto P = compile_combo(constant, strand, pool0, n_pool0, pool1, n_pool1, mismatches, use_first);
+        P->to_device(-1);
+        DeviceGuard g(P->device);
+        Stager st;
+        scg::ReadBatch b;
+        while (fq.next_batch(b, BATCH_READS, BATCH_BYTES)) {
+            auto& s = st.acquire();
+            ScgReads R = st.stage(s, 0, b);
+            launch_batch(P.get(), R, b.size(), s.stream);
+            s.busy = true;
+        }
+        st.drain();
+        std::vector<int32_t> cells(static_cast<size_t>(P->n_counters) + 1);
+        read_counters(P.get(), cells.data());
+        combo_compact(cells.data(), n_pool0, n_pool1, indices_out, freq_out, k_out);
+        *total_out = static_cast<int32_t>(P->total);
+    });
+}
+
+int scg_count_dual_barcodes(const char* path1, const char* constant1, int reverse1, int mismatches1, const char* const* pool1,
+                            const char* path2, const char* constant2, int reverse2, int mismatches2, const char* const* pool2,
+                            int32_t n_pool, int randomized, int use_first, int diagnostics, int nthreads,
+                            int32_t* counts_out, int32_t* total_out, char* err, size_t errcap) {
+    (void)nthreads;
+    return guarded(err, errcap, [&] {
+        if (!path1 || !path2 || !counts_out || !total_out) throw Error(SCG_ERR_INVALID, "null argument");
+        scg::FastqStream fq1(path1);                                         // src/count_dual_barcodes.cpp:93-97
+        scg::FastqStream fq2(path2);
+        if (diagnostics) {
+            throw Error(SCG_ERR_UNSUPPORTED, "include.invalid=TRUE (diagnostics) is not implemented by this engine yet");
+        }
+        auto P = compile_dual(constant1, reverse1, mismatches1, pool1, constant2, reverse2, mismatches2, pool2, n_pool, randomized, use_first);
+        P->to_device(-1);
+        DeviceGuard g(P->device);
+        Stager st;
+        scg::ReadBatch b1, b2;
+        for (;;) {
+            // Both files advance in lock-step by read count (process_data.hpp:246-290).
+            bool more1 = fq1.next_batch(b1, BATCH_READS / 4, INT64_MAX);
+            bool more2 = fq2.next_batch(b2, BATCH_READS / 4, INT64_MAX);
+            if (b1.size() != b2.size()) {
+                throw Error(SCG_ERR_IO, "different number of reads in paired FASTQ files");   // process_data.hpp:284-285
+            }
+            if (!more1 && !more2) break;
+            auto& s = st.acquire();
+            ScgReads R1 = st.stage(s, 0, b1);
+            ScgReads R2 = st.stage(s, 1, b2);
+            launch_batch_paired(P.get(), R1, R2, b1.size(), s.stream);
+            s.busy = true;
+        }
+        st.drain();
+        read_counters(P.get(), counts_out);
+        *total_out = static_cast<int32_t>(P->total);
+    });
+}
+
+int scg_match_barcodes(const char* const* sequences, int32_t n_sequences, const char* const* choices, int32_t n_choices,
+                       int substitutions, int reverse, int32_t* index_out, int32_t* mismatches_out, char* err, size_t errcap) {
+    return guarded(err, errcap, [&] {
+        if ((n_sequences > 0 && (!sequences || !index_out || !mismatches_out)) || (n_choices > 0 && !choices)) {
+            throw Error(SCG_ERR_INVALID, "null argument");
+        }
+        int clen = scg::pool_length(choices, n_choices);                     // src/match_barcodes.cpp:12
+        scg::HostTable ht = scg::build_index_table(choices, n_choices, clen);   // :13
+        int slen = scg::pool_length(sequences, n_sequences);                 // :20
+        if (n_sequences > 0 && slen != clen) {
+            throw Error(SCG_ERR_INVALID, "sequences should have the same length as the choices (" + std::to_string(clen) + ")");
+        }
+        if (substitutions < 0) throw Error(SCG_ERR_INVALID, "negative number of mismatches");
+        if (n_sequences == 0) return;
+        int device = resolve_device(-1);
+        DeviceGuard g(device);
+        DevTable tab;
+        tab.upload(ht);
+        std::vector<uint8_t> flat(static_cast<size_t>(n_sequences) * clen);
+        for (int32_t i = 0; i < n_sequences; ++i) std::memcpy(flat.data() + static_cast<size_t>(i) * clen, sequences[i], clen);
+        DevBuf d_seqs, d_idx, d_mm;
+        d_seqs.upload(flat);
+        d_idx.alloc(sizeof(int32_t) * n_sequences);
+        d_mm.alloc(sizeof(int32_t) * n_sequences);
+        HIP_CHECK(scg::launch_match(tab.view, d_seqs.as<uint8_t>(), n_sequences, substitutions, reverse, d_idx.as<int32_t>(), d_mm.as<int32_t>(), nullptr));
+        HIP_CHECK(hipMemcpy(index_out, d_idx.p, sizeof(int32_t) * n_sequences, hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(mismatches_out, d_mm.p, sizeof(int32_t) * n_sequences, hipMemcpyDeviceToHost));
+    });
+}
+
+int scg_synth_reads(const scg_synth_spec* spec, char* d_seqs_out, int64_t n_reads, void* stream, char* err, size_t errcap) {
+    return guarded(err, errcap, [&] {
+        if (!spec || (!d_seqs_out && n_reads > 0)) throw Error(SCG_ERR_INVALID, "null argument");
+        if (spec->read_len <= 0 || spec->template_len < 0 || spec->n_regions < 0 || spec->n_regions > 2) {
+            throw Error(SCG_ERR_INVALID, "bad synthetic read specification");
+        }
+        HIP_CHECK(scg::launch_synth(*spec, d_seqs_out, n_reads, static_cast<hipStream_t>(stream)));
+    });
+}
+
+} // extern "C"

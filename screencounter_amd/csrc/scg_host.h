@@ -1,0 +1,101 @@
+// scg_host.h -- internal C++ interface of the host runtime (not part of the C ABI).
+#ifndef SCG_HOST_H
+#define SCG_HOST_H
+
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/scg.h"
+#include "scg_common.h"
+
+namespace scg {
+
+// Carries an SCG_ERR_* code to the C boundary, where it becomes (code, message).
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string& msg) : std::runtime_error(msg), code(c) {}
+};
+
+// ---------------------------------------------------------------------------------------------
+// Template: kaori/ScanTemplate.hpp:53-95.
+// ---------------------------------------------------------------------------------------------
+struct HostTemplate {
+    ScgTemplate t;
+    bool fwd, rev;
+};
+// strand: 0 forward, 1 reverse, 2 both.  Throws Error(SCG_ERR_INVALID) like the reference.
+HostTemplate parse_template(const char* constant, int strand);
+
+// ---------------------------------------------------------------------------------------------
+// Pools: src/utils.cpp:5-23 (equal lengths), kaori/BarcodeSearch.hpp:23-60 (fill_library),
+// kaori/MismatchTrie.hpp:93-205 (IUPAC expansion, DuplicateAction::ERROR).
+// ---------------------------------------------------------------------------------------------
+int pool_length(const char* const* pool, int32_t n);   // throws if lengths differ
+
+struct HostTable {
+    int32_t len = 0;
+    int32_t n_entries = 0;
+    uint32_t mask = 0;
+    int32_t sentinel_val = -1;
+    std::vector<uint64_t> keys;
+    std::vector<int32_t> vals;
+    std::vector<uint64_t> list_keys;
+    std::vector<int32_t> list_vals;
+};
+
+// value = barcode index; two barcodes sharing one concrete sequence => Error("duplicate sequences
+// detected (a, b) when constructing the trie").
+HostTable build_index_table(const char* const* pool, int32_t n, int32_t len);
+
+// value = uid of the concrete sequence (duplicates within the pool merge).  expansions[i] receives
+// the uids of barcode i's concrete expansions, in lexicographic (A,C,G,T) order.
+HostTable build_uid_table(const char* const* pool, int32_t n, int32_t len,
+                          std::vector<std::vector<int32_t> >& expansions,
+                          std::vector<uint64_t>& uid_keys);
+
+struct HostPairTable {
+    int32_t n_entries = 0;
+    uint32_t mask = 0;
+    std::vector<uint64_t> keys;
+    std::vector<int32_t> vals;
+    std::vector<uint64_t> list_key1, list_key2;
+    std::vector<int32_t> list_vals;
+};
+HostPairTable build_pair_table(const std::vector<std::vector<int32_t> >& exp1, const std::vector<uint64_t>& uid_keys1,
+                               const std::vector<std::vector<int32_t> >& exp2, const std::vector<uint64_t>& uid_keys2);
+
+// Packs an ASCII query (reads side: only ACGT are bases).  Returns false if longer than 32.
+// nmask gets 0b11 at every non-ACGT position.
+bool pack_query(const char* s, int len, bool reverse_complement, uint64_t& key, uint64_t& nmask, int& n_other);
+
+// ---------------------------------------------------------------------------------------------
+// FASTQ: kaori/FastqReader.hpp:42-110 over byteme readers.
+// ---------------------------------------------------------------------------------------------
+struct ReadBatch {
+    std::vector<char> seqs;
+    std::vector<uint64_t> offsets;   // n + 1
+    int64_t size() const { return static_cast<int64_t>(offsets.size()) - 1; }
+    void clear() { seqs.clear(); offsets.assign(1, 0); }
+};
+
+class FastqStream {
+public:
+    explicit FastqStream(const char* path);
+    ~FastqStream();
+    FastqStream(const FastqStream&) = delete;
+    FastqStream& operator=(const FastqStream&) = delete;
+
+    // Appends up to max_reads records / max_bytes sequence bytes to `out` (which is cleared first).
+    // Returns false once the file is exhausted and nothing was appended.
+    bool next_batch(ReadBatch& out, int64_t max_reads, int64_t max_bytes);
+
+private:
+    struct Impl;
+    Impl* impl;
+};
+
+} // namespace scg
+
+#endif

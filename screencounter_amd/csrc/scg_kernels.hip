@@ -1,0 +1,315 @@
+// scg_kernels.hip -- counting kernels (gfx950) and their launchers.
+//
+// General engine: one read (or read pair) per lane.  Each kernel is the device counterpart of one
+// kaori handler's process() (paths relative to inst/include/kaori/handlers/ in the reference):
+//   single_kernel <- SingleBarcodeSingleEnd::process          SingleBarcodeSingleEnd.hpp:93-104
+//                    + SimpleSingleMatch::search_first/best    ../SimpleSingleMatch.hpp:200-306
+//   combo_kernel  <- CombinatorialBarcodesSingleEnd::process   CombinatorialBarcodesSingleEnd.hpp:149-258
+//   dual_kernel   <- DualBarcodesPairedEnd::process            DualBarcodesPairedEnd.hpp:228-381
+// Per-handler vector<int> counters + serial reduce() become device atomics on one int32 array.
+#include <hip/hip_runtime.h>
+
+#include "scg_engine.hip.h"
+#include "scg_launch.h"
+
+using namespace scgdev;
+
+namespace {
+
+constexpr int BLOCK = 256;
+
+// ---------------------------------------------------------------------------------------------
+// single
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int single_read(const ScgSingleParams& P, const Read& rd) {
+    const ScgTemplate* T = P.tmpl;
+    const int len = T->len;
+    const int max_mm = P.max_mm;
+    int found = 0, index = -1, best = max_mm + 1;
+    for (int p = 0; p + len <= rd.n; ++p) {
+        for (int s = 0; s < 2; ++s) {                 // forward before reverse at each position
+            if (s == 0 ? !P.fwd : !P.rev) continue;
+            int c = const_mismatches(T, s != 0, rd.p, p, max_mm);
+            if (c > max_mm) continue;
+            int start = s ? T->rstart[0] : T->fstart[0];
+            Query q = pack_region(rd.p + p + start, P.table.len, s != 0);
+            int idx, d;
+            table_match(P.table, q, max_mm - c, idx, d);
+            if (idx < 0) continue;
+            int tot = c + d;
+            if (P.use_first) {
+                return idx;                           // SimpleSingleMatch.hpp:207-224 (tot <= max_mm by construction)
+            } else if (tot == best) {                 // :265-289
+                if (index != idx) { found = 0; index = -1; }
+            } else if (tot < best) {
+                found = 1; best = tot; index = idx;
+            }
+        }
+    }
+    return found ? index : -1;
+}
+
+__global__ __launch_bounds__(BLOCK) void single_kernel(ScgSingleParams P, ScgReads R, int64_t n_reads,
+                                                        int32_t* __restrict__ counts) {
+    int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n_reads) return;
+    Read rd = get_read(R, i);
+    int idx = single_read(P, rd);
+    if (idx >= 0) atomicAdd(&counts[idx], 1);
+}
+
+// ---------------------------------------------------------------------------------------------
+// combo (two variable regions in one template)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool combo_candidate(const ScgComboParams& P, const Read& rd, int p, bool reverse, int c,
+                                                int out[SCG_MAX_REGIONS], int& total) {
+    const ScgTemplate* T = P.tmpl;
+    int obs = c;
+    for (int r = 0; r < SCG_MAX_REGIONS; ++r) {
+        // reverse scan order meets the pools back to front (CombinatorialBarcodesSingleEnd.hpp:111-116)
+        int slot = reverse ? (SCG_MAX_REGIONS - 1 - r) : r;
+        int start = reverse ? T->rstart[r] : T->fstart[r];
+        const ScgTable& tab = P.table[slot];
+        Query q = pack_region(rd.p + p + start, tab.len, reverse);
+        int idx, d;
+        table_match(tab, q, P.max_mm - obs, idx, d);   // :168
+        if (idx < 0) return false;
+        obs += d;
+        if (obs > P.max_mm) return false;               // :173-176
+        out[slot] = idx;                                // :178-182
+    }
+    total = obs;
+    return true;
+}
+
+__global__ __launch_bounds__(BLOCK) void combo_kernel(ScgComboParams P, ScgReads R, int64_t n_reads,
+                                                       int32_t* __restrict__ cells) {
+    int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n_reads) return;
+    Read rd = get_read(R, i);
+    const ScgTemplate* T = P.tmpl;
+    const int len = T->len;
+    int found = 0, best = P.max_mm + 1;
+    int best_id[SCG_MAX_REGIONS] = {0, 0};
+    for (int p = 0; p + len <= rd.n && !(found && P.use_first); ++p) {
+        for (int s = 0; s < 2; ++s) {
+            if (s == 0 ? !P.fwd : !P.rev) continue;
+            int c = const_mismatches(T, s != 0, rd.p, p, P.max_mm);
+            if (c > P.max_mm) continue;
+            int cand[SCG_MAX_REGIONS], tot;
+            if (!combo_candidate(P, rd, p, s != 0, c, cand, tot)) continue;
+            if (P.use_first) {                          // :197-217
+                found = 1; best_id[0] = cand[0]; best_id[1] = cand[1];
+                break;
+            } else if (tot <= best) {                   // :225-241
+                if (tot == best) {
+                    if (best_id[0] != cand[0] || best_id[1] != cand[1]) found = 0;
+                } else {
+                    found = 1; best = tot; best_id[0] = cand[0]; best_id[1] = cand[1];
+                }
+            }
+        }
+    }
+    if (found) atomicAdd(&cells[(int64_t)best_id[0] * P.n_pool[1] + best_id[1]], 1);
+}
+
+// ---------------------------------------------------------------------------------------------
+// dual (paired-end)
+// ---------------------------------------------------------------------------------------------
+// One orientation: template 1 on read a, template 2 on read b.
+// use_first: index of the first valid (hit1, hit2) combination or -1.
+__device__ __forceinline__ int dual_first(const ScgDualParams& P, const Read& a, const Read& b) {
+    const ScgTemplate* T1 = P.tmpl1;
+    const ScgTemplate* T2 = P.tmpl2;
+    int s1 = P.rev1 ? T1->rstart[0] : T1->fstart[0];
+    int s2 = P.rev2 ? T2->rstart[0] : T2->fstart[0];
+    for (int p1 = 0; p1 + T1->len <= a.n; ++p1) {
+        int c1 = const_mismatches(T1, P.rev1 != 0, a.p, p1, P.max_mm1);
+        if (c1 > P.max_mm1) continue;
+        Query q1 = pack_region(a.p + p1 + s1, P.table1.len, P.rev1 != 0);
+        for (int p2 = 0; p2 + T2->len <= b.n; ++p2) {
+            int c2 = const_mismatches(T2, P.rev2 != 0, b.p, p2, P.max_mm2);
+            if (c2 > P.max_mm2) continue;
+            Query q2 = pack_region(b.p + p2 + s2, P.table2.len, P.rev2 != 0);
+            int idx, tot;
+            pair_match(P.table1, P.table2, P.pairs, q1, P.max_mm1 - c1, q2, P.max_mm2 - c2, idx, tot);
+            if (idx >= 0) return idx;                   // DualBarcodesPairedEnd.hpp:264-276
+        }
+    }
+    return -1;
+}
+
+// best: (chosen, best_mismatches) as DualBarcodesPairedEnd.hpp:310-347
+__device__ __forceinline__ void dual_best(const ScgDualParams& P, const Read& a, const Read& b, int& chosen, int& best) {
+    const ScgTemplate* T1 = P.tmpl1;
+    const ScgTemplate* T2 = P.tmpl2;
+    int s1 = P.rev1 ? T1->rstart[0] : T1->fstart[0];
+    int s2 = P.rev2 ? T2->rstart[0] : T2->fstart[0];
+    chosen = -1;
+    best = P.max_mm1 + P.max_mm2 + 1;
+    for (int p1 = 0; p1 + T1->len <= a.n; ++p1) {
+        int c1 = const_mismatches(T1, P.rev1 != 0, a.p, p1, P.max_mm1);
+        if (c1 > P.max_mm1) continue;
+        Query q1 = pack_region(a.p + p1 + s1, P.table1.len, P.rev1 != 0);
+        for (int p2 = 0; p2 + T2->len <= b.n; ++p2) {
+            int c2 = const_mismatches(T2, P.rev2 != 0, b.p, p2, P.max_mm2);
+            if (c2 > P.max_mm2) continue;
+            Query q2 = pack_region(b.p + p2 + s2, P.table2.len, P.rev2 != 0);
+            int idx, tot;
+            pair_match(P.table1, P.table2, P.pairs, q1, P.max_mm1 - c1, q2, P.max_mm2 - c2, idx, tot);
+            if (idx >= 0) {                             // :333-341
+                int cur = tot + c1 + c2;
+                if (cur < best) { chosen = idx; best = cur; }
+                else if (cur == best && chosen != idx) { chosen = -1; }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void dual_kernel(ScgDualParams P, ScgReads R1, ScgReads R2, int64_t n_pairs,
+                                                      int32_t* __restrict__ counts) {
+    int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n_pairs) return;
+    Read a = get_read(R1, i), b = get_read(R2, i);
+    int idx;
+    if (P.use_first) {                                  // :356-360
+        idx = dual_first(P, a, b);
+        if (idx < 0 && P.randomized) idx = dual_first(P, b, a);
+    } else {                                            // :362-376
+        int best;
+        dual_best(P, a, b, idx, best);
+        if (P.randomized) {
+            int idx2, best2;
+            dual_best(P, b, a, idx2, best2);
+            if (idx < 0 || best > best2) { idx = idx2; best = best2; }
+            else if (best == best2 && idx != idx2) { idx = -1; }
+        }
+    }
+    if (idx >= 0) atomicAdd(&counts[idx], 1);
+}
+
+// ---------------------------------------------------------------------------------------------
+// matchBarcodes: one packed query per lane.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void match_kernel(ScgTable tab, const uint8_t* __restrict__ seqs, int32_t n, int cap, int reverse,
+                                                       int32_t* __restrict__ index_out, int32_t* __restrict__ mm_out) {
+    int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    Query q = pack_region(seqs + (size_t)i * tab.len, tab.len, reverse != 0);
+    int idx, d;
+    table_match(tab, q, cap, idx, d);
+    index_out[i] = idx >= 0 ? idx : -1;
+    mm_out[i] = idx >= 0 ? d : -1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// synthetic reads
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t splitmix64(uint64_t& s) {
+    uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ float u01(uint64_t& s) { return (float)(splitmix64(s) >> 40) * (1.0f / 16777216.0f); }
+__device__ __forceinline__ uint32_t below(uint64_t& s, uint32_t n) { return (uint32_t)(((splitmix64(s) >> 32) * (uint64_t)n) >> 32); }
+
+__global__ __launch_bounds__(BLOCK) void synth_kernel(scg_synth_spec S, char* __restrict__ out, int64_t n_reads) {
+    int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n_reads) return;
+    const char B[4] = {'A', 'C', 'G', 'T'};
+    uint64_t g = (uint64_t)(S.first_read + i);
+    // one stream for the choices every mate of a pair must share, one for this buffer's bases
+    uint64_t shared = S.seed ^ (g * 0xD1342543DE82EF95ull);
+    uint64_t priv = (S.seed + 0x632BE59BD9B4E019ull * (uint64_t)(S.pair_column + 1)) ^ (g * 0xA0761D6478BD642Full);
+    char* dst = out + (size_t)i * (size_t)S.read_len;
+    const int L = S.read_len, T = S.template_len;
+
+    bool junk = u01(shared) < S.p_junk || T > L;
+    bool flip = u01(shared) < S.p_reverse;
+    int k0 = 0, k1 = 0;
+    if (S.d_pair_index) {
+        bool invalid = u01(shared) < S.p_invalid_pair;
+        uint32_t row = below(shared, (uint32_t)S.n_pairs);
+        uint32_t row2 = below(shared, (uint32_t)S.n_pairs);
+        // an "invalid" pair takes its two barcodes from two independent rows
+        int r = (invalid && S.pair_column == 1) ? (int)row2 : (int)row;
+        k0 = S.d_pair_index[2 * (size_t)r + S.pair_column];
+    } else {
+        k0 = (int)below(shared, (uint32_t)(S.n_pool[0] > 0 ? S.n_pool[0] : 1));
+        k1 = (int)below(shared, (uint32_t)(S.n_pool[1] > 0 ? S.n_pool[1] : 1));
+    }
+    int offset = junk ? 0 : (int)below(shared, (uint32_t)(L - T + 1));
+
+    for (int j = 0; j < L; ++j) {
+        char c = B[below(priv, 4)];
+        if (!junk && j >= offset && j < offset + T) {
+            int t = j - offset;
+            char tc = S.d_template[t];
+            if (tc != '-') {
+                c = tc;
+            } else {
+                for (int r = 0; r < S.n_regions; ++r) {
+                    int rel = t - S.region_start[r];
+                    if (rel >= 0 && rel < S.region_len[r]) {
+                        int k = r == 0 ? k0 : k1;
+                        c = S.d_pool[r][(size_t)k * S.region_len[r] + rel];
+                    }
+                }
+            }
+            if (u01(priv) < S.p_sub) {               // substitution to a different base
+                uint32_t cur = c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : 3;
+                c = B[(cur + 1 + below(priv, 3)) & 3];
+            }
+        }
+        if (u01(priv) < S.p_n) c = 'N';
+        dst[j] = c;
+    }
+    if (flip) {
+        for (int a = 0, b = L - 1; a <= b; ++a, --b) {
+            char x = dst[a], y = dst[b];
+            auto comp = [](char ch) { return ch == 'A' ? 'T' : ch == 'C' ? 'G' : ch == 'G' ? 'C' : ch == 'T' ? 'A' : ch; };
+            dst[a] = comp(y);
+            dst[b] = comp(x);
+        }
+    }
+}
+
+inline unsigned grid_for(int64_t n) { return (unsigned)((n + BLOCK - 1) / BLOCK); }
+
+} // namespace
+
+namespace scg {
+
+hipError_t launch_single(const ScgSingleParams& P, const ScgReads& R, int64_t n, int32_t* counts, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(single_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, stream, P, R, n, counts);
+    return hipGetLastError();
+}
+
+hipError_t launch_combo(const ScgComboParams& P, const ScgReads& R, int64_t n, int32_t* cells, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(combo_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, stream, P, R, n, cells);
+    return hipGetLastError();
+}
+
+hipError_t launch_dual(const ScgDualParams& P, const ScgReads& R1, const ScgReads& R2, int64_t n, int32_t* counts, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(dual_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, stream, P, R1, R2, n, counts);
+    return hipGetLastError();
+}
+
+hipError_t launch_match(const ScgTable& tab, const uint8_t* d_seqs, int32_t n, int cap, int reverse,
+                        int32_t* d_index, int32_t* d_mm, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(match_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, stream, tab, d_seqs, n, cap, reverse, d_index, d_mm);
+    return hipGetLastError();
+}
+
+hipError_t launch_synth(const scg_synth_spec& S, char* d_out, int64_t n, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(synth_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, stream, S, d_out, n);
+    return hipGetLastError();
+}
+
+} // namespace scg

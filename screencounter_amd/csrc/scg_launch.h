@@ -1,0 +1,21 @@
+// scg_launch.h -- launchers exported by scg_kernels.hip to the host runtime.
+#ifndef SCG_LAUNCH_H
+#define SCG_LAUNCH_H
+
+#include <hip/hip_runtime_api.h>
+
+#include "../../include/scg.h"
+#include "scg_common.h"
+
+namespace scg {
+
+hipError_t launch_single(const ScgSingleParams& P, const ScgReads& R, int64_t n, int32_t* counts, hipStream_t stream);
+hipError_t launch_combo(const ScgComboParams& P, const ScgReads& R, int64_t n, int32_t* cells, hipStream_t stream);
+hipError_t launch_dual(const ScgDualParams& P, const ScgReads& R1, const ScgReads& R2, int64_t n, int32_t* counts, hipStream_t stream);
+hipError_t launch_match(const ScgTable& tab, const uint8_t* d_seqs, int32_t n, int cap, int reverse,
+                        int32_t* d_index, int32_t* d_mm, hipStream_t stream);
+hipError_t launch_synth(const scg_synth_spec& S, char* d_out, int64_t n, hipStream_t stream);
+
+} // namespace scg
+
+#endif

@@ -1,0 +1,320 @@
+// scg_library.cpp -- host-side compilation of templates and barcode pools into the flat tables
+// the kernels consume.  Replaces the constructors of kaori::ScanTemplate, SimpleBarcodeSearch,
+// SegmentedBarcodeSearch and the mismatch trie build (see scg_host.h for citations).
+#include "scg_host.h"
+
+#include <algorithm>
+#include <cstring>
+
+namespace scg {
+
+namespace {
+
+// code = (ascii >> 1) & 3 :  A0 C1 T2 G3
+inline int base_code(char c) {
+    switch (c) {
+        case 'A': case 'a': return 0;
+        case 'C': case 'c': return 1;
+        case 'T': case 't': return 2;
+        case 'G': case 'g': return 3;
+        default: return -1;
+    }
+}
+
+// Allowed codes of a library character in the reference's expansion order A, C, G, T
+// (kaori/MismatchTrie.hpp:163-188).  Returns the count, 0 for an unknown character.
+int iupac_codes(char c, int out[4]) {
+    const int A = 0, C = 1, T = 2, G = 3;
+    int n = 0;
+    auto put = [&](int x) { out[n++] = x; };
+    switch (c) {
+        case 'A': case 'a': put(A); break;
+        case 'C': case 'c': put(C); break;
+        case 'G': case 'g': put(G); break;
+        case 'T': case 't': put(T); break;
+        case 'R': case 'r': put(A); put(G); break;
+        case 'Y': case 'y': put(C); put(T); break;
+        case 'S': case 's': put(C); put(G); break;
+        case 'W': case 'w': put(A); put(T); break;
+        case 'K': case 'k': put(G); put(T); break;
+        case 'M': case 'm': put(A); put(C); break;
+        case 'B': case 'b': put(C); put(G); put(T); break;
+        case 'D': case 'd': put(A); put(G); put(T); break;
+        case 'H': case 'h': put(A); put(C); put(T); break;
+        case 'V': case 'v': put(A); put(C); put(G); break;
+        case 'N': case 'n': put(A); put(C); put(G); put(T); break;
+        default: break;
+    }
+    return n;
+}
+
+const int64_t MAX_EXPANSIONS = int64_t(1) << 26;
+
+// Calls f(key) for every concrete expansion of `s` in lexicographic (A,C,G,T) order.
+template<class F>
+void for_each_expansion(const char* s, int len, F f) {
+    int cnt[SCG_MAX_BARCODE], codes[SCG_MAX_BARCODE][4], choice[SCG_MAX_BARCODE];
+    for (int p = 0; p < len; ++p) {
+        cnt[p] = iupac_codes(s[p], codes[p]);
+        choice[p] = 0;
+    }
+    for (;;) {
+        uint64_t key = 0;
+        for (int p = 0; p < len; ++p) {
+            key |= static_cast<uint64_t>(codes[p][choice[p]]) << (2 * p);
+        }
+        f(key);
+        int p = len - 1;
+        for (; p >= 0; --p) {
+            if (++choice[p] < cnt[p]) break;
+            choice[p] = 0;
+        }
+        if (p < 0) break;
+    }
+}
+
+int64_t count_expansions(const char* const* pool, int32_t n, int32_t len) {
+    int64_t total = 0;
+    int codes[4];
+    for (int32_t i = 0; i < n; ++i) {
+        int64_t m = 1;
+        for (int p = 0; p < len; ++p) {
+            int c = iupac_codes(pool[i][p], codes);
+            if (c == 0) {
+                // kaori/MismatchTrie.hpp:187
+                throw Error(SCG_ERR_INVALID, std::string("unknown base '") + pool[i][p] + "' detected when constructing the trie");
+            }
+            m *= c;
+            if (m > MAX_EXPANSIONS) break;
+        }
+        total += m;
+        if (total > MAX_EXPANSIONS) {
+            throw Error(SCG_ERR_UNSUPPORTED, "barcode pool expands to more than 2^26 concrete sequences");
+        }
+    }
+    return total;
+}
+
+uint32_t capacity_for(int64_t entries) {
+    uint64_t cap = 16;
+    while (cap < static_cast<uint64_t>(entries) * 4) cap <<= 1;
+    return static_cast<uint32_t>(cap);
+}
+
+struct Builder {
+    std::vector<uint64_t>& keys;
+    std::vector<int32_t>& vals;
+    uint32_t mask;
+    Builder(std::vector<uint64_t>& k, std::vector<int32_t>& v, uint32_t capacity) : keys(k), vals(v), mask(capacity - 1) {
+        keys.assign(capacity, SCG_EMPTY_KEY);
+        vals.assign(capacity, -1);
+    }
+    // Returns the slot holding `key`, inserting it (with val) if absent; *existed tells which.
+    uint32_t upsert(uint64_t key, int32_t val, bool* existed) {
+        uint32_t h = scg_hash64(key) & mask;
+        for (;;) {
+            if (keys[h] == key) { *existed = true; return h; }
+            if (keys[h] == SCG_EMPTY_KEY) { keys[h] = key; vals[h] = val; *existed = false; return h; }
+            h = (h + 1) & mask;
+        }
+    }
+};
+
+void check_len(int32_t len) {
+    if (len > SCG_MAX_BARCODE) {
+        throw Error(SCG_ERR_UNSUPPORTED, "variable regions longer than 32 bp are not supported by this engine (got " + std::to_string(len) + ")");
+    }
+}
+
+[[noreturn]] void throw_duplicate(int32_t a, int32_t b) {
+    // kaori/MismatchTrie.hpp:119-122
+    throw Error(SCG_ERR_INVALID, "duplicate sequences detected (" + std::to_string(a + 1) + ", " + std::to_string(b + 1) + ") when constructing the trie");
+}
+
+} // namespace
+
+HostTemplate parse_template(const char* constant, int strand) {
+    size_t len = std::strlen(constant);
+    if (len > SCG_MAX_TEMPLATE) {
+        // src/count_single_barcodes.cpp:46
+        throw Error(SCG_ERR_INVALID, "lacking compile-time support for constant regions longer than 256 bp");
+    }
+    HostTemplate out;
+    std::memset(&out.t, 0, sizeof(out.t));
+    out.fwd = (strand != 1);   // src/utils.cpp:33-41: 0 forward, 1 reverse, anything else both
+    out.rev = (strand != 0);   // kaori/utils.hpp:33-39
+    ScgTemplate& t = out.t;
+    t.len = static_cast<int32_t>(len);
+
+    int L = t.len;
+    int nreg = 0, nconst = 0;
+    int starts[SCG_MAX_TEMPLATE], ends[SCG_MAX_TEMPLATE];
+    for (int i = 0; i < L; ++i) {
+        char b = constant[i];
+        if (b == '-') {
+            if (nreg && ends[nreg - 1] == i) {
+                ++ends[nreg - 1];
+            } else {
+                starts[nreg] = i; ends[nreg] = i + 1; ++nreg;
+            }
+        } else {
+            int c = base_code(b);
+            if (c < 0) {
+                if (out.fwd) {
+                    throw Error(SCG_ERR_INVALID, std::string("unknown base '") + b + "'");          // kaori/utils.hpp:156-158
+                } else {
+                    throw Error(SCG_ERR_INVALID, std::string("cannot complement unknown base '") + b + "'");  // :117
+                }
+            }
+            t.fpos[nconst] = static_cast<uint8_t>(i);
+            t.fcode[nconst] = static_cast<uint8_t>(c);
+            ++nconst;
+        }
+    }
+    t.nconst = nconst;
+    t.nreg = nreg;
+    // reverse-complemented template: position i of it is the complement of position L-1-i
+    for (int k = 0; k < nconst; ++k) {
+        int src = nconst - 1 - k;
+        t.rpos[k] = static_cast<uint8_t>(L - 1 - t.fpos[src]);
+        t.rcode[k] = static_cast<uint8_t>(t.fcode[src] ^ 2);
+    }
+    // Callers reject any template whose region count is not the one they expect, so only
+    // region counts the engine can use are materialised.
+    if (nreg <= SCG_MAX_REGIONS) {
+        for (int r = 0; r < nreg; ++r) {
+            t.fstart[r] = starts[r];
+            t.flen[r] = ends[r] - starts[r];
+            int src = nreg - 1 - r;             // kaori/ScanTemplate.hpp:82-94
+            t.rstart[r] = L - ends[src];
+            t.rlen[r] = ends[src] - starts[src];
+        }
+    }
+    return out;
+}
+
+int pool_length(const char* const* pool, int32_t n) {
+    // src/utils.cpp:5-23
+    size_t size = 0;
+    for (int32_t i = 0; i < n; ++i) {
+        size_t cur = std::strlen(pool[i]);
+        if (i == 0) {
+            size = cur;
+        } else if (cur != size) {
+            throw Error(SCG_ERR_INVALID, "variable regions should all have the same length (" + std::to_string(size) + ")");
+        }
+    }
+    return static_cast<int>(size);
+}
+
+HostTable build_index_table(const char* const* pool, int32_t n, int32_t len) {
+    check_len(len);
+    HostTable T;
+    T.len = len;
+    int64_t total = count_expansions(pool, n, len);
+    Builder B(T.keys, T.vals, capacity_for(total));
+    T.mask = B.mask;
+    T.list_keys.reserve(total);
+    T.list_vals.reserve(total);
+    for (int32_t i = 0; i < n; ++i) {
+        for_each_expansion(pool[i], len, [&](uint64_t key) {
+            if (key == SCG_EMPTY_KEY) {
+                if (T.sentinel_val >= 0) throw_duplicate(T.sentinel_val, i);
+                T.sentinel_val = i;
+            } else {
+                bool existed;
+                uint32_t slot = B.upsert(key, i, &existed);
+                if (existed) throw_duplicate(T.vals[slot], i);
+            }
+            T.list_keys.push_back(key);
+            T.list_vals.push_back(i);
+        });
+    }
+    T.n_entries = static_cast<int32_t>(T.list_keys.size());
+    return T;
+}
+
+HostTable build_uid_table(const char* const* pool, int32_t n, int32_t len,
+                          std::vector<std::vector<int32_t> >& expansions,
+                          std::vector<uint64_t>& uid_keys) {
+    check_len(len);
+    HostTable T;
+    T.len = len;
+    int64_t total = count_expansions(pool, n, len);
+    Builder B(T.keys, T.vals, capacity_for(total));
+    T.mask = B.mask;
+    expansions.assign(n, std::vector<int32_t>());
+    uid_keys.clear();
+    for (int32_t i = 0; i < n; ++i) {
+        for_each_expansion(pool[i], len, [&](uint64_t key) {
+            int32_t uid;
+            if (key == SCG_EMPTY_KEY) {
+                if (T.sentinel_val < 0) {
+                    T.sentinel_val = static_cast<int32_t>(uid_keys.size());
+                    uid_keys.push_back(key);
+                }
+                uid = T.sentinel_val;
+            } else {
+                bool existed;
+                uint32_t slot = B.upsert(key, static_cast<int32_t>(uid_keys.size()), &existed);
+                if (!existed) uid_keys.push_back(key);
+                uid = T.vals[slot];
+            }
+            expansions[i].push_back(uid);
+        });
+    }
+    T.list_keys = uid_keys;
+    T.list_vals.resize(uid_keys.size());
+    for (size_t u = 0; u < uid_keys.size(); ++u) T.list_vals[u] = static_cast<int32_t>(u);
+    T.n_entries = static_cast<int32_t>(uid_keys.size());
+    return T;
+}
+
+HostPairTable build_pair_table(const std::vector<std::vector<int32_t> >& exp1, const std::vector<uint64_t>& uid_keys1,
+                               const std::vector<std::vector<int32_t> >& exp2, const std::vector<uint64_t>& uid_keys2) {
+    HostPairTable P;
+    int64_t total = 0;
+    for (size_t i = 0; i < exp1.size(); ++i) {
+        total += static_cast<int64_t>(exp1[i].size()) * static_cast<int64_t>(exp2[i].size());
+        if (total > MAX_EXPANSIONS) {
+            throw Error(SCG_ERR_UNSUPPORTED, "barcode pairs expand to more than 2^26 concrete sequences");
+        }
+    }
+    Builder B(P.keys, P.vals, capacity_for(total));
+    P.mask = B.mask;
+    for (size_t i = 0; i < exp1.size(); ++i) {
+        // concatenated expansions in lexicographic order: first barcode major
+        for (int32_t u1 : exp1[i]) {
+            for (int32_t u2 : exp2[i]) {
+                uint64_t key = (static_cast<uint64_t>(static_cast<uint32_t>(u1)) << 32) | static_cast<uint32_t>(u2);
+                bool existed;
+                uint32_t slot = B.upsert(key, static_cast<int32_t>(i), &existed);
+                if (existed) throw_duplicate(P.vals[slot], static_cast<int32_t>(i));
+                P.list_key1.push_back(uid_keys1[u1]);
+                P.list_key2.push_back(uid_keys2[u2]);
+                P.list_vals.push_back(static_cast<int32_t>(i));
+            }
+        }
+    }
+    P.n_entries = static_cast<int32_t>(P.list_vals.size());
+    return P;
+}
+
+bool pack_query(const char* s, int len, bool reverse_complement, uint64_t& key, uint64_t& nmask, int& n_other) {
+    if (len > SCG_MAX_BARCODE) return false;
+    key = 0; nmask = 0; n_other = 0;
+    for (int j = 0; j < len; ++j) {
+        int c = base_code(s[j]);
+        int pos = reverse_complement ? (len - 1 - j) : j;
+        if (c < 0) {
+            nmask |= 3ull << (2 * pos);
+            ++n_other;
+        } else {
+            if (reverse_complement) c ^= 2;
+            key |= static_cast<uint64_t>(c) << (2 * pos);
+        }
+    }
+    return true;
+}
+
+} // namespace scg

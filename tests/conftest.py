@@ -1,0 +1,47 @@
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _ensure_built():
+    """libscg.so and liboracle.so are build products; make them if the tree is fresh."""
+    lib = os.path.join(ROOT, "screencounter_amd", "libscg.so")
+    ora = os.path.join(ROOT, "oracle", "liboracle.so")
+    if not os.path.exists(lib):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "screencounter_amd", "csrc")])
+    if not os.path.exists(ora):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), os.path.join(ROOT, "oracle", "liboracle.so")])
+
+
+_ensure_built()
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle.pyoracle import Oracle
+    return Oracle()
+
+
+@pytest.fixture(scope="session")
+def sc():
+    import screencounter_amd
+    screencounter_amd.load()
+    return screencounter_amd
+
+
+@pytest.fixture(scope="session")
+def gpu():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")

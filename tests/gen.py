@@ -1,0 +1,192 @@
+"""Random workload generators shared by the oracle fuzzers and the parity tests (test infrastructure)."""
+from __future__ import annotations
+
+import random
+
+BASES = "ACGT"
+COMP = {"A": "T", "C": "G", "G": "C", "T": "A", "N": "N", "a": "t", "c": "g", "g": "c", "t": "a", "n": "n"}
+IUPAC = "RYSWKMBDHVN"
+
+
+def rc(s: str) -> str:
+    return "".join(COMP.get(c, "N") for c in reversed(s))
+
+
+def rand_seq(rng: random.Random, n: int, alphabet: str = BASES) -> str:
+    return "".join(rng.choice(alphabet) for _ in range(n))
+
+
+def mutate(rng: random.Random, s: str, p_sub: float, p_n: float, p_lower: float) -> str:
+    out = []
+    for c in s:
+        if rng.random() < p_sub:
+            c = rng.choice([b for b in BASES if b != c.upper()])
+        if rng.random() < p_n:
+            c = rng.choice("NnRX.")  # any non-ACGT byte is "other" to the scanner
+        if rng.random() < p_lower:
+            c = c.lower()
+        out.append(c)
+    return "".join(out)
+
+
+def make_pool(rng: random.Random, n: int, length: int, alphabet: str, min_dist: int = 1, iupac_rate: float = 0.0):
+    """distinct sequences with pairwise Hamming distance >= min_dist (on the concrete bases)"""
+    pool: list[str] = []
+    tries = 0
+    while len(pool) < n and tries < 20000:
+        tries += 1
+        s = rand_seq(rng, length, alphabet)
+        if all(sum(a != b for a, b in zip(s, t)) >= min_dist for t in pool):
+            pool.append(s)
+    if iupac_rate > 0:
+        pool = ["".join(rng.choice(IUPAC) if rng.random() < iupac_rate else c for c in s) for s in pool]
+    return pool
+
+
+def make_template(rng: random.Random, nvar: int, var_lens: list[int], flank_lo: int, flank_hi: int) -> str:
+    parts = [rand_seq(rng, rng.randint(flank_lo, flank_hi))]
+    for v in range(nvar):
+        parts.append("-" * var_lens[v])
+        lo = max(flank_lo, 1) if v < nvar - 1 else flank_lo  # keep regions separate
+        parts.append(rand_seq(rng, rng.randint(lo, flank_hi)))
+    t = "".join(parts)
+    if rng.random() < 0.2:
+        t = t.lower()
+    return t
+
+
+def fill_template(template: str, inserts: list[str]) -> str:
+    out = []
+    it = iter(inserts)
+    i = 0
+    while i < len(template):
+        if template[i] == "-":
+            j = i
+            while j < len(template) and template[j] == "-":
+                j += 1
+            out.append(next(it))
+            i = j
+        else:
+            out.append(template[i].upper())
+            i += 1
+    return "".join(out)
+
+
+def concrete(rng: random.Random, s: str) -> str:
+    """pick one concrete expansion of an IUPAC library string"""
+    table = {"R": "AG", "Y": "CT", "S": "CG", "W": "AT", "K": "GT", "M": "AC", "B": "CGT", "D": "AGT", "H": "ACT", "V": "ACG", "N": "ACGT"}
+    return "".join(rng.choice(table[c]) if c in table else c for c in s.upper())
+
+
+def make_reads(rng, template, pools, n, strand, p_sub, p_n, p_lower, p_junk, pad_hi, valid_pairs=None):
+    reads = []
+    for _ in range(n):
+        if rng.random() < p_junk:
+            reads.append(rand_seq(rng, rng.randint(0, len(template) + pad_hi)))
+            continue
+        if valid_pairs is not None:
+            raise AssertionError
+        ins = [concrete(rng, rng.choice(p)) for p in pools]
+        core = fill_template(template, ins)
+        core = mutate(rng, core, p_sub, p_n, p_lower)
+        read = rand_seq(rng, rng.randint(0, pad_hi)) + core + rand_seq(rng, rng.randint(0, pad_hi))
+        if rng.random() < 0.1:  # two constructs in one read
+            ins2 = [concrete(rng, rng.choice(p)) for p in pools]
+            read += rand_seq(rng, rng.randint(0, 3)) + mutate(rng, fill_template(template, ins2), p_sub, p_n, p_lower)
+        if strand == 1 or (strand == 2 and rng.random() < 0.5):
+            read = rc(read)
+        reads.append(read)
+    return reads
+
+
+
+
+# ---------------------------------------------------------------------------------------------
+# Whole random cases (inputs only) for the three entry points and the matcher.
+# ---------------------------------------------------------------------------------------------
+def random_single_case(rng: random.Random, max_vlen: int = 33, sizes=(1, 30, 200)) -> dict:
+    vlen = rng.choice([v for v in (3, 4, 6, 8, 10, 20, 33) if v <= max_vlen])
+    alphabet = rng.choice(["AC", "ACG", BASES, BASES])
+    npool = rng.choice([1, 2, 5, 20, 100])
+    pool = make_pool(rng, npool, vlen, alphabet, min_dist=1, iupac_rate=rng.choice([0, 0, 0.05]))
+    template = make_template(rng, 1, [vlen], rng.choice([0, 1, 3]), rng.choice([4, 8, 12, 40]))
+    strand = rng.choice([0, 1, 2])
+    mm = rng.choice([0, 1, 1, 2, 3])
+    first = rng.random() < 0.5
+    reads = make_reads(rng, template, [pool], rng.choice(sizes), strand, rng.choice([0, 0.02, 0.08]), rng.choice([0, 0.01, 0.05]),
+                       rng.choice([0, 0.3]), 0.1, rng.choice([0, 5, 30]))
+    return dict(kind="single", template=template, strand=strand, pool=pool, mismatches=mm, use_first=first, reads=reads)
+
+
+def random_combo_case(rng: random.Random, sizes=(1, 30, 200)) -> dict:
+    v0, v1 = rng.choice([3, 5, 8, 14]), rng.choice([3, 6, 14])
+    alphabet = rng.choice(["AC", BASES, BASES])
+    p0 = make_pool(rng, rng.choice([1, 4, 30]), v0, alphabet, iupac_rate=rng.choice([0, 0, 0.05]))
+    p1 = make_pool(rng, rng.choice([1, 4, 30]), v1, alphabet, iupac_rate=rng.choice([0, 0, 0.05]))
+    template = make_template(rng, 2, [v0, v1], rng.choice([0, 1, 3]), rng.choice([4, 8, 12]))
+    strand = rng.choice([0, 1, 2])
+    mm = rng.choice([0, 1, 2, 3])
+    first = rng.random() < 0.5
+    reads = make_reads(rng, template, [p0, p1], rng.choice(sizes), strand, rng.choice([0, 0.03, 0.08]), rng.choice([0, 0.02]),
+                       rng.choice([0, 0.3]), 0.1, rng.choice([0, 5, 30]))
+    return dict(kind="combo", template=template, strand=strand, pool0=p0, pool1=p1, mismatches=mm, use_first=first, reads=reads)
+
+
+def random_dual_case(rng: random.Random, hazard_free: bool = True, sizes=(1, 30, 150), max_mm: int = 2) -> dict:
+    l1, l2 = rng.choice([4, 6, 9, 12]), rng.choice([4, 7, 12])
+    mm1, mm2 = rng.randint(0, max_mm), rng.randint(0, max_mm)
+    # pools whose members are >= 2*cap+1 apart cannot trigger the reference's order-dependent
+    # segmented-search cache
+    d1 = 2 * mm1 + 1 if hazard_free else 1
+    d2 = 2 * mm2 + 1 if hazard_free else 1
+    u1 = make_pool(rng, rng.choice([1, 3, 8]), l1, BASES, min_dist=d1)
+    u2 = make_pool(rng, rng.choice([1, 3, 8]), l2, BASES, min_dist=d2)
+    allpairs = [(a, b) for a in u1 for b in u2]
+    rng.shuffle(allpairs)
+    pairs = allpairs[: rng.randint(1, len(allpairs))]
+    pool1 = [a for a, _ in pairs]
+    pool2 = [b for _, b in pairs]
+    t1 = make_template(rng, 1, [l1], rng.choice([0, 2, 4]), rng.choice([4, 8]))
+    t2 = make_template(rng, 1, [l2], rng.choice([0, 2, 4]), rng.choice([4, 8]))
+    rev1, rev2 = rng.random() < 0.3, rng.random() < 0.3
+    randomized = rng.random() < 0.4
+    first = rng.random() < 0.5
+    n = rng.choice(sizes)
+    r1s, r2s = [], []
+    p_sub, p_n = rng.choice([0, 0.03, 0.08]), rng.choice([0, 0.02])
+    for _ in range(n):
+        u = rng.random()
+        if u < 0.1:
+            a, b = rand_seq(rng, rng.randint(0, 30)), rand_seq(rng, rng.randint(0, 30))
+        else:
+            if u < 0.8:
+                x, y = rng.choice(pairs)
+            else:
+                x, y = rng.choice(u1), rng.choice(u2)
+            a = mutate(rng, fill_template(t1, [x]), p_sub, p_n, 0.05)
+            b = mutate(rng, fill_template(t2, [y]), p_sub, p_n, 0.05)
+            pad = rng.choice([0, 4, 20])
+            a = rand_seq(rng, rng.randint(0, pad)) + a + rand_seq(rng, rng.randint(0, pad))
+            b = rand_seq(rng, rng.randint(0, pad)) + b + rand_seq(rng, rng.randint(0, pad))
+            if rng.random() < 0.1:
+                x2, _ = rng.choice(pairs)
+                a += mutate(rng, fill_template(t1, [x2]), p_sub, p_n, 0.0)
+            if rev1:
+                a = rc(a)
+            if rev2:
+                b = rc(b)
+            if randomized and rng.random() < 0.5:
+                a, b = b, a
+        r1s.append(a)
+        r2s.append(b)
+    return dict(kind="dual", template1=t1, reverse1=rev1, mismatches1=mm1, pool1=pool1,
+                template2=t2, reverse2=rev2, mismatches2=mm2, pool2=pool2,
+                randomized=randomized, use_first=first, reads1=r1s, reads2=r2s)
+
+
+def random_match_case(rng: random.Random) -> dict:
+    vlen = rng.choice([3, 5, 8, 12])
+    alphabet = rng.choice(["AC", BASES])
+    pool = make_pool(rng, rng.choice([1, 4, 30]), vlen, alphabet, iupac_rate=rng.choice([0, 0.1]))
+    seqs = [mutate(rng, concrete(rng, rng.choice(pool)), 0.15, 0.03, 0.1) for _ in range(40)]
+    return dict(kind="match", sequences=seqs, choices=pool, substitutions=rng.choice([0, 1, 2, 3]), reverse=rng.random() < 0.5)
