@@ -170,9 +170,11 @@ int scg_combo_compact(const int32_t* cells, int32_t n_pool0, int32_t n_pool1,
                       int32_t** indices_out, int32_t** freq_out, int64_t* k_out,
                       char* err, size_t errcap);
 
-/* Average duration in milliseconds of the counting kernel launches issued through this plan
- * since the last scg_plan_reset, measured with HIP events recorded on the launch stream around
- * each launch when profiling is switched on.  Used by bench.py for the roofline figure. */
+/* Kernel timing for the roofline figure: while profiling is on, every counting-kernel launch
+ * issued through the plan is bracketed by HIP events recorded on the launch stream.
+ * scg_plan_set_profiling(plan, 1) opens a fresh measurement window; scg_plan_kernel_stats
+ * synchronises on the recorded events and returns their summed duration in milliseconds and the
+ * number of launches in the window. */
 int scg_plan_set_profiling(scg_plan* plan, int enabled);
 int scg_plan_kernel_stats(scg_plan* plan, double* total_ms_out, int64_t* launches_out,
                           char* err, size_t errcap);

@@ -530,7 +530,6 @@ int scg_plan_reset(scg_plan* plan, void* stream, char* err, size_t errcap) {
         DeviceGuard g(plan->device);
         HIP_CHECK(hipMemsetAsync(plan->counters, 0, static_cast<size_t>(plan->n_counters) * sizeof(int32_t), static_cast<hipStream_t>(stream)));
         plan->total = 0;
-        plan->events_used = 0;
     });
 }
 
@@ -580,6 +579,7 @@ int scg_combo_compact(const int32_t* cells, int32_t n_pool0, int32_t n_pool1,
 int scg_plan_set_profiling(scg_plan* plan, int enabled) {
     if (!plan) return SCG_ERR_INVALID;
     plan->profiling = enabled != 0;
+    plan->events_used = 0;   // (re)starting a measurement window
     return SCG_OK;
 }
 
