@@ -149,15 +149,17 @@ int scg_plan_reset(scg_plan* plan, void* stream, char* err, size_t errcap);
 /* Count one batch of single-end reads resident in device memory (single and combo plans).
  *   d_seqs     concatenated read bytes (ASCII, any case; anything but ACGT is "other")
  *   d_offsets  n_reads + 1 byte offsets into d_seqs, or NULL when every read has fixed_len bytes
+ *   max_len    ragged batches only: an upper bound on the read lengths if known, else 0.  A hint
+ *              that selects the LDS tile shape; results never depend on it.
  * Asynchronous on `stream`; accumulates into the plan's counters.  One step of the hot path. */
 int scg_count_batch(scg_plan* plan, const char* d_seqs, const uint32_t* d_offsets, int32_t fixed_len,
-                    int64_t n_reads, void* stream, char* err, size_t errcap);
+                    int32_t max_len, int64_t n_reads, void* stream, char* err, size_t errcap);
 
 /* Same for read pairs (dual plans); pair i is (read i of batch 1, read i of batch 2). */
 int scg_count_batch_paired(scg_plan* plan,
                            const char* d_seqs1, const uint32_t* d_offsets1, int32_t fixed_len1,
                            const char* d_seqs2, const uint32_t* d_offsets2, int32_t fixed_len2,
-                           int64_t n_pairs, void* stream, char* err, size_t errcap);
+                           int32_t max_len, int64_t n_pairs, void* stream, char* err, size_t errcap);
 
 /* Synchronise `stream` and copy the counters (num_counters int32) and the number of reads seen
  * so far to the host.  Either output may be NULL. */

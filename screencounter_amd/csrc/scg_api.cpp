@@ -125,14 +125,14 @@ struct PinnedBuf {
     template<class T> T* as() const { return static_cast<T*>(p); }
 };
 
-struct DevTable {
-    DevBuf keys, vals, lkeys, lvals;
-    ScgTable view;
-    void upload(const scg::HostTable& h) {
-        keys.upload(h.keys); vals.upload(h.vals); lkeys.upload(h.list_keys); lvals.upload(h.list_vals);
-        view.keys = keys.as<uint64_t>(); view.vals = vals.as<int32_t>();
-        view.mask = h.mask; view.len = h.len; view.sentinel_val = h.sentinel_val; view.n_entries = h.n_entries;
-        view.list_keys = lkeys.as<uint64_t>(); view.list_vals = lvals.as<int32_t>();
+struct DevIndex {
+    DevBuf entries, next, slots;
+    ScgIndex view;
+    void upload(const scg::HostIndex& h) {
+        entries.upload(h.entries); next.upload(h.next); slots.upload(h.slots);
+        view.entries = entries.as<uint4>(); view.next = next.as<int32_t>(); view.slots = slots.as<uint2>();
+        view.slot_mask = h.slot_mask; view.n_entries = h.n_entries; view.len = h.len; view.nseg = h.nseg;
+        for (int s = 0; s < SCG_MAX_SEGMENTS; ++s) view.segmask[s] = h.segmask[s];
     }
 };
 
@@ -157,7 +157,7 @@ struct scg_plan {
 
     // host-compiled pieces (valid before any device work)
     scg::HostTemplate ht1, ht2;
-    scg::HostTable htab[2];
+    scg::HostIndex htab[2];
     scg::HostPairTable hpairs;
     int32_t n_pool[2] = {0, 0};
     int max_mm1 = 0, max_mm2 = 0;
@@ -165,7 +165,7 @@ struct scg_plan {
 
     // device state
     DevBuf d_tmpl1, d_tmpl2;
-    DevTable tab[2];
+    DevIndex tab[2];
     DevPairTable pairs;
     DevBuf own_counters;
     int32_t* counters = nullptr;
@@ -196,7 +196,7 @@ struct scg_plan {
         counters = own_counters.as<int32_t>();
         HIP_CHECK(hipMemset(counters, 0, static_cast<size_t>(n_counters) * sizeof(int32_t)));
         // host copies are no longer needed
-        for (auto& h : htab) { h = scg::HostTable(); }
+        for (auto& h : htab) { h = scg::HostIndex(); }
         hpairs = scg::HostPairTable();
     }
 
@@ -219,11 +219,12 @@ struct scg_plan {
 
 namespace {
 
-ScgReads make_reads(const char* d_seqs, const uint32_t* d_offsets, int32_t fixed_len) {
+ScgReads make_reads(const char* d_seqs, const uint32_t* d_offsets, int32_t fixed_len, int32_t max_len) {
     ScgReads r;
     r.seqs = reinterpret_cast<const uint8_t*>(d_seqs);
     r.offsets = d_offsets;
-    r.fixed_len = fixed_len;
+    r.fixed_len = d_offsets ? 0 : fixed_len;
+    r.max_len = d_offsets ? max_len : fixed_len;
     return r;
 }
 
@@ -251,7 +252,8 @@ std::unique_ptr<scg_plan> compile_single(const char* constant, int strand, const
                     ") should be the same as the barcode_pool region (" + std::to_string(vlen) + ")");
     }
     if (mismatches < 0) throw Error(SCG_ERR_INVALID, "negative number of mismatches");
-    P->htab[0] = scg::build_index_table(pool, n_pool, plen);   // BarcodeSearch.hpp:23-60
+    P->htab[0] = scg::build_index(pool, n_pool, plen, mismatches);   // BarcodeSearch.hpp:23-60
+    scg::build_seeds(P->ht1.t, mismatches);
     P->n_pool[0] = n_pool;
     P->n_counters = n_pool;
     P->max_mm1 = mismatches;
@@ -279,8 +281,9 @@ std::unique_ptr<scg_plan> compile_combo(const char* constant, int strand,
         }
     }
     if (mismatches < 0) throw Error(SCG_ERR_INVALID, "negative number of mismatches");
-    P->htab[0] = scg::build_index_table(pool0, n0, len0);
-    P->htab[1] = scg::build_index_table(pool1, n1, len1);
+    P->htab[0] = scg::build_index(pool0, n0, len0, mismatches);
+    P->htab[1] = scg::build_index(pool1, n1, len1, mismatches);
+    scg::build_seeds(P->ht1.t, mismatches);
     P->n_pool[0] = n0; P->n_pool[1] = n1;
     int64_t cells = static_cast<int64_t>(n0) * static_cast<int64_t>(n1);
     if (cells > (int64_t(1) << 30)) {
@@ -315,8 +318,10 @@ std::unique_ptr<scg_plan> compile_dual(const char* constant1, int reverse1, int 
     if (mismatches1 < 0 || mismatches2 < 0) throw Error(SCG_ERR_INVALID, "negative number of mismatches");
     std::vector<std::vector<int32_t> > exp1, exp2;
     std::vector<uint64_t> uk1, uk2;
-    P->htab[0] = scg::build_uid_table(pool1, n_pool, len1, exp1, uk1);
-    P->htab[1] = scg::build_uid_table(pool2, n_pool, len2, exp2, uk2);
+    P->htab[0] = scg::build_uid_index(pool1, n_pool, len1, mismatches1, exp1, uk1);
+    P->htab[1] = scg::build_uid_index(pool2, n_pool, len2, mismatches2, exp2, uk2);
+    scg::build_seeds(P->ht1.t, mismatches1);
+    scg::build_seeds(P->ht2.t, mismatches2);
     P->hpairs = scg::build_pair_table(exp1, uk1, exp2, uk2);   // :138-178 (duplicate pairs => error)
     P->n_pool[0] = P->n_pool[1] = n_pool;
     P->n_counters = n_pool;
@@ -332,18 +337,18 @@ void launch_batch(scg_plan* P, const ScgReads& R, int64_t n, hipStream_t stream)
     if (P->kind == scg_plan::SINGLE) {
         ScgSingleParams sp;
         sp.tmpl = P->d_tmpl1.as<ScgTemplate>();
-        sp.table = P->tab[0].view;
+        sp.index = P->tab[0].view;
         sp.max_mm = P->max_mm1; sp.use_first = P->use_first;
         sp.fwd = P->ht1.fwd; sp.rev = P->ht1.rev;
-        HIP_CHECK(scg::launch_single(sp, R, n, P->counters, stream));
+        HIP_CHECK(scg::launch_single(sp, P->ht1.t.len, R, n, P->counters, stream));
     } else {
         ScgComboParams cp;
         cp.tmpl = P->d_tmpl1.as<ScgTemplate>();
-        cp.table[0] = P->tab[0].view; cp.table[1] = P->tab[1].view;
+        cp.index[0] = P->tab[0].view; cp.index[1] = P->tab[1].view;
         cp.n_pool[0] = P->n_pool[0]; cp.n_pool[1] = P->n_pool[1];
         cp.max_mm = P->max_mm1; cp.use_first = P->use_first;
         cp.fwd = P->ht1.fwd; cp.rev = P->ht1.rev;
-        HIP_CHECK(scg::launch_combo(cp, R, n, P->counters, stream));
+        HIP_CHECK(scg::launch_combo(cp, P->ht1.t.len, R, n, P->counters, stream));
     }
     timer.stop();
     P->total += n;
@@ -353,10 +358,10 @@ void launch_batch_paired(scg_plan* P, const ScgReads& R1, const ScgReads& R2, in
     scg_plan::Timer timer(P, stream);
     ScgDualParams dp;
     dp.tmpl1 = P->d_tmpl1.as<ScgTemplate>(); dp.tmpl2 = P->d_tmpl2.as<ScgTemplate>();
-    dp.table1 = P->tab[0].view; dp.table2 = P->tab[1].view; dp.pairs = P->pairs.view;
+    dp.index1 = P->tab[0].view; dp.index2 = P->tab[1].view; dp.pairs = P->pairs.view;
     dp.rev1 = P->rev1; dp.rev2 = P->rev2; dp.max_mm1 = P->max_mm1; dp.max_mm2 = P->max_mm2;
     dp.randomized = P->randomized; dp.use_first = P->use_first;
-    HIP_CHECK(scg::launch_dual(dp, R1, R2, n, P->counters, stream));
+    HIP_CHECK(scg::launch_dual(dp, std::max(P->ht1.t.len, P->ht2.t.len), R1, R2, n, P->counters, stream));
     timer.stop();
     P->total += n;
 }
@@ -397,10 +402,16 @@ struct Stager {
         s.d_offs[which].ensure((n + 1) * sizeof(uint32_t));
         if (nbytes) std::memcpy(s.h_seqs[which].p, b.seqs.data(), nbytes);
         uint32_t* ho = s.h_offs[which].as<uint32_t>();
-        for (size_t i = 0; i <= n; ++i) ho[i] = static_cast<uint32_t>(b.offsets[i]);
+        uint64_t max_len = 0;
+        ho[0] = static_cast<uint32_t>(b.offsets[0]);
+        for (size_t i = 1; i <= n; ++i) {
+            ho[i] = static_cast<uint32_t>(b.offsets[i]);
+            max_len = std::max<uint64_t>(max_len, b.offsets[i] - b.offsets[i - 1]);
+        }
         if (nbytes) HIP_CHECK(hipMemcpyAsync(s.d_seqs[which].p, s.h_seqs[which].p, nbytes, hipMemcpyHostToDevice, s.stream));
         HIP_CHECK(hipMemcpyAsync(s.d_offs[which].p, ho, (n + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, s.stream));
-        return make_reads(s.d_seqs[which].as<char>(), s.d_offs[which].as<uint32_t>(), 0);
+        return make_reads(s.d_seqs[which].as<char>(), s.d_offs[which].as<uint32_t>(), 0,
+                          static_cast<int32_t>(std::min<uint64_t>(max_len, 1u << 30)));
     }
 
     void drain() {
@@ -533,19 +544,19 @@ int scg_plan_reset(scg_plan* plan, void* stream, char* err, size_t errcap) {
     });
 }
 
-int scg_count_batch(scg_plan* plan, const char* d_seqs, const uint32_t* d_offsets, int32_t fixed_len,
+int scg_count_batch(scg_plan* plan, const char* d_seqs, const uint32_t* d_offsets, int32_t fixed_len, int32_t max_len,
                     int64_t n_reads, void* stream, char* err, size_t errcap) {
     return guarded(err, errcap, [&] {
         if (!plan) throw Error(SCG_ERR_INVALID, "null plan");
         if (plan->kind == scg_plan::DUAL) throw Error(SCG_ERR_INVALID, "scg_count_batch called on a dual plan; use scg_count_batch_paired");
         check_reads_args(d_seqs, d_offsets, fixed_len, n_reads);
         DeviceGuard g(plan->device);
-        launch_batch(plan, make_reads(d_seqs, d_offsets, fixed_len), n_reads, static_cast<hipStream_t>(stream));
+        launch_batch(plan, make_reads(d_seqs, d_offsets, fixed_len, max_len), n_reads, static_cast<hipStream_t>(stream));
     });
 }
 
 int scg_count_batch_paired(scg_plan* plan, const char* d_seqs1, const uint32_t* d_offsets1, int32_t fixed_len1,
-                           const char* d_seqs2, const uint32_t* d_offsets2, int32_t fixed_len2,
+                           const char* d_seqs2, const uint32_t* d_offsets2, int32_t fixed_len2, int32_t max_len,
                            int64_t n_pairs, void* stream, char* err, size_t errcap) {
     return guarded(err, errcap, [&] {
         if (!plan) throw Error(SCG_ERR_INVALID, "null plan");
@@ -553,7 +564,7 @@ int scg_count_batch_paired(scg_plan* plan, const char* d_seqs1, const uint32_t* 
         check_reads_args(d_seqs1, d_offsets1, fixed_len1, n_pairs);
         check_reads_args(d_seqs2, d_offsets2, fixed_len2, n_pairs);
         DeviceGuard g(plan->device);
-        launch_batch_paired(plan, make_reads(d_seqs1, d_offsets1, fixed_len1), make_reads(d_seqs2, d_offsets2, fixed_len2),
+        launch_batch_paired(plan, make_reads(d_seqs1, d_offsets1, fixed_len1, max_len), make_reads(d_seqs2, d_offsets2, fixed_len2, max_len),
                             n_pairs, static_cast<hipStream_t>(stream));
     });
 }
@@ -697,7 +708,7 @@ int scg_match_barcodes(const char* const* sequences, int32_t n_sequences, const 
             throw Error(SCG_ERR_INVALID, "null argument");
         }
         int clen = scg::pool_length(choices, n_choices);                     // src/match_barcodes.cpp:12
-        scg::HostTable ht = scg::build_index_table(choices, n_choices, clen);   // :13
+        scg::HostIndex ht = scg::build_index(choices, n_choices, clen, substitutions < 0 ? 0 : substitutions);   // :13
         int slen = scg::pool_length(sequences, n_sequences);                 // :20
         if (n_sequences > 0 && slen != clen) {
             throw Error(SCG_ERR_INVALID, "sequences should have the same length as the choices (" + std::to_string(clen) + ")");
@@ -706,7 +717,7 @@ int scg_match_barcodes(const char* const* sequences, int32_t n_sequences, const 
         if (n_sequences == 0) return;
         int device = resolve_device(-1);
         DeviceGuard g(device);
-        DevTable tab;
+        DevIndex tab;
         tab.upload(ht);
         std::vector<uint8_t> flat(static_cast<size_t>(n_sequences) * clen);
         for (int32_t i = 0; i < n_sequences; ++i) std::memcpy(flat.data() + static_cast<size_t>(i) * clen, sequences[i], clen);

@@ -3,19 +3,39 @@
 // Base encoding used everywhere on the device: code = (ascii >> 1) & 3, i.e.
 //   A/a -> 0, C/c -> 1, T/t -> 2, G/g -> 3;  complement(code) = code ^ 2.
 // A byte is a "standard base" (kaori/utils.hpp:122-133) iff (byte & 0xDF) == "ACTG"[code].
-// Barcodes of up to 32 bases are packed 2 bits per base into one uint64 (base j at bits 2j, 2j+1).
+//
+// Packed barcodes ("keys") are PLANE-SPLIT: for a barcode of len <= 32 bases, bit j of the low
+// 32-bit word is code bit 0 of base j and bit j of the high word is code bit 1 of base j.
+// The same split is used for reads staged in LDS (one bit-plane per code bit plus a validity
+// plane), so a variable region is cut out of a read with two funnel shifts, reverse-complemented
+// with two bit reversals, and compared with XOR / OR / popcount.
 #ifndef SCG_COMMON_H
 #define SCG_COMMON_H
 
 #include <stdint.h>
+#include <hip/hip_vector_types.h>
 
 #define SCG_MAX_TEMPLATE 256   // reference: src/count_single_barcodes.cpp:37-47
 #define SCG_MAX_REGIONS 2      // reference: src/count_combo_barcodes_single.cpp:44-46
 #define SCG_MAX_BARCODE 32     // bases per variable region handled by the packed-key engine
+#define SCG_MAX_SEGMENTS 4     // pigeonhole segments of the library index (mismatch budgets <= 3)
+#define SCG_MAX_SEEDS 4        // pigeonhole seeds of the constant-region scan (budgets <= 3)
+#define SCG_SEED_LEN 12        // constant bases per seed (at most)
 #define SCG_EMPTY_KEY (~0ull)
 
 #define SCG_MISSING (-1)
 #define SCG_AMBIGUOUS (-2)
+
+// Seeds for the bit-parallel constant-region scan.  With at most k mismatching constant bases,
+// at least one of k+1 disjoint groups of constant positions matches exactly (pigeonhole), so the
+// union of the seeds' exact-match positions is a superset of the positions the reference's
+// ScanTemplate reports (kaori/ScanTemplate.hpp:233-252); every candidate is then verified exactly.
+struct ScgSeeds {
+    int32_t nseeds;                                  // 0 => every position is a candidate
+    int32_t len[SCG_MAX_SEEDS];                      // bases in seed i (0 => matches everywhere)
+    uint8_t pos[SCG_MAX_SEEDS][SCG_SEED_LEN];        // template offsets, ascending
+    uint8_t code[SCG_MAX_SEEDS][SCG_SEED_LEN];       // expected base codes
+};
 
 // One template = constant bases + variable regions (kaori/ScanTemplate.hpp:53-95).
 // Constant positions are listed explicitly so that the scanner touches nothing else.
@@ -31,30 +51,38 @@ struct ScgTemplate {
     uint8_t fcode[SCG_MAX_TEMPLATE];   // base code expected at fpos[k]
     uint8_t rpos[SCG_MAX_TEMPLATE];    // constant positions, reverse-complemented template
     uint8_t rcode[SCG_MAX_TEMPLATE];
+    // bit-plane form of the same information, for the LDS-staged kernels (word w covers template
+    // positions 32w .. 32w+31): code bit planes and the constant-position mask, per strand
+    uint32_t fplane0[SCG_MAX_TEMPLATE / 32], fplane1[SCG_MAX_TEMPLATE / 32], fmask[SCG_MAX_TEMPLATE / 32];
+    uint32_t rplane0[SCG_MAX_TEMPLATE / 32], rplane1[SCG_MAX_TEMPLATE / 32], rmask[SCG_MAX_TEMPLATE / 32];
+    ScgSeeds fseeds, rseeds;           // built for the plan's mismatch budget
 };
 
-// Open-addressing hash table: packed concrete barcode -> value (barcode index, or sequence uid
-// for dual pools).  Replaces the exact std::unordered_map + mismatch trie of
-// kaori/BarcodeSearch.hpp:243-251; mismatch search enumerates the Hamming neighbourhood
-// of the query instead of walking a trie (same unique-minimum semantics).
-struct ScgTable {
-    const uint64_t* keys;     // capacity entries, SCG_EMPTY_KEY where free
-    const int32_t* vals;
-    uint32_t mask;            // capacity - 1
-    int32_t len;              // bases per key
-    int32_t sentinel_val;     // value of the one key that equals SCG_EMPTY_KEY (32 x G), else -1
-    int32_t n_entries;        // concrete sequences stored (after IUPAC expansion)
-    const uint64_t* list_keys;  // the same entries as a dense list, for brute-force search
-    const int32_t* list_vals;
+// Library index: every concrete barcode (IUPAC codes expanded) once, reachable through
+// nseg = budget + 1 hash tables keyed by disjoint segments of the barcode.  An entry within
+// Hamming distance <= c of a query agrees with it exactly on at least one of any c+1 segments,
+// so walking c+1 short chains and verifying each member by XOR + popcount finds every
+// neighbour.  Replaces the exact std::unordered_map + mismatch trie + per-thread caches of
+// kaori/BarcodeSearch.hpp:243-251 and kaori/MismatchTrie.hpp:446-501 with the same
+// unique-minimum semantics.
+struct ScgIndex {
+    const uint4* entries;       // n_entries x {key lo, key hi, value, 0}
+    const int32_t* next;        // [nseg][n_entries] chain links (-1 ends a chain)
+    const uint2* slots;         // [nseg][slot_mask + 1] {tag, head entry + 1} ; head 0 = empty
+    uint32_t slot_mask;
+    int32_t n_entries;
+    int32_t len;                // bases per key
+    int32_t nseg;               // 0 => no index (budget too wide): dense scan of `entries`
+    uint64_t segmask[SCG_MAX_SEGMENTS];   // plane-split mask of segment s
 };
 
 // (uid1, uid2) -> valid pair index, for dual barcodes (kaori/handlers/DualBarcodesPairedEnd.hpp:138-178).
 struct ScgPairTable {
-    const uint64_t* keys;     // (uid1 << 32) | uid2
+    const uint64_t* keys;     // (uid1 << 32) | uid2, SCG_EMPTY_KEY where free
     const int32_t* vals;
     uint32_t mask;
     int32_t n_entries;
-    // dense list of every concrete (seq1, seq2, pair index) for brute-force search at caps > 2
+    // dense list of every concrete (seq1, seq2, pair index) for brute-force search at wide budgets
     const uint64_t* list_key1;
     const uint64_t* list_key2;
     const int32_t* list_vals;
@@ -64,11 +92,12 @@ struct ScgReads {
     const uint8_t* seqs;
     const uint32_t* offsets;  // n + 1 entries, or nullptr for fixed-length reads
     int32_t fixed_len;
+    int32_t max_len;          // hint: upper bound on the read lengths (0 = unknown); picks the LDS tile shape only
 };
 
 struct ScgSingleParams {
     const ScgTemplate* tmpl;
-    ScgTable table;
+    ScgIndex index;
     int32_t max_mm;
     int32_t use_first;
     int32_t fwd, rev;
@@ -76,7 +105,7 @@ struct ScgSingleParams {
 
 struct ScgComboParams {
     const ScgTemplate* tmpl;
-    ScgTable table[SCG_MAX_REGIONS];
+    ScgIndex index[SCG_MAX_REGIONS];
     int32_t n_pool[SCG_MAX_REGIONS];
     int32_t max_mm;
     int32_t use_first;
@@ -86,7 +115,7 @@ struct ScgComboParams {
 struct ScgDualParams {
     const ScgTemplate* tmpl1;
     const ScgTemplate* tmpl2;
-    ScgTable table1, table2;
+    ScgIndex index1, index2;
     ScgPairTable pairs;
     int32_t rev1, rev2;
     int32_t max_mm1, max_mm2;

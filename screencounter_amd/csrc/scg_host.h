@@ -34,24 +34,26 @@ HostTemplate parse_template(const char* constant, int strand);
 // ---------------------------------------------------------------------------------------------
 int pool_length(const char* const* pool, int32_t n);   // throws if lengths differ
 
-struct HostTable {
+struct HostIndex {
     int32_t len = 0;
     int32_t n_entries = 0;
-    uint32_t mask = 0;
-    int32_t sentinel_val = -1;
-    std::vector<uint64_t> keys;
-    std::vector<int32_t> vals;
-    std::vector<uint64_t> list_keys;
-    std::vector<int32_t> list_vals;
+    int32_t nseg = 0;
+    uint32_t slot_mask = 0;
+    uint64_t segmask[SCG_MAX_SEGMENTS] = {0, 0, 0, 0};
+    std::vector<uint32_t> entries;   // 4 words per entry: key lo, key hi, value, 0
+    std::vector<int32_t> next;       // [nseg][n_entries]
+    std::vector<uint32_t> slots;     // 2 words per slot: tag, head + 1 ; [nseg][slot_mask + 1]
 };
 
+// max_mm is the plan's mismatch budget for this pool: the index gets max_mm + 1 segments
+// (none, i.e. dense scans, when that exceeds SCG_MAX_SEGMENTS).
 // value = barcode index; two barcodes sharing one concrete sequence => Error("duplicate sequences
 // detected (a, b) when constructing the trie").
-HostTable build_index_table(const char* const* pool, int32_t n, int32_t len);
+HostIndex build_index(const char* const* pool, int32_t n, int32_t len, int max_mm);
 
 // value = uid of the concrete sequence (duplicates within the pool merge).  expansions[i] receives
 // the uids of barcode i's concrete expansions, in lexicographic (A,C,G,T) order.
-HostTable build_uid_table(const char* const* pool, int32_t n, int32_t len,
+HostIndex build_uid_index(const char* const* pool, int32_t n, int32_t len, int max_mm,
                           std::vector<std::vector<int32_t> >& expansions,
                           std::vector<uint64_t>& uid_keys);
 
@@ -66,9 +68,9 @@ struct HostPairTable {
 HostPairTable build_pair_table(const std::vector<std::vector<int32_t> >& exp1, const std::vector<uint64_t>& uid_keys1,
                                const std::vector<std::vector<int32_t> >& exp2, const std::vector<uint64_t>& uid_keys2);
 
-// Packs an ASCII query (reads side: only ACGT are bases).  Returns false if longer than 32.
-// nmask gets 0b11 at every non-ACGT position.
-bool pack_query(const char* s, int len, bool reverse_complement, uint64_t& key, uint64_t& nmask, int& n_other);
+// Chooses the pigeonhole seeds of both strands for a mismatch budget (fills t.fseeds / t.rseeds).
+void build_seeds(ScgTemplate& t, int max_mm);
+
 
 // ---------------------------------------------------------------------------------------------
 // FASTQ: kaori/FastqReader.hpp:42-110 over byteme readers.

@@ -1,6 +1,10 @@
 // scg_kernels.hip -- counting kernels (gfx950) and their launchers.
 //
-// General engine: one read (or read pair) per lane.  Each kernel is the device counterpart of one
+// Two engines compute the same function.  The *staged* kernels (scg_staged.hip.h: reads transposed
+// into LDS bit planes, bit-parallel seed scan, exact verification) are what normally runs; the
+// byte-wise *general* engine handles whatever does not fit the staged tiles (very long reads or
+// templates) from inside the same kernels, and can be forced with SCG_FORCE_GENERAL=1 for tests.
+// One read (or read pair) per lane.  Each kernel is the device counterpart of one
 // kaori handler's process() (paths relative to inst/include/kaori/handlers/ in the reference):
 //   single_kernel <- SingleBarcodeSingleEnd::process          SingleBarcodeSingleEnd.hpp:93-104
 //                    + SimpleSingleMatch::search_first/best    ../SimpleSingleMatch.hpp:200-306
@@ -9,7 +13,10 @@
 // Per-handler vector<int> counters + serial reduce() become device atomics on one int32 array.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "scg_engine.hip.h"
+#include "scg_staged.hip.h"
 #include "scg_launch.h"
 
 using namespace scgdev;
@@ -32,9 +39,9 @@ __device__ __forceinline__ int single_read(const ScgSingleParams& P, const Read&
             int c = const_mismatches(T, s != 0, rd.p, p, max_mm);
             if (c > max_mm) continue;
             int start = s ? T->rstart[0] : T->fstart[0];
-            Query q = pack_region(rd.p + p + start, P.table.len, s != 0);
+            Query q = pack_region(rd.p + p + start, P.index.len, s != 0);
             int idx, d;
-            table_match(P.table, q, max_mm - c, idx, d);
+            index_match(P.index, q, max_mm - c, idx, d);
             if (idx < 0) continue;
             int tot = c + d;
             if (P.use_first) {
@@ -69,10 +76,10 @@ __device__ __forceinline__ bool combo_candidate(const ScgComboParams& P, const R
         // reverse scan order meets the pools back to front (CombinatorialBarcodesSingleEnd.hpp:111-116)
         int slot = reverse ? (SCG_MAX_REGIONS - 1 - r) : r;
         int start = reverse ? T->rstart[r] : T->fstart[r];
-        const ScgTable& tab = P.table[slot];
+        const ScgIndex& tab = P.index[slot];
         Query q = pack_region(rd.p + p + start, tab.len, reverse);
         int idx, d;
-        table_match(tab, q, P.max_mm - obs, idx, d);   // :168
+        index_match(tab, q, P.max_mm - obs, idx, d);   // :168
         if (idx < 0) return false;
         obs += d;
         if (obs > P.max_mm) return false;               // :173-176
@@ -82,15 +89,11 @@ __device__ __forceinline__ bool combo_candidate(const ScgComboParams& P, const R
     return true;
 }
 
-__global__ __launch_bounds__(BLOCK) void combo_kernel(ScgComboParams P, ScgReads R, int64_t n_reads,
-                                                       int32_t* __restrict__ cells) {
-    int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= n_reads) return;
-    Read rd = get_read(R, i);
+// Returns 1 and fills best_id when the read yields a combination.
+__device__ __forceinline__ int combo_read(const ScgComboParams& P, const Read& rd, int best_id[SCG_MAX_REGIONS]) {
     const ScgTemplate* T = P.tmpl;
     const int len = T->len;
     int found = 0, best = P.max_mm + 1;
-    int best_id[SCG_MAX_REGIONS] = {0, 0};
     for (int p = 0; p + len <= rd.n && !(found && P.use_first); ++p) {
         for (int s = 0; s < 2; ++s) {
             if (s == 0 ? !P.fwd : !P.rev) continue;
@@ -110,7 +113,16 @@ __global__ __launch_bounds__(BLOCK) void combo_kernel(ScgComboParams P, ScgReads
             }
         }
     }
-    if (found) atomicAdd(&cells[(int64_t)best_id[0] * P.n_pool[1] + best_id[1]], 1);
+    return found;
+}
+
+__global__ __launch_bounds__(BLOCK) void combo_kernel(ScgComboParams P, ScgReads R, int64_t n_reads,
+                                                       int32_t* __restrict__ cells) {
+    int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n_reads) return;
+    Read rd = get_read(R, i);
+    int best_id[SCG_MAX_REGIONS] = {0, 0};
+    if (combo_read(P, rd, best_id)) atomicAdd(&cells[(int64_t)best_id[0] * P.n_pool[1] + best_id[1]], 1);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -126,13 +138,13 @@ __device__ __forceinline__ int dual_first(const ScgDualParams& P, const Read& a,
     for (int p1 = 0; p1 + T1->len <= a.n; ++p1) {
         int c1 = const_mismatches(T1, P.rev1 != 0, a.p, p1, P.max_mm1);
         if (c1 > P.max_mm1) continue;
-        Query q1 = pack_region(a.p + p1 + s1, P.table1.len, P.rev1 != 0);
+        Query q1 = pack_region(a.p + p1 + s1, P.index1.len, P.rev1 != 0);
         for (int p2 = 0; p2 + T2->len <= b.n; ++p2) {
             int c2 = const_mismatches(T2, P.rev2 != 0, b.p, p2, P.max_mm2);
             if (c2 > P.max_mm2) continue;
-            Query q2 = pack_region(b.p + p2 + s2, P.table2.len, P.rev2 != 0);
+            Query q2 = pack_region(b.p + p2 + s2, P.index2.len, P.rev2 != 0);
             int idx, tot;
-            pair_match(P.table1, P.table2, P.pairs, q1, P.max_mm1 - c1, q2, P.max_mm2 - c2, idx, tot);
+            pair_match(P.index1, P.index2, P.pairs, q1, P.max_mm1 - c1, q2, P.max_mm2 - c2, idx, tot);
             if (idx >= 0) return idx;                   // DualBarcodesPairedEnd.hpp:264-276
         }
     }
@@ -150,13 +162,13 @@ __device__ __forceinline__ void dual_best(const ScgDualParams& P, const Read& a,
     for (int p1 = 0; p1 + T1->len <= a.n; ++p1) {
         int c1 = const_mismatches(T1, P.rev1 != 0, a.p, p1, P.max_mm1);
         if (c1 > P.max_mm1) continue;
-        Query q1 = pack_region(a.p + p1 + s1, P.table1.len, P.rev1 != 0);
+        Query q1 = pack_region(a.p + p1 + s1, P.index1.len, P.rev1 != 0);
         for (int p2 = 0; p2 + T2->len <= b.n; ++p2) {
             int c2 = const_mismatches(T2, P.rev2 != 0, b.p, p2, P.max_mm2);
             if (c2 > P.max_mm2) continue;
-            Query q2 = pack_region(b.p + p2 + s2, P.table2.len, P.rev2 != 0);
+            Query q2 = pack_region(b.p + p2 + s2, P.index2.len, P.rev2 != 0);
             int idx, tot;
-            pair_match(P.table1, P.table2, P.pairs, q1, P.max_mm1 - c1, q2, P.max_mm2 - c2, idx, tot);
+            pair_match(P.index1, P.index2, P.pairs, q1, P.max_mm1 - c1, q2, P.max_mm2 - c2, idx, tot);
             if (idx >= 0) {                             // :333-341
                 int cur = tot + c1 + c2;
                 if (cur < best) { chosen = idx; best = cur; }
@@ -166,11 +178,7 @@ __device__ __forceinline__ void dual_best(const ScgDualParams& P, const Read& a,
     }
 }
 
-__global__ __launch_bounds__(BLOCK) void dual_kernel(ScgDualParams P, ScgReads R1, ScgReads R2, int64_t n_pairs,
-                                                      int32_t* __restrict__ counts) {
-    int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= n_pairs) return;
-    Read a = get_read(R1, i), b = get_read(R2, i);
+__device__ __forceinline__ int dual_pair(const ScgDualParams& P, const Read& a, const Read& b) {
     int idx;
     if (P.use_first) {                                  // :356-360
         idx = dual_first(P, a, b);
@@ -185,19 +193,243 @@ __global__ __launch_bounds__(BLOCK) void dual_kernel(ScgDualParams P, ScgReads R
             else if (best == best2 && idx != idx2) { idx = -1; }
         }
     }
+    return idx;
+}
+
+__global__ __launch_bounds__(BLOCK) void dual_kernel(ScgDualParams P, ScgReads R1, ScgReads R2, int64_t n_pairs,
+                                                      int32_t* __restrict__ counts) {
+    int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n_pairs) return;
+    Read a = get_read(R1, i), b = get_read(R2, i);
+    int idx = dual_pair(P, a, b);
+    if (idx >= 0) atomicAdd(&counts[idx], 1);
+}
+
+// =============================================================================================
+// Staged kernels
+// =============================================================================================
+template<int NW, int NT>
+__device__ __forceinline__ int single_read_staged(const ScgSingleParams& P, const Tile<NW>& tile, const StagedRead& sr) {
+    const ScgTemplate* T = P.tmpl;
+    const int max_mm = P.max_mm;
+    uint32_t candF[NW], candR[NW];
+    scan_read<NW>(tile, sr, T, P.fwd != 0, P.rev != 0, candF, candR);
+    int found = 0, index = -1, best = max_mm + 1;
+    for (;;) {
+        int pf = first_bit<NW>(candF), pr = first_bit<NW>(candR);
+        bool rev = pr < pf;                           // forward first on ties
+        int p = rev ? pr : pf;
+        if (p >= (1 << 30)) break;
+        clear_bit<NW>(candF, rev ? -1 : p);
+        clear_bit<NW>(candR, rev ? p : -1);
+        int c = window_mismatches<NW, NT>(tile, sr.bit + p, T, rev);
+        if (c > max_mm) continue;
+        int start = rev ? T->rstart[0] : T->fstart[0];
+        Query q = region_query<NW>(tile, sr.bit + p + start, P.index.len, rev);
+        int idx, d;
+        index_match(P.index, q, max_mm - c, idx, d);
+        if (idx < 0) continue;
+        int tot = c + d;
+        if (P.use_first) {
+            return idx;
+        } else if (tot == best) {
+            if (index != idx) { found = 0; index = -1; }
+        } else if (tot < best) {
+            found = 1; best = tot; index = idx;
+        }
+    }
+    return found ? index : -1;
+}
+
+template<int NW, int NT>
+__global__ __launch_bounds__(STAGE_BLOCK) void single_staged_kernel(ScgSingleParams P, ScgReads R, int64_t n_reads,
+                                                                   int32_t* __restrict__ counts) {
+    __shared__ Tile<NW> tile;
+    const int64_t r0 = (int64_t)blockIdx.x * STAGE_BLOCK;
+    const int nr = (int)((n_reads - r0) < STAGE_BLOCK ? (n_reads - r0) : STAGE_BLOCK);
+    int64_t span0 = 0;
+    const bool staged = (P.tmpl->len <= 32 * NT) && stage_reads<NW>(R, n_reads, r0, nr, tile, span0);
+    __syncthreads();
+    if ((int)threadIdx.x >= nr) return;
+    Read rd = get_read(R, r0 + threadIdx.x);
+    int idx;
+    if (staged && rd.n <= 32 * NW) {
+        StagedRead sr;
+        sr.bit = (int)((int64_t)(rd.p - R.seqs) - span0);
+        sr.n = rd.n;
+        idx = single_read_staged<NW, NT>(P, tile, sr);
+    } else {
+        idx = single_read(P, rd);
+    }
+    if (idx >= 0) atomicAdd(&counts[idx], 1);
+}
+
+template<int NW, int NT>
+__device__ __forceinline__ bool combo_candidate_staged(const ScgComboParams& P, const Tile<NW>& tile, const StagedRead& sr,
+                                                       int p, bool reverse, int c, int out[SCG_MAX_REGIONS], int& total) {
+    const ScgTemplate* T = P.tmpl;
+    int obs = c;
+#pragma unroll
+    for (int r = 0; r < SCG_MAX_REGIONS; ++r) {
+        int slot = reverse ? (SCG_MAX_REGIONS - 1 - r) : r;
+        int start = reverse ? T->rstart[r] : T->fstart[r];
+        const ScgIndex& tab = P.index[slot];
+        Query q = region_query<NW>(tile, sr.bit + p + start, tab.len, reverse);
+        int idx, d;
+        index_match(tab, q, P.max_mm - obs, idx, d);
+        if (idx < 0) return false;
+        obs += d;
+        if (obs > P.max_mm) return false;
+        out[slot] = idx;
+    }
+    total = obs;
+    return true;
+}
+
+template<int NW, int NT>
+__global__ __launch_bounds__(STAGE_BLOCK) void combo_staged_kernel(ScgComboParams P, ScgReads R, int64_t n_reads,
+                                                                  int32_t* __restrict__ cells) {
+    __shared__ Tile<NW> tile;
+    const int64_t r0 = (int64_t)blockIdx.x * STAGE_BLOCK;
+    const int nr = (int)((n_reads - r0) < STAGE_BLOCK ? (n_reads - r0) : STAGE_BLOCK);
+    int64_t span0 = 0;
+    const bool staged = (P.tmpl->len <= 32 * NT) && stage_reads<NW>(R, n_reads, r0, nr, tile, span0);
+    __syncthreads();
+    if ((int)threadIdx.x >= nr) return;
+    Read rd = get_read(R, r0 + threadIdx.x);
+    int found = 0, best = P.max_mm + 1;
+    int best_id[SCG_MAX_REGIONS] = {0, 0};
+    if (staged && rd.n <= 32 * NW) {
+        const ScgTemplate* T = P.tmpl;
+        StagedRead sr;
+        sr.bit = (int)((int64_t)(rd.p - R.seqs) - span0);
+        sr.n = rd.n;
+        uint32_t candF[NW], candR[NW];
+        scan_read<NW>(tile, sr, T, P.fwd != 0, P.rev != 0, candF, candR);
+        for (;;) {
+            int pf = first_bit<NW>(candF), pr = first_bit<NW>(candR);
+            bool rev = pr < pf;
+            int p = rev ? pr : pf;
+            if (p >= (1 << 30)) break;
+            clear_bit<NW>(candF, rev ? -1 : p);
+            clear_bit<NW>(candR, rev ? p : -1);
+            int c = window_mismatches<NW, NT>(tile, sr.bit + p, T, rev);
+            if (c > P.max_mm) continue;
+            int cand[SCG_MAX_REGIONS], tot;
+            if (!combo_candidate_staged<NW, NT>(P, tile, sr, p, rev, c, cand, tot)) continue;
+            if (P.use_first) {
+                found = 1; best_id[0] = cand[0]; best_id[1] = cand[1];
+                break;
+            } else if (tot <= best) {
+                if (tot == best) {
+                    if (best_id[0] != cand[0] || best_id[1] != cand[1]) found = 0;
+                } else {
+                    found = 1; best = tot; best_id[0] = cand[0]; best_id[1] = cand[1];
+                }
+            }
+        }
+    } else {
+        found = combo_read(P, rd, best_id);
+    }
+    if (found) atomicAdd(&cells[(int64_t)best_id[0] * P.n_pool[1] + best_id[1]], 1);
+}
+
+// One orientation of a staged pair: template 1 on (ta, a), template 2 on (tb, b).
+template<int NW, int NT, bool BEST>
+__device__ __forceinline__ void dual_orientation_staged(const ScgDualParams& P,
+                                                        const Tile<NW>& ta, const StagedRead& a,
+                                                        const Tile<NW>& tb, const StagedRead& b,
+                                                        int& chosen, int& best) {
+    const ScgTemplate* T1 = P.tmpl1;
+    const ScgTemplate* T2 = P.tmpl2;
+    const bool rev1 = P.rev1 != 0, rev2 = P.rev2 != 0;
+    const int s1 = rev1 ? T1->rstart[0] : T1->fstart[0];
+    const int s2 = rev2 ? T2->rstart[0] : T2->fstart[0];
+    chosen = -1;
+    best = P.max_mm1 + P.max_mm2 + 1;
+    uint32_t c1[NW], c2[NW], unused[NW];
+    if (rev1) scan_read<NW>(ta, a, T1, false, true, unused, c1); else scan_read<NW>(ta, a, T1, true, false, c1, unused);
+    if (rev2) scan_read<NW>(tb, b, T2, false, true, unused, c2); else scan_read<NW>(tb, b, T2, true, false, c2, unused);
+    for (;;) {
+        int p1 = first_bit<NW>(c1);
+        if (p1 >= (1 << 30)) break;
+        clear_bit<NW>(c1, p1);
+        int m1 = window_mismatches<NW, NT>(ta, a.bit + p1, T1, rev1);
+        if (m1 > P.max_mm1) continue;
+        Query q1 = region_query<NW>(ta, a.bit + p1 + s1, P.index1.len, rev1);
+        uint32_t w2[NW];
+#pragma unroll
+        for (int i = 0; i < NW; ++i) w2[i] = c2[i];
+        for (;;) {
+            int p2 = first_bit<NW>(w2);
+            if (p2 >= (1 << 30)) break;
+            clear_bit<NW>(w2, p2);
+            int m2 = window_mismatches<NW, NT>(tb, b.bit + p2, T2, rev2);
+            if (m2 > P.max_mm2) {
+                clear_bit<NW>(c2, p2);      // never a hit of mate 2: drop it for later outer iterations
+                continue;
+            }
+            Query q2 = region_query<NW>(tb, b.bit + p2 + s2, P.index2.len, rev2);
+            int idx, tot;
+            pair_match(P.index1, P.index2, P.pairs, q1, P.max_mm1 - m1, q2, P.max_mm2 - m2, idx, tot);
+            if (idx >= 0) {
+                if (!BEST) { chosen = idx; return; }
+                int cur = tot + m1 + m2;
+                if (cur < best) { chosen = idx; best = cur; }
+                else if (cur == best && chosen != idx) { chosen = -1; }
+            }
+        }
+    }
+}
+
+template<int NW, int NT>
+__global__ __launch_bounds__(STAGE_BLOCK) void dual_staged_kernel(ScgDualParams P, ScgReads R1, ScgReads R2, int64_t n_pairs,
+                                                                 int32_t* __restrict__ counts) {
+    __shared__ Tile<NW> tile1;
+    __shared__ Tile<NW> tile2;
+    const int64_t r0 = (int64_t)blockIdx.x * STAGE_BLOCK;
+    const int nr = (int)((n_pairs - r0) < STAGE_BLOCK ? (n_pairs - r0) : STAGE_BLOCK);
+    int64_t span1 = 0, span2 = 0;
+    const bool fits = P.tmpl1->len <= 32 * NT && P.tmpl2->len <= 32 * NT;
+    const bool ok1 = fits && stage_reads<NW>(R1, n_pairs, r0, nr, tile1, span1);
+    const bool ok2 = ok1 && stage_reads<NW>(R2, n_pairs, r0, nr, tile2, span2);
+    __syncthreads();
+    if ((int)threadIdx.x >= nr) return;
+    Read a = get_read(R1, r0 + threadIdx.x), b = get_read(R2, r0 + threadIdx.x);
+    int idx;
+    if (ok2 && a.n <= 32 * NW && b.n <= 32 * NW) {
+        StagedRead sa, sb;
+        sa.bit = (int)((int64_t)(a.p - R1.seqs) - span1); sa.n = a.n;
+        sb.bit = (int)((int64_t)(b.p - R2.seqs) - span2); sb.n = b.n;
+        int best;
+        if (P.use_first) {
+            dual_orientation_staged<NW, NT, false>(P, tile1, sa, tile2, sb, idx, best);
+            if (idx < 0 && P.randomized) dual_orientation_staged<NW, NT, false>(P, tile2, sb, tile1, sa, idx, best);
+        } else {
+            dual_orientation_staged<NW, NT, true>(P, tile1, sa, tile2, sb, idx, best);
+            if (P.randomized) {
+                int idx2, best2;
+                dual_orientation_staged<NW, NT, true>(P, tile2, sb, tile1, sa, idx2, best2);
+                if (idx < 0 || best > best2) { idx = idx2; best = best2; }
+                else if (best == best2 && idx != idx2) { idx = -1; }
+            }
+        }
+    } else {
+        idx = dual_pair(P, a, b);
+    }
     if (idx >= 0) atomicAdd(&counts[idx], 1);
 }
 
 // ---------------------------------------------------------------------------------------------
 // matchBarcodes: one packed query per lane.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void match_kernel(ScgTable tab, const uint8_t* __restrict__ seqs, int32_t n, int cap, int reverse,
+__global__ __launch_bounds__(BLOCK) void match_kernel(ScgIndex tab, const uint8_t* __restrict__ seqs, int32_t n, int cap, int reverse,
                                                        int32_t* __restrict__ index_out, int32_t* __restrict__ mm_out) {
     int i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
     Query q = pack_region(seqs + (size_t)i * tab.len, tab.len, reverse != 0);
     int idx, d;
-    table_match(tab, q, cap, idx, d);
+    index_match(tab, q, cap, idx, d);
     index_out[i] = idx >= 0 ? idx : -1;
     mm_out[i] = idx >= 0 ? d : -1;
 }
@@ -281,25 +513,74 @@ inline unsigned grid_for(int64_t n) { return (unsigned)((n + BLOCK - 1) / BLOCK)
 
 namespace scg {
 
-hipError_t launch_single(const ScgSingleParams& P, const ScgReads& R, int64_t n, int32_t* counts, hipStream_t stream) {
-    if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(single_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, stream, P, R, n, counts);
-    return hipGetLastError();
+namespace {
+
+// Test hook: SCG_FORCE_GENERAL=1 runs the byte-wise engine alone (read at every launch so that a
+// test process can flip it).
+bool force_general() {
+    const char* e = std::getenv("SCG_FORCE_GENERAL");
+    return e && *e && *e != '0';
 }
 
-hipError_t launch_combo(const ScgComboParams& P, const ScgReads& R, int64_t n, int32_t* cells, hipStream_t stream) {
-    if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(combo_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, stream, P, R, n, cells);
-    return hipGetLastError();
+// NW in {5, 10}: plane words per read; NT in {2, 4, 8}: plane words per template window.
+template<template<int, int> class Launch, class... Args>
+hipError_t dispatch_shape(int max_len, int tmpl_len, Args&&... args) {
+    const bool wide = max_len > 160;
+    if (tmpl_len <= 64) return wide ? Launch<10, 2>::go(args...) : Launch<5, 2>::go(args...);
+    if (tmpl_len <= 128) return wide ? Launch<10, 4>::go(args...) : Launch<5, 4>::go(args...);
+    return wide ? Launch<10, 8>::go(args...) : Launch<5, 8>::go(args...);
 }
 
-hipError_t launch_dual(const ScgDualParams& P, const ScgReads& R1, const ScgReads& R2, int64_t n, int32_t* counts, hipStream_t stream) {
+template<int NW, int NT> struct LaunchSingle {
+    static hipError_t go(const ScgSingleParams& P, const ScgReads& R, int64_t n, int32_t* counts, hipStream_t stream) {
+        hipLaunchKernelGGL((single_staged_kernel<NW, NT>), dim3(grid_for(n)), dim3(STAGE_BLOCK), 0, stream, P, R, n, counts);
+        return hipGetLastError();
+    }
+};
+template<int NW, int NT> struct LaunchCombo {
+    static hipError_t go(const ScgComboParams& P, const ScgReads& R, int64_t n, int32_t* cells, hipStream_t stream) {
+        hipLaunchKernelGGL((combo_staged_kernel<NW, NT>), dim3(grid_for(n)), dim3(STAGE_BLOCK), 0, stream, P, R, n, cells);
+        return hipGetLastError();
+    }
+};
+template<int NW, int NT> struct LaunchDual {
+    static hipError_t go(const ScgDualParams& P, const ScgReads& R1, const ScgReads& R2, int64_t n, int32_t* counts, hipStream_t stream) {
+        hipLaunchKernelGGL((dual_staged_kernel<NW, NT>), dim3(grid_for(n)), dim3(STAGE_BLOCK), 0, stream, P, R1, R2, n, counts);
+        return hipGetLastError();
+    }
+};
+
+} // namespace
+
+hipError_t launch_single(const ScgSingleParams& P, int tmpl_len, const ScgReads& R, int64_t n, int32_t* counts, hipStream_t stream) {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(dual_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, stream, P, R1, R2, n, counts);
-    return hipGetLastError();
+    if (force_general()) {
+        hipLaunchKernelGGL(single_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, stream, P, R, n, counts);
+        return hipGetLastError();
+    }
+    return dispatch_shape<LaunchSingle>(R.max_len, tmpl_len, P, R, n, counts, stream);
 }
 
-hipError_t launch_match(const ScgTable& tab, const uint8_t* d_seqs, int32_t n, int cap, int reverse,
+hipError_t launch_combo(const ScgComboParams& P, int tmpl_len, const ScgReads& R, int64_t n, int32_t* cells, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    if (force_general()) {
+        hipLaunchKernelGGL(combo_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, stream, P, R, n, cells);
+        return hipGetLastError();
+    }
+    return dispatch_shape<LaunchCombo>(R.max_len, tmpl_len, P, R, n, cells, stream);
+}
+
+hipError_t launch_dual(const ScgDualParams& P, int tmpl_len, const ScgReads& R1, const ScgReads& R2, int64_t n, int32_t* counts, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    if (force_general()) {
+        hipLaunchKernelGGL(dual_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, stream, P, R1, R2, n, counts);
+        return hipGetLastError();
+    }
+    const int max_len = R1.max_len > R2.max_len ? R1.max_len : R2.max_len;
+    return dispatch_shape<LaunchDual>(max_len, tmpl_len, P, R1, R2, n, counts, stream);
+}
+
+hipError_t launch_match(const ScgIndex& tab, const uint8_t* d_seqs, int32_t n, int cap, int reverse,
                         int32_t* d_index, int32_t* d_mm, hipStream_t stream) {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(match_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, stream, tab, d_seqs, n, cap, reverse, d_index, d_mm);

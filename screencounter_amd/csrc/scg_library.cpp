@@ -61,7 +61,8 @@ void for_each_expansion(const char* s, int len, F f) {
     for (;;) {
         uint64_t key = 0;
         for (int p = 0; p < len; ++p) {
-            key |= static_cast<uint64_t>(codes[p][choice[p]]) << (2 * p);
+            uint64_t c = static_cast<uint64_t>(codes[p][choice[p]]);
+            key |= ((c & 1) << p) | ((c >> 1) << (32 + p));    // plane-split (scg_common.h)
         }
         f(key);
         int p = len - 1;
@@ -179,6 +180,15 @@ HostTemplate parse_template(const char* constant, int strand) {
         t.rpos[k] = static_cast<uint8_t>(L - 1 - t.fpos[src]);
         t.rcode[k] = static_cast<uint8_t>(t.fcode[src] ^ 2);
     }
+    for (int k = 0; k < nconst; ++k) {
+        int fp = t.fpos[k], rp = t.rpos[k];
+        t.fmask[fp >> 5] |= 1u << (fp & 31);
+        t.fplane0[fp >> 5] |= static_cast<uint32_t>(t.fcode[k] & 1) << (fp & 31);
+        t.fplane1[fp >> 5] |= static_cast<uint32_t>(t.fcode[k] >> 1) << (fp & 31);
+        t.rmask[rp >> 5] |= 1u << (rp & 31);
+        t.rplane0[rp >> 5] |= static_cast<uint32_t>(t.rcode[k] & 1) << (rp & 31);
+        t.rplane1[rp >> 5] |= static_cast<uint32_t>(t.rcode[k] >> 1) << (rp & 31);
+    }
     // Callers reject any template whose region count is not the one they expect, so only
     // region counts the engine can use are materialised.
     if (nreg <= SCG_MAX_REGIONS) {
@@ -207,67 +217,127 @@ int pool_length(const char* const* pool, int32_t n) {
     return static_cast<int>(size);
 }
 
-HostTable build_index_table(const char* const* pool, int32_t n, int32_t len) {
+namespace {
+
+// Lays the concrete entries (key, value) out as a segment index (scg_common.h: ScgIndex).
+void finish_index(HostIndex& X, const std::vector<uint64_t>& keys, const std::vector<int32_t>& vals, int32_t len, int max_mm) {
+    X.len = len;
+    X.n_entries = static_cast<int32_t>(keys.size());
+    X.entries.resize(keys.size() * 4);
+    for (size_t e = 0; e < keys.size(); ++e) {
+        X.entries[4 * e] = static_cast<uint32_t>(keys[e]);
+        X.entries[4 * e + 1] = static_cast<uint32_t>(keys[e] >> 32);
+        X.entries[4 * e + 2] = static_cast<uint32_t>(vals[e]);
+        X.entries[4 * e + 3] = 0;
+    }
+    int nseg = max_mm + 1;
+    if (nseg > SCG_MAX_SEGMENTS) {
+        X.nseg = 0;            // budget too wide for pigeonhole tables: dense scans
+        return;
+    }
+    X.nseg = nseg;
+    uint32_t cap = 16;
+    while (cap < keys.size() * 2) cap <<= 1;
+    X.slot_mask = cap - 1;
+    X.slots.assign(static_cast<size_t>(nseg) * cap * 2, 0);
+    X.next.assign(static_cast<size_t>(nseg) * keys.size(), -1);
+    for (int sgm = 0; sgm < nseg; ++sgm) {
+        int a = static_cast<int>(static_cast<int64_t>(sgm) * len / nseg);
+        int b = static_cast<int>(static_cast<int64_t>(sgm + 1) * len / nseg);
+        uint64_t m32 = (b - a >= 32) ? 0xFFFFFFFFull : (((1ull << (b - a)) - 1ull) << a);
+        uint64_t mask = m32 | (m32 << 32);
+        X.segmask[sgm] = mask;
+        uint32_t* slots = X.slots.data() + static_cast<size_t>(sgm) * cap * 2;
+        int32_t* next = X.next.data() + static_cast<size_t>(sgm) * keys.size();
+        // Insert back to front so that every chain lists its entries in ascending order.
+        for (size_t i = keys.size(); i-- > 0;) {
+            uint64_t sk = keys[i] & mask;
+            uint32_t h = scg_hash64(sk);
+            uint32_t pos = h & X.slot_mask;
+            for (;;) {
+                uint32_t head = slots[2 * pos + 1];
+                if (head == 0) {
+                    slots[2 * pos] = h;
+                    slots[2 * pos + 1] = static_cast<uint32_t>(i) + 1;
+                    break;
+                }
+                if (slots[2 * pos] == h && (keys[head - 1] & mask) == sk) {
+                    next[i] = static_cast<int32_t>(head - 1);
+                    slots[2 * pos + 1] = static_cast<uint32_t>(i) + 1;
+                    break;
+                }
+                pos = (pos + 1) & X.slot_mask;
+            }
+        }
+    }
+}
+
+} // namespace
+
+HostIndex build_index(const char* const* pool, int32_t n, int32_t len, int max_mm) {
     check_len(len);
-    HostTable T;
-    T.len = len;
     int64_t total = count_expansions(pool, n, len);
-    Builder B(T.keys, T.vals, capacity_for(total));
-    T.mask = B.mask;
-    T.list_keys.reserve(total);
-    T.list_vals.reserve(total);
+    std::vector<uint64_t> hk;
+    std::vector<int32_t> hv;
+    Builder B(hk, hv, capacity_for(total));     // host-only exact map, for duplicate detection
+    int32_t sentinel = -1;                      // owner of the one key equal to SCG_EMPTY_KEY (32 x G)
+    std::vector<uint64_t> keys;
+    std::vector<int32_t> vals;
+    keys.reserve(total);
+    vals.reserve(total);
     for (int32_t i = 0; i < n; ++i) {
         for_each_expansion(pool[i], len, [&](uint64_t key) {
             if (key == SCG_EMPTY_KEY) {
-                if (T.sentinel_val >= 0) throw_duplicate(T.sentinel_val, i);
-                T.sentinel_val = i;
+                if (sentinel >= 0) throw_duplicate(sentinel, i);
+                sentinel = i;
             } else {
                 bool existed;
                 uint32_t slot = B.upsert(key, i, &existed);
-                if (existed) throw_duplicate(T.vals[slot], i);
+                if (existed) throw_duplicate(hv[slot], i);
             }
-            T.list_keys.push_back(key);
-            T.list_vals.push_back(i);
+            keys.push_back(key);
+            vals.push_back(i);
         });
     }
-    T.n_entries = static_cast<int32_t>(T.list_keys.size());
-    return T;
+    HostIndex X;
+    finish_index(X, keys, vals, len, max_mm);
+    return X;
 }
 
-HostTable build_uid_table(const char* const* pool, int32_t n, int32_t len,
+HostIndex build_uid_index(const char* const* pool, int32_t n, int32_t len, int max_mm,
                           std::vector<std::vector<int32_t> >& expansions,
                           std::vector<uint64_t>& uid_keys) {
     check_len(len);
-    HostTable T;
-    T.len = len;
     int64_t total = count_expansions(pool, n, len);
-    Builder B(T.keys, T.vals, capacity_for(total));
-    T.mask = B.mask;
+    std::vector<uint64_t> hk;
+    std::vector<int32_t> hv;
+    Builder B(hk, hv, capacity_for(total));
+    int32_t sentinel = -1;
     expansions.assign(n, std::vector<int32_t>());
     uid_keys.clear();
     for (int32_t i = 0; i < n; ++i) {
         for_each_expansion(pool[i], len, [&](uint64_t key) {
             int32_t uid;
             if (key == SCG_EMPTY_KEY) {
-                if (T.sentinel_val < 0) {
-                    T.sentinel_val = static_cast<int32_t>(uid_keys.size());
+                if (sentinel < 0) {
+                    sentinel = static_cast<int32_t>(uid_keys.size());
                     uid_keys.push_back(key);
                 }
-                uid = T.sentinel_val;
+                uid = sentinel;
             } else {
                 bool existed;
                 uint32_t slot = B.upsert(key, static_cast<int32_t>(uid_keys.size()), &existed);
                 if (!existed) uid_keys.push_back(key);
-                uid = T.vals[slot];
+                uid = hv[slot];
             }
             expansions[i].push_back(uid);
         });
     }
-    T.list_keys = uid_keys;
-    T.list_vals.resize(uid_keys.size());
-    for (size_t u = 0; u < uid_keys.size(); ++u) T.list_vals[u] = static_cast<int32_t>(u);
-    T.n_entries = static_cast<int32_t>(uid_keys.size());
-    return T;
+    std::vector<int32_t> vals(uid_keys.size());
+    for (size_t u = 0; u < uid_keys.size(); ++u) vals[u] = static_cast<int32_t>(u);
+    HostIndex X;
+    finish_index(X, uid_keys, vals, len, max_mm);
+    return X;
 }
 
 HostPairTable build_pair_table(const std::vector<std::vector<int32_t> >& exp1, const std::vector<uint64_t>& uid_keys1,
@@ -300,21 +370,31 @@ HostPairTable build_pair_table(const std::vector<std::vector<int32_t> >& exp1, c
     return P;
 }
 
-bool pack_query(const char* s, int len, bool reverse_complement, uint64_t& key, uint64_t& nmask, int& n_other) {
-    if (len > SCG_MAX_BARCODE) return false;
-    key = 0; nmask = 0; n_other = 0;
-    for (int j = 0; j < len; ++j) {
-        int c = base_code(s[j]);
-        int pos = reverse_complement ? (len - 1 - j) : j;
-        if (c < 0) {
-            nmask |= 3ull << (2 * pos);
-            ++n_other;
-        } else {
-            if (reverse_complement) c ^= 2;
-            key |= static_cast<uint64_t>(c) << (2 * pos);
+void build_seeds(ScgTemplate& t, int max_mm) {
+    // k + 1 disjoint groups of constant positions for a budget of k mismatches; with fewer than
+    // k + 1 constant bases (or k + 1 > SCG_MAX_SEEDS) no filter is possible and every position is
+    // a candidate.
+    auto fill = [&](ScgSeeds& S, const uint8_t* pos, const uint8_t* code) {
+        std::memset(&S, 0, sizeof(S));
+        int want = max_mm + 1;
+        if (want > SCG_MAX_SEEDS || t.nconst < want) {
+            S.nseeds = 0;
+            return;
         }
-    }
-    return true;
+        S.nseeds = want;
+        for (int i = 0; i < want; ++i) {
+            int a = static_cast<int>(static_cast<int64_t>(i) * t.nconst / want);
+            int b = static_cast<int>(static_cast<int64_t>(i + 1) * t.nconst / want);
+            int m = std::min(b - a, SCG_SEED_LEN);
+            S.len[i] = m;
+            for (int j = 0; j < m; ++j) {
+                S.pos[i][j] = pos[a + j];
+                S.code[i][j] = code[a + j];
+            }
+        }
+    };
+    fill(t.fseeds, t.fpos, t.fcode);
+    fill(t.rseeds, t.rpos, t.rcode);
 }
 
 } // namespace scg

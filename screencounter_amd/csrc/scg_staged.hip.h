@@ -1,0 +1,310 @@
+// scg_staged.hip.h -- the LDS-staged bit-plane scanner (the fast path of every counting kernel).
+//
+// Work decomposition for one workgroup of 256 lanes = 256 consecutive reads:
+//
+//  Phase A  (cooperative, coalesced)   the workgroup's contiguous byte span of ASCII reads is
+//           loaded once, 16 B per lane per load, and transposed on the fly into three bit planes
+//           in LDS: code bit 0, code bit 1 and validity (1 = ACGTacgt), one bit per base.
+//           This is the only pass over the read bytes: HBM traffic = the algorithmic bytes.
+//  Phase B  (one read per lane)        each lane pulls its read's plane bits out of LDS with
+//           funnel shifts and runs a bit-parallel (Shift-And) exact search for k+1 pigeonhole
+//           seeds of the template's constant bases on each strand; the union of the hits is a
+//           superset of the positions where the reference's ScanTemplate reports <= k constant
+//           mismatches (kaori/ScanTemplate.hpp:183-252).
+//  Phase C  (one read per lane)        candidates are visited in the reference's order
+//           (position-major, forward before reverse: kaori/SimpleSingleMatch.hpp:226-242); each is
+//           verified exactly against the template planes (XOR/AND/popcount over the window taken
+//           from LDS), its variable region is cut out of the planes and matched through the
+//           segment index (scg_engine.hip.h).
+//
+// Reads longer than 32*NW bases, templates longer than 32*NT and workgroups whose byte span
+// exceeds the LDS tile are handled by the byte-wise general engine inside the same kernel, so
+// the result never depends on which path ran.
+#ifndef SCG_STAGED_HIP_H
+#define SCG_STAGED_HIP_H
+
+#include <hip/hip_runtime.h>
+#include "scg_engine.hip.h"
+
+namespace scgdev {
+
+constexpr int STAGE_BLOCK = 256;      // lanes = reads per workgroup
+
+template<int NW>
+struct Tile {
+    static constexpr int CAP_BYTES = STAGE_BLOCK * 32 * NW;          // bytes (= bases) per tile
+    static constexpr int WORDS = CAP_BYTES / 32 + NW + 4;            // plane words incl. read-ahead slack
+    uint32_t p0[WORDS];
+    uint32_t p1[WORDS];
+    uint32_t v[WORDS];
+};
+
+// 16 ASCII bytes -> 16 bits of each plane.
+__device__ __forceinline__ void transpose_chunk(const uint4& x, uint32_t& p0, uint32_t& p1, uint32_t& v) {
+    const uint32_t d[4] = {x.x, x.y, x.z, x.w};
+    uint32_t a0[2] = {0, 0}, a1[2] = {0, 0}, ai[2] = {0, 0};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t w = (i & 1) ? 0x80402010u : 0x08040201u;     // bit weights of the 4 bytes
+        uint32_t k = (d[i] >> 1) & 0x03030303u;                     // codes
+        uint32_t expect = __builtin_amdgcn_perm(0u, 0x47544341u, k);   // "ACTG"[code] per byte
+        uint32_t z = expect ^ (d[i] & 0xDFDFDFDFu);                 // zero byte <=> standard base
+        uint32_t nz = (((z & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | z) & 0x80808080u;
+        a0[i >> 1] = __builtin_amdgcn_udot4(k & 0x01010101u, w, a0[i >> 1], false);
+        a1[i >> 1] = __builtin_amdgcn_udot4(k & 0x02020202u, w, a1[i >> 1], false);
+        ai[i >> 1] = __builtin_amdgcn_udot4(nz, w, ai[i >> 1], false);
+    }
+    p0 = a0[0] | (a0[1] << 8);
+    p1 = (a1[0] >> 1) | (a1[1] << 7);
+    v = ~((ai[0] >> 7) | (ai[1] << 1)) & 0xFFFFu;
+}
+
+// Phase A.  Returns false when the workgroup's span does not fit the tile (caller falls back to
+// the byte-wise engine for the whole workgroup).  On success `span0` is the byte offset (from
+// R.seqs) that bit 0 of the planes corresponds to; it may be negative by up to 15.
+template<int NW>
+__device__ __forceinline__ bool stage_reads(const ScgReads& R, int64_t n_reads, int64_t r0, int nr,
+                                            Tile<NW>& tile, int64_t& span0) {
+    uint64_t b0, b1, total;
+    if (R.offsets) {
+        b0 = R.offsets[r0];
+        b1 = R.offsets[r0 + nr];
+        total = R.offsets[n_reads];
+    } else {
+        b0 = (uint64_t)r0 * (uint64_t)R.fixed_len;
+        b1 = (uint64_t)(r0 + nr) * (uint64_t)R.fixed_len;
+        total = (uint64_t)n_reads * (uint64_t)R.fixed_len;
+    }
+    const int delta = (int)((uintptr_t)(R.seqs + b0) & 15u);
+    const uint64_t span = (b1 - b0) + (uint64_t)delta;
+    if (span > (uint64_t)Tile<NW>::CAP_BYTES) return false;
+    span0 = (int64_t)b0 - delta;
+    const int nchunks = (int)((span + 15) >> 4);
+    uint16_t* h0 = reinterpret_cast<uint16_t*>(tile.p0);
+    uint16_t* h1 = reinterpret_cast<uint16_t*>(tile.p1);
+    uint16_t* hv = reinterpret_cast<uint16_t*>(tile.v);
+    for (int c = threadIdx.x; c < nchunks; c += STAGE_BLOCK) {
+        int64_t cb = span0 + 16 * (int64_t)c;
+        uint4 x;
+        if (cb >= 0 && (uint64_t)(cb + 16) <= total) {
+            x = *reinterpret_cast<const uint4*>(R.seqs + cb);
+        } else {
+            // first / last chunk of the buffer: never touch bytes outside [0, total)
+            uint32_t t[4] = {0, 0, 0, 0};
+            for (int j = 0; j < 16; ++j) {
+                int64_t o = cb + j;
+                uint32_t byte = (o >= 0 && (uint64_t)o < total) ? R.seqs[o] : 0u;
+                t[j >> 2] |= byte << (8 * (j & 3));
+            }
+            x = make_uint4(t[0], t[1], t[2], t[3]);
+        }
+        uint32_t p0, p1, v;
+        transpose_chunk(x, p0, p1, v);
+        h0[c] = (uint16_t)p0;
+        h1[c] = (uint16_t)p1;
+        hv[c] = (uint16_t)v;
+    }
+    return true;
+}
+
+// NW words of a bit vector starting at bit `bit` of an LDS plane.
+template<int NW>
+__device__ __forceinline__ void load_bits(const uint32_t* __restrict__ plane, int bit, uint32_t out[NW]) {
+    const int w0 = bit >> 5, sh = bit & 31;
+    uint32_t lo = plane[w0];
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        uint32_t hi = plane[w0 + i + 1];
+        out[i] = __builtin_amdgcn_alignbit(hi, lo, sh);
+        lo = hi;
+    }
+}
+
+// Mask with the low `count` bits set across NW words (count may be <= 0 or >= 32*NW).
+template<int NW>
+__device__ __forceinline__ void low_bits(int count, uint32_t out[NW]) {
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        int c = count - 32 * i;
+        out[i] = c >= 32 ? 0xFFFFFFFFu : (c > 0 ? ((1u << c) - 1u) : 0u);
+    }
+}
+
+// x >>= g over NW little-endian words, g wave-uniform and < 32.
+template<int NW>
+__device__ __forceinline__ void shift_right_small(uint32_t x[NW], int g) {
+#pragma unroll
+    for (int i = 0; i < NW - 1; ++i) x[i] = __builtin_amdgcn_alignbit(x[i + 1], x[i], g);
+    x[NW - 1] >>= g;
+}
+
+template<int NW>
+__device__ __forceinline__ void shift_right(uint32_t x[NW], int g) {
+    while (g > 0) {
+        int step = g < 31 ? g : 31;
+        shift_right_small<NW>(x, step);
+        g -= step;
+    }
+}
+
+// The four base-match planes of one read.
+template<int NW>
+struct BasePlanes {
+    uint32_t e[4][NW];     // e[code][word]: bit j set iff base j is a standard base with that code
+};
+
+template<int NW>
+__device__ __forceinline__ void and_code(uint32_t a[NW], const BasePlanes<NW>& E, int code) {
+    // `code` is wave-uniform: a scalar branch, static register indices
+    switch (code) {
+        case 0:
+#pragma unroll
+            for (int i = 0; i < NW; ++i) a[i] &= E.e[0][i];
+            break;
+        case 1:
+#pragma unroll
+            for (int i = 0; i < NW; ++i) a[i] &= E.e[1][i];
+            break;
+        case 2:
+#pragma unroll
+            for (int i = 0; i < NW; ++i) a[i] &= E.e[2][i];
+            break;
+        default:
+#pragma unroll
+            for (int i = 0; i < NW; ++i) a[i] &= E.e[3][i];
+            break;
+    }
+}
+
+// Phase B for one strand: positions p (bit p of cand) where at least one seed matches exactly
+// and p + T <= n.
+template<int NW>
+__device__ __forceinline__ void seed_candidates(const BasePlanes<NW>& E, const ScgSeeds& S, int tlen, int n,
+                                                uint32_t cand[NW]) {
+    uint32_t ok[NW];
+    low_bits<NW>(n - tlen + 1, ok);
+    if (S.nseeds == 0) {
+#pragma unroll
+        for (int i = 0; i < NW; ++i) cand[i] = ok[i];
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < NW; ++i) cand[i] = 0;
+    for (int s = 0; s < S.nseeds; ++s) {
+        uint32_t a[NW];
+#pragma unroll
+        for (int i = 0; i < NW; ++i) a[i] = 0xFFFFFFFFu;
+        int m = S.len[s];
+        if (m > 0) {
+            and_code<NW>(a, E, S.code[s][m - 1]);
+            for (int j = m - 2; j >= 0; --j) {
+                shift_right<NW>(a, (int)S.pos[s][j + 1] - (int)S.pos[s][j]);
+                and_code<NW>(a, E, S.code[s][j]);
+            }
+            shift_right<NW>(a, (int)S.pos[s][0]);
+        }
+#pragma unroll
+        for (int i = 0; i < NW; ++i) cand[i] |= a[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NW; ++i) cand[i] &= ok[i];
+}
+
+// Lowest set bit of an NW-word mask, or 1 << 30 when empty.
+template<int NW>
+__device__ __forceinline__ int first_bit(const uint32_t m[NW]) {
+    int pos = 1 << 30;
+#pragma unroll
+    for (int i = NW - 1; i >= 0; --i) {
+        if (m[i]) pos = 32 * i + (__ffs((int)m[i]) - 1);
+    }
+    return pos;
+}
+
+template<int NW>
+__device__ __forceinline__ void clear_bit(uint32_t m[NW], int pos) {
+    const int w = pos >> 5;
+    const uint32_t b = 1u << (pos & 31);
+#pragma unroll
+    for (int i = 0; i < NW; ++i) m[i] &= ~(w == i ? b : 0u);
+}
+
+// Exact number of constant-region mismatches of the template placed at plane bit `bit`
+// (kaori/ScanTemplate.hpp:233-252: a non-standard base mismatches a constant position).
+template<int NW, int NT>
+__device__ __forceinline__ int window_mismatches(const Tile<NW>& tile, int bit, const ScgTemplate* __restrict__ T, bool reverse) {
+    uint32_t w0[NT], w1[NT], wv[NT];
+    load_bits<NT>(tile.p0, bit, w0);
+    load_bits<NT>(tile.p1, bit, w1);
+    load_bits<NT>(tile.v, bit, wv);
+    int mm = 0;
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        uint32_t t0 = reverse ? T->rplane0[i] : T->fplane0[i];
+        uint32_t t1 = reverse ? T->rplane1[i] : T->fplane1[i];
+        uint32_t cm = reverse ? T->rmask[i] : T->fmask[i];
+        uint32_t same = wv[i] & ~((w0[i] ^ t0) | (w1[i] ^ t1));
+        mm += __popc(cm & ~same);
+    }
+    return mm;
+}
+
+// Variable region of `len` <= 32 bases starting at plane bit `bit`.
+template<int NW>
+__device__ __forceinline__ Query region_query(const Tile<NW>& tile, int bit, int len, bool reverse) {
+    uint32_t a[1], b[1], c[1];
+    load_bits<1>(tile.p0, bit, a);
+    load_bits<1>(tile.p1, bit, b);
+    load_bits<1>(tile.v, bit, c);
+    const uint32_t m = low_mask(len);
+    Query q;
+    q.other = ~c[0] & m;
+    q.lo = a[0] & m & ~q.other;
+    q.hi = b[0] & m & ~q.other;
+    q.n_other = __popc(q.other);
+    return reverse ? reverse_complement(q, len) : q;
+}
+
+// Per-lane view of one staged read.
+struct StagedRead {
+    int bit;      // plane bit of base 0
+    int n;        // length
+};
+
+// Phase B for both strands of one template.
+template<int NW>
+__device__ __forceinline__ void scan_read(const Tile<NW>& tile, const StagedRead& sr, const ScgTemplate* __restrict__ T,
+                                          bool fwd, bool rev, uint32_t candF[NW], uint32_t candR[NW]) {
+    BasePlanes<NW> E;
+    {
+        uint32_t p0[NW], p1[NW], v[NW], lim[NW];
+        load_bits<NW>(tile.p0, sr.bit, p0);
+        load_bits<NW>(tile.p1, sr.bit, p1);
+        load_bits<NW>(tile.v, sr.bit, v);
+        low_bits<NW>(sr.n, lim);
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            uint32_t vv = v[i] & lim[i];
+            E.e[0][i] = vv & ~p0[i] & ~p1[i];
+            E.e[1][i] = vv & p0[i] & ~p1[i];
+            E.e[2][i] = vv & ~p0[i] & p1[i];
+            E.e[3][i] = vv & p0[i] & p1[i];
+        }
+    }
+    if (fwd) {
+        seed_candidates<NW>(E, T->fseeds, T->len, sr.n, candF);
+    } else {
+#pragma unroll
+        for (int i = 0; i < NW; ++i) candF[i] = 0;
+    }
+    if (rev) {
+        seed_candidates<NW>(E, T->rseeds, T->len, sr.n, candR);
+    } else {
+#pragma unroll
+        for (int i = 0; i < NW; ++i) candR[i] = 0;
+    }
+}
+
+} // namespace scgdev
+
+#endif

@@ -137,8 +137,9 @@ class Plan:
         check(self._lib.scg_plan_reset(self._h, C.c_void_p(_stream_handle(stream)), err, _lib.ERRCAP), err)
 
     # ---- the hot path ---------------------------------------------------------------------------
-    def count(self, seqs, offsets=None, fixed_len: int = 0, n_reads: Optional[int] = None, stream=None) -> None:
-        """One step: count a batch of single-end reads resident in HBM (asynchronous)."""
+    def count(self, seqs, offsets=None, fixed_len: int = 0, n_reads: Optional[int] = None, stream=None, max_len: int = 0) -> None:
+        """One step: count a batch of single-end reads resident in HBM (asynchronous).
+        max_len (ragged batches): upper bound on the read lengths if known; a tile-shape hint only."""
         _check_u8(seqs, "seqs")
         _check_offsets(offsets, "offsets")
         if offsets is not None:
@@ -151,10 +152,10 @@ class Plan:
                 raise ValueError("seqs is shorter than n_reads * fixed_len")
         err = errbuf()
         check(self._lib.scg_count_batch(self._h, C.c_void_p(_dev_ptr(seqs)), C.c_void_p(_dev_ptr(offsets)), int(fixed_len),
-                                        int(n), C.c_void_p(_stream_handle(stream)), err, _lib.ERRCAP), err)
+                                        int(max_len), int(n), C.c_void_p(_stream_handle(stream)), err, _lib.ERRCAP), err)
 
     def count_paired(self, seqs1, seqs2, offsets1=None, offsets2=None, fixed_len1: int = 0, fixed_len2: int = 0,
-                     n_pairs: Optional[int] = None, stream=None) -> None:
+                     n_pairs: Optional[int] = None, stream=None, max_len: int = 0) -> None:
         _check_u8(seqs1, "seqs1")
         _check_u8(seqs2, "seqs2")
         _check_offsets(offsets1, "offsets1")
@@ -177,7 +178,7 @@ class Plan:
         err = errbuf()
         check(self._lib.scg_count_batch_paired(self._h, C.c_void_p(_dev_ptr(seqs1)), C.c_void_p(_dev_ptr(offsets1)), int(fixed_len1),
                                                C.c_void_p(_dev_ptr(seqs2)), C.c_void_p(_dev_ptr(offsets2)), int(fixed_len2),
-                                               int(n_pairs), C.c_void_p(_stream_handle(stream)), err, _lib.ERRCAP), err)
+                                               int(max_len), int(n_pairs), C.c_void_p(_stream_handle(stream)), err, _lib.ERRCAP), err)
 
     def read(self, stream=None):
         """Synchronise and fetch (counts int32[num_counters], total reads seen)."""

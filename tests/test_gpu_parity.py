@@ -12,6 +12,16 @@ from tests import gen
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["staged", "general"], autouse=True)
+def engine(request, monkeypatch):
+    """Every parity test runs on the LDS-staged kernels and on the byte-wise general engine."""
+    if request.param == "general":
+        monkeypatch.setenv("SCG_FORCE_GENERAL", "1")
+    else:
+        monkeypatch.delenv("SCG_FORCE_GENERAL", raising=False)
+    return request.param
+
+
 def _unsupported(case):
     lens = [len(p[0]) for k, p in case.items() if k.startswith("pool") and p]
     return any(n > 32 for n in lens)
