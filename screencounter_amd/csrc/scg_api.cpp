@@ -157,6 +157,7 @@ struct scg_plan {
 
     // host-compiled pieces (valid before any device work)
     scg::HostTemplate ht1, ht2;
+    ScgScan scan1, scan2;
     scg::HostIndex htab[2];
     scg::HostPairTable hpairs;
     int32_t n_pool[2] = {0, 0};
@@ -253,7 +254,7 @@ std::unique_ptr<scg_plan> compile_single(const char* constant, int strand, const
     }
     if (mismatches < 0) throw Error(SCG_ERR_INVALID, "negative number of mismatches");
     P->htab[0] = scg::build_index(pool, n_pool, plen, mismatches);   // BarcodeSearch.hpp:23-60
-    scg::build_seeds(P->ht1.t, mismatches);
+    P->scan1 = scg::build_scan(P->ht1.t, mismatches);
     P->n_pool[0] = n_pool;
     P->n_counters = n_pool;
     P->max_mm1 = mismatches;
@@ -283,7 +284,7 @@ std::unique_ptr<scg_plan> compile_combo(const char* constant, int strand,
     if (mismatches < 0) throw Error(SCG_ERR_INVALID, "negative number of mismatches");
     P->htab[0] = scg::build_index(pool0, n0, len0, mismatches);
     P->htab[1] = scg::build_index(pool1, n1, len1, mismatches);
-    scg::build_seeds(P->ht1.t, mismatches);
+    P->scan1 = scg::build_scan(P->ht1.t, mismatches);
     P->n_pool[0] = n0; P->n_pool[1] = n1;
     int64_t cells = static_cast<int64_t>(n0) * static_cast<int64_t>(n1);
     if (cells > (int64_t(1) << 30)) {
@@ -320,8 +321,8 @@ std::unique_ptr<scg_plan> compile_dual(const char* constant1, int reverse1, int 
     std::vector<uint64_t> uk1, uk2;
     P->htab[0] = scg::build_uid_index(pool1, n_pool, len1, mismatches1, exp1, uk1);
     P->htab[1] = scg::build_uid_index(pool2, n_pool, len2, mismatches2, exp2, uk2);
-    scg::build_seeds(P->ht1.t, mismatches1);
-    scg::build_seeds(P->ht2.t, mismatches2);
+    P->scan1 = scg::build_scan(P->ht1.t, mismatches1);
+    P->scan2 = scg::build_scan(P->ht2.t, mismatches2);
     P->hpairs = scg::build_pair_table(exp1, uk1, exp2, uk2);   // :138-178 (duplicate pairs => error)
     P->n_pool[0] = P->n_pool[1] = n_pool;
     P->n_counters = n_pool;
@@ -336,6 +337,7 @@ void launch_batch(scg_plan* P, const ScgReads& R, int64_t n, hipStream_t stream)
     scg_plan::Timer timer(P, stream);
     if (P->kind == scg_plan::SINGLE) {
         ScgSingleParams sp;
+        sp.scan = P->scan1;
         sp.tmpl = P->d_tmpl1.as<ScgTemplate>();
         sp.index = P->tab[0].view;
         sp.max_mm = P->max_mm1; sp.use_first = P->use_first;
@@ -343,6 +345,7 @@ void launch_batch(scg_plan* P, const ScgReads& R, int64_t n, hipStream_t stream)
         HIP_CHECK(scg::launch_single(sp, P->ht1.t.len, R, n, P->counters, stream));
     } else {
         ScgComboParams cp;
+        cp.scan = P->scan1;
         cp.tmpl = P->d_tmpl1.as<ScgTemplate>();
         cp.index[0] = P->tab[0].view; cp.index[1] = P->tab[1].view;
         cp.n_pool[0] = P->n_pool[0]; cp.n_pool[1] = P->n_pool[1];
@@ -357,6 +360,7 @@ void launch_batch(scg_plan* P, const ScgReads& R, int64_t n, hipStream_t stream)
 void launch_batch_paired(scg_plan* P, const ScgReads& R1, const ScgReads& R2, int64_t n, hipStream_t stream) {
     scg_plan::Timer timer(P, stream);
     ScgDualParams dp;
+    dp.scan1 = P->scan1; dp.scan2 = P->scan2;
     dp.tmpl1 = P->d_tmpl1.as<ScgTemplate>(); dp.tmpl2 = P->d_tmpl2.as<ScgTemplate>();
     dp.index1 = P->tab[0].view; dp.index2 = P->tab[1].view; dp.pairs = P->pairs.view;
     dp.rev1 = P->rev1; dp.rev2 = P->rev2; dp.max_mm1 = P->max_mm1; dp.max_mm2 = P->max_mm2;

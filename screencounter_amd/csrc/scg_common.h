@@ -30,11 +30,26 @@
 // at least one of k+1 disjoint groups of constant positions matches exactly (pigeonhole), so the
 // union of the seeds' exact-match positions is a superset of the positions the reference's
 // ScanTemplate reports (kaori/ScanTemplate.hpp:233-252); every candidate is then verified exactly.
+// Packed into dwords so that the whole description travels in the kernel-argument segment and
+// lives in SGPRs (gfx950 has no scalar byte loads).
 struct ScgSeeds {
-    int32_t nseeds;                                  // 0 => every position is a candidate
-    int32_t len[SCG_MAX_SEEDS];                      // bases in seed i (0 => matches everywhere)
-    uint8_t pos[SCG_MAX_SEEDS][SCG_SEED_LEN];        // template offsets, ascending
-    uint8_t code[SCG_MAX_SEEDS][SCG_SEED_LEN];       // expected base codes
+    int32_t nseeds;                          // 0 => every position is a candidate
+    int32_t len[SCG_MAX_SEEDS];              // bases in seed i (0 => matches everywhere)
+    int32_t first[SCG_MAX_SEEDS];            // template offset of the seed's first base
+    uint32_t codes[SCG_MAX_SEEDS];           // base j of the seed at bits 2j, 2j+1
+    uint32_t gaps[SCG_MAX_SEEDS][SCG_SEED_LEN / 4];   // byte j: offset(base j+1) - offset(base j)
+};
+
+// Everything the staged scan of one template needs, by value in the kernel arguments.
+struct ScgScan {
+    int32_t len;                              // template length T
+    int32_t nreg;
+    int32_t fstart[SCG_MAX_REGIONS];          // variable-region starts, forward template
+    int32_t rstart[SCG_MAX_REGIONS];          // ... on the reverse-complemented template
+    ScgSeeds fseeds, rseeds;
+    // bit planes of the constant bases (word w covers template positions 32w .. 32w+31)
+    uint32_t fplane0[SCG_MAX_TEMPLATE / 32], fplane1[SCG_MAX_TEMPLATE / 32], fmask[SCG_MAX_TEMPLATE / 32];
+    uint32_t rplane0[SCG_MAX_TEMPLATE / 32], rplane1[SCG_MAX_TEMPLATE / 32], rmask[SCG_MAX_TEMPLATE / 32];
 };
 
 // One template = constant bases + variable regions (kaori/ScanTemplate.hpp:53-95).
@@ -51,11 +66,6 @@ struct ScgTemplate {
     uint8_t fcode[SCG_MAX_TEMPLATE];   // base code expected at fpos[k]
     uint8_t rpos[SCG_MAX_TEMPLATE];    // constant positions, reverse-complemented template
     uint8_t rcode[SCG_MAX_TEMPLATE];
-    // bit-plane form of the same information, for the LDS-staged kernels (word w covers template
-    // positions 32w .. 32w+31): code bit planes and the constant-position mask, per strand
-    uint32_t fplane0[SCG_MAX_TEMPLATE / 32], fplane1[SCG_MAX_TEMPLATE / 32], fmask[SCG_MAX_TEMPLATE / 32];
-    uint32_t rplane0[SCG_MAX_TEMPLATE / 32], rplane1[SCG_MAX_TEMPLATE / 32], rmask[SCG_MAX_TEMPLATE / 32];
-    ScgSeeds fseeds, rseeds;           // built for the plan's mismatch budget
 };
 
 // Library index: every concrete barcode (IUPAC codes expanded) once, reachable through
@@ -96,7 +106,8 @@ struct ScgReads {
 };
 
 struct ScgSingleParams {
-    const ScgTemplate* tmpl;
+    ScgScan scan;
+    const ScgTemplate* tmpl;   // byte-wise form, for the general engine
     ScgIndex index;
     int32_t max_mm;
     int32_t use_first;
@@ -104,6 +115,7 @@ struct ScgSingleParams {
 };
 
 struct ScgComboParams {
+    ScgScan scan;
     const ScgTemplate* tmpl;
     ScgIndex index[SCG_MAX_REGIONS];
     int32_t n_pool[SCG_MAX_REGIONS];
@@ -113,6 +125,7 @@ struct ScgComboParams {
 };
 
 struct ScgDualParams {
+    ScgScan scan1, scan2;
     const ScgTemplate* tmpl1;
     const ScgTemplate* tmpl2;
     ScgIndex index1, index2;

@@ -68,8 +68,9 @@ struct HostPairTable {
 HostPairTable build_pair_table(const std::vector<std::vector<int32_t> >& exp1, const std::vector<uint64_t>& uid_keys1,
                                const std::vector<std::vector<int32_t> >& exp2, const std::vector<uint64_t>& uid_keys2);
 
-// Chooses the pigeonhole seeds of both strands for a mismatch budget (fills t.fseeds / t.rseeds).
-void build_seeds(ScgTemplate& t, int max_mm);
+// The staged-scan description of a template for a mismatch budget: bit planes of the constant
+// bases and the pigeonhole seeds of both strands.
+ScgScan build_scan(const ScgTemplate& t, int max_mm);
 
 
 // ---------------------------------------------------------------------------------------------

@@ -210,7 +210,7 @@ __global__ __launch_bounds__(BLOCK) void dual_kernel(ScgDualParams P, ScgReads R
 // =============================================================================================
 template<int NW, int NT>
 __device__ __forceinline__ int single_read_staged(const ScgSingleParams& P, const Tile<NW>& tile, const StagedRead& sr) {
-    const ScgTemplate* T = P.tmpl;
+    const ScgScan& T = P.scan;
     const int max_mm = P.max_mm;
     uint32_t candF[NW], candR[NW];
     scan_read<NW>(tile, sr, T, P.fwd != 0, P.rev != 0, candF, candR);
@@ -224,7 +224,7 @@ __device__ __forceinline__ int single_read_staged(const ScgSingleParams& P, cons
         clear_bit<NW>(candR, rev ? p : -1);
         int c = window_mismatches<NW, NT>(tile, sr.bit + p, T, rev);
         if (c > max_mm) continue;
-        int start = rev ? T->rstart[0] : T->fstart[0];
+        int start = rev ? T.rstart[0] : T.fstart[0];
         Query q = region_query<NW>(tile, sr.bit + p + start, P.index.len, rev);
         int idx, d;
         index_match(P.index, q, max_mm - c, idx, d);
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(STAGE_BLOCK) void single_staged_kernel(ScgSinglePar
     const int64_t r0 = (int64_t)blockIdx.x * STAGE_BLOCK;
     const int nr = (int)((n_reads - r0) < STAGE_BLOCK ? (n_reads - r0) : STAGE_BLOCK);
     int64_t span0 = 0;
-    const bool staged = (P.tmpl->len <= 32 * NT) && stage_reads<NW>(R, n_reads, r0, nr, tile, span0);
+    const bool staged = (P.scan.len <= 32 * NT) && stage_reads<NW>(R, n_reads, r0, nr, tile, span0);
     __syncthreads();
     if ((int)threadIdx.x >= nr) return;
     Read rd = get_read(R, r0 + threadIdx.x);
@@ -267,12 +267,12 @@ __global__ __launch_bounds__(STAGE_BLOCK) void single_staged_kernel(ScgSinglePar
 template<int NW, int NT>
 __device__ __forceinline__ bool combo_candidate_staged(const ScgComboParams& P, const Tile<NW>& tile, const StagedRead& sr,
                                                        int p, bool reverse, int c, int out[SCG_MAX_REGIONS], int& total) {
-    const ScgTemplate* T = P.tmpl;
+    const ScgScan& T = P.scan;
     int obs = c;
 #pragma unroll
     for (int r = 0; r < SCG_MAX_REGIONS; ++r) {
         int slot = reverse ? (SCG_MAX_REGIONS - 1 - r) : r;
-        int start = reverse ? T->rstart[r] : T->fstart[r];
+        int start = reverse ? T.rstart[r] : T.fstart[r];
         const ScgIndex& tab = P.index[slot];
         Query q = region_query<NW>(tile, sr.bit + p + start, tab.len, reverse);
         int idx, d;
@@ -293,14 +293,14 @@ __global__ __launch_bounds__(STAGE_BLOCK) void combo_staged_kernel(ScgComboParam
     const int64_t r0 = (int64_t)blockIdx.x * STAGE_BLOCK;
     const int nr = (int)((n_reads - r0) < STAGE_BLOCK ? (n_reads - r0) : STAGE_BLOCK);
     int64_t span0 = 0;
-    const bool staged = (P.tmpl->len <= 32 * NT) && stage_reads<NW>(R, n_reads, r0, nr, tile, span0);
+    const bool staged = (P.scan.len <= 32 * NT) && stage_reads<NW>(R, n_reads, r0, nr, tile, span0);
     __syncthreads();
     if ((int)threadIdx.x >= nr) return;
     Read rd = get_read(R, r0 + threadIdx.x);
     int found = 0, best = P.max_mm + 1;
     int best_id[SCG_MAX_REGIONS] = {0, 0};
     if (staged && rd.n <= 32 * NW) {
-        const ScgTemplate* T = P.tmpl;
+        const ScgScan& T = P.scan;
         StagedRead sr;
         sr.bit = (int)((int64_t)(rd.p - R.seqs) - span0);
         sr.n = rd.n;
@@ -340,11 +340,11 @@ __device__ __forceinline__ void dual_orientation_staged(const ScgDualParams& P,
                                                         const Tile<NW>& ta, const StagedRead& a,
                                                         const Tile<NW>& tb, const StagedRead& b,
                                                         int& chosen, int& best) {
-    const ScgTemplate* T1 = P.tmpl1;
-    const ScgTemplate* T2 = P.tmpl2;
+    const ScgScan& T1 = P.scan1;
+    const ScgScan& T2 = P.scan2;
     const bool rev1 = P.rev1 != 0, rev2 = P.rev2 != 0;
-    const int s1 = rev1 ? T1->rstart[0] : T1->fstart[0];
-    const int s2 = rev2 ? T2->rstart[0] : T2->fstart[0];
+    const int s1 = rev1 ? T1.rstart[0] : T1.fstart[0];
+    const int s2 = rev2 ? T2.rstart[0] : T2.fstart[0];
     chosen = -1;
     best = P.max_mm1 + P.max_mm2 + 1;
     uint32_t c1[NW], c2[NW], unused[NW];
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(STAGE_BLOCK) void dual_staged_kernel(ScgDualParams 
     const int64_t r0 = (int64_t)blockIdx.x * STAGE_BLOCK;
     const int nr = (int)((n_pairs - r0) < STAGE_BLOCK ? (n_pairs - r0) : STAGE_BLOCK);
     int64_t span1 = 0, span2 = 0;
-    const bool fits = P.tmpl1->len <= 32 * NT && P.tmpl2->len <= 32 * NT;
+    const bool fits = P.scan1.len <= 32 * NT && P.scan2.len <= 32 * NT;
     const bool ok1 = fits && stage_reads<NW>(R1, n_pairs, r0, nr, tile1, span1);
     const bool ok2 = ok1 && stage_reads<NW>(R2, n_pairs, r0, nr, tile2, span2);
     __syncthreads();

@@ -180,15 +180,6 @@ HostTemplate parse_template(const char* constant, int strand) {
         t.rpos[k] = static_cast<uint8_t>(L - 1 - t.fpos[src]);
         t.rcode[k] = static_cast<uint8_t>(t.fcode[src] ^ 2);
     }
-    for (int k = 0; k < nconst; ++k) {
-        int fp = t.fpos[k], rp = t.rpos[k];
-        t.fmask[fp >> 5] |= 1u << (fp & 31);
-        t.fplane0[fp >> 5] |= static_cast<uint32_t>(t.fcode[k] & 1) << (fp & 31);
-        t.fplane1[fp >> 5] |= static_cast<uint32_t>(t.fcode[k] >> 1) << (fp & 31);
-        t.rmask[rp >> 5] |= 1u << (rp & 31);
-        t.rplane0[rp >> 5] |= static_cast<uint32_t>(t.rcode[k] & 1) << (rp & 31);
-        t.rplane1[rp >> 5] |= static_cast<uint32_t>(t.rcode[k] >> 1) << (rp & 31);
-    }
     // Callers reject any template whose region count is not the one they expect, so only
     // region counts the engine can use are materialised.
     if (nreg <= SCG_MAX_REGIONS) {
@@ -370,12 +361,28 @@ HostPairTable build_pair_table(const std::vector<std::vector<int32_t> >& exp1, c
     return P;
 }
 
-void build_seeds(ScgTemplate& t, int max_mm) {
+ScgScan build_scan(const ScgTemplate& t, int max_mm) {
+    ScgScan sc;
+    std::memset(&sc, 0, sizeof(sc));
+    sc.len = t.len;
+    sc.nreg = t.nreg;
+    for (int r = 0; r < SCG_MAX_REGIONS; ++r) {
+        sc.fstart[r] = t.fstart[r];
+        sc.rstart[r] = t.rstart[r];
+    }
+    for (int k = 0; k < t.nconst; ++k) {
+        int fp = t.fpos[k], rp = t.rpos[k];
+        sc.fmask[fp >> 5] |= 1u << (fp & 31);
+        sc.fplane0[fp >> 5] |= static_cast<uint32_t>(t.fcode[k] & 1) << (fp & 31);
+        sc.fplane1[fp >> 5] |= static_cast<uint32_t>(t.fcode[k] >> 1) << (fp & 31);
+        sc.rmask[rp >> 5] |= 1u << (rp & 31);
+        sc.rplane0[rp >> 5] |= static_cast<uint32_t>(t.rcode[k] & 1) << (rp & 31);
+        sc.rplane1[rp >> 5] |= static_cast<uint32_t>(t.rcode[k] >> 1) << (rp & 31);
+    }
     // k + 1 disjoint groups of constant positions for a budget of k mismatches; with fewer than
     // k + 1 constant bases (or k + 1 > SCG_MAX_SEEDS) no filter is possible and every position is
     // a candidate.
     auto fill = [&](ScgSeeds& S, const uint8_t* pos, const uint8_t* code) {
-        std::memset(&S, 0, sizeof(S));
         int want = max_mm + 1;
         if (want > SCG_MAX_SEEDS || t.nconst < want) {
             S.nseeds = 0;
@@ -387,14 +394,19 @@ void build_seeds(ScgTemplate& t, int max_mm) {
             int b = static_cast<int>(static_cast<int64_t>(i + 1) * t.nconst / want);
             int m = std::min(b - a, SCG_SEED_LEN);
             S.len[i] = m;
+            S.first[i] = pos[a];
             for (int j = 0; j < m; ++j) {
-                S.pos[i][j] = pos[a + j];
-                S.code[i][j] = code[a + j];
+                S.codes[i] |= static_cast<uint32_t>(code[a + j]) << (2 * j);
+                if (j + 1 < m) {
+                    uint32_t gap = static_cast<uint32_t>(pos[a + j + 1] - pos[a + j]);   // 1..255
+                    S.gaps[i][j >> 2] |= gap << (8 * (j & 3));
+                }
             }
         }
     };
-    fill(t.fseeds, t.fpos, t.fcode);
-    fill(t.rseeds, t.rpos, t.rcode);
+    fill(sc.fseeds, t.fpos, t.fcode);
+    fill(sc.rseeds, t.rpos, t.rcode);
+    return sc;
 }
 
 } // namespace scg

@@ -177,7 +177,7 @@ __device__ __forceinline__ void and_code(uint32_t a[NW], const BasePlanes<NW>& E
 }
 
 // Phase B for one strand: positions p (bit p of cand) where at least one seed matches exactly
-// and p + T <= n.
+// and p + T <= n.  The seed description is wave-uniform (kernel arguments, SGPRs).
 template<int NW>
 __device__ __forceinline__ void seed_candidates(const BasePlanes<NW>& E, const ScgSeeds& S, int tlen, int n,
                                                 uint32_t cand[NW]) {
@@ -190,18 +190,22 @@ __device__ __forceinline__ void seed_candidates(const BasePlanes<NW>& E, const S
     }
 #pragma unroll
     for (int i = 0; i < NW; ++i) cand[i] = 0;
-    for (int s = 0; s < S.nseeds; ++s) {
+#pragma unroll
+    for (int s = 0; s < SCG_MAX_SEEDS; ++s) {
+        if (s >= S.nseeds) break;
         uint32_t a[NW];
 #pragma unroll
         for (int i = 0; i < NW; ++i) a[i] = 0xFFFFFFFFu;
-        int m = S.len[s];
+        const int m = S.len[s];
         if (m > 0) {
-            and_code<NW>(a, E, S.code[s][m - 1]);
+            const uint32_t codes = S.codes[s];
+            and_code<NW>(a, E, (codes >> (2 * (m - 1))) & 3);
             for (int j = m - 2; j >= 0; --j) {
-                shift_right<NW>(a, (int)S.pos[s][j + 1] - (int)S.pos[s][j]);
-                and_code<NW>(a, E, S.code[s][j]);
+                int gap = (S.gaps[s][j >> 2] >> (8 * (j & 3))) & 0xFF;
+                shift_right<NW>(a, gap);
+                and_code<NW>(a, E, (codes >> (2 * j)) & 3);
             }
-            shift_right<NW>(a, (int)S.pos[s][0]);
+            shift_right<NW>(a, S.first[s]);
         }
 #pragma unroll
         for (int i = 0; i < NW; ++i) cand[i] |= a[i];
@@ -232,7 +236,7 @@ __device__ __forceinline__ void clear_bit(uint32_t m[NW], int pos) {
 // Exact number of constant-region mismatches of the template placed at plane bit `bit`
 // (kaori/ScanTemplate.hpp:233-252: a non-standard base mismatches a constant position).
 template<int NW, int NT>
-__device__ __forceinline__ int window_mismatches(const Tile<NW>& tile, int bit, const ScgTemplate* __restrict__ T, bool reverse) {
+__device__ __forceinline__ int window_mismatches(const Tile<NW>& tile, int bit, const ScgScan& T, bool reverse) {
     uint32_t w0[NT], w1[NT], wv[NT];
     load_bits<NT>(tile.p0, bit, w0);
     load_bits<NT>(tile.p1, bit, w1);
@@ -240,9 +244,9 @@ __device__ __forceinline__ int window_mismatches(const Tile<NW>& tile, int bit, 
     int mm = 0;
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
-        uint32_t t0 = reverse ? T->rplane0[i] : T->fplane0[i];
-        uint32_t t1 = reverse ? T->rplane1[i] : T->fplane1[i];
-        uint32_t cm = reverse ? T->rmask[i] : T->fmask[i];
+        uint32_t t0 = reverse ? T.rplane0[i] : T.fplane0[i];
+        uint32_t t1 = reverse ? T.rplane1[i] : T.fplane1[i];
+        uint32_t cm = reverse ? T.rmask[i] : T.fmask[i];
         uint32_t same = wv[i] & ~((w0[i] ^ t0) | (w1[i] ^ t1));
         mm += __popc(cm & ~same);
     }
@@ -273,7 +277,7 @@ struct StagedRead {
 
 // Phase B for both strands of one template.
 template<int NW>
-__device__ __forceinline__ void scan_read(const Tile<NW>& tile, const StagedRead& sr, const ScgTemplate* __restrict__ T,
+__device__ __forceinline__ void scan_read(const Tile<NW>& tile, const StagedRead& sr, const ScgScan& T,
                                           bool fwd, bool rev, uint32_t candF[NW], uint32_t candR[NW]) {
     BasePlanes<NW> E;
     {
@@ -292,13 +296,13 @@ __device__ __forceinline__ void scan_read(const Tile<NW>& tile, const StagedRead
         }
     }
     if (fwd) {
-        seed_candidates<NW>(E, T->fseeds, T->len, sr.n, candF);
+        seed_candidates<NW>(E, T.fseeds, T.len, sr.n, candF);
     } else {
 #pragma unroll
         for (int i = 0; i < NW; ++i) candF[i] = 0;
     }
     if (rev) {
-        seed_candidates<NW>(E, T->rseeds, T->len, sr.n, candR);
+        seed_candidates<NW>(E, T.rseeds, T.len, sr.n, candR);
     } else {
 #pragma unroll
         for (int i = 0; i < NW; ++i) candR[i] = 0;
