@@ -226,6 +226,8 @@ ScgReads make_reads(const char* d_seqs, const uint32_t* d_offsets, int32_t fixed
     r.offsets = d_offsets;
     r.fixed_len = d_offsets ? 0 : fixed_len;
     r.max_len = d_offsets ? max_len : fixed_len;
+    const char* ab = std::getenv("SCG_ABLATE");   // profiling aid only: results are wrong when set
+    r.ablate = ab ? std::atoi(ab) : 0;
     return r;
 }
 

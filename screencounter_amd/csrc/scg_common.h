@@ -20,7 +20,7 @@
 #define SCG_MAX_BARCODE 32     // bases per variable region handled by the packed-key engine
 #define SCG_MAX_SEGMENTS 4     // pigeonhole segments of the library index (mismatch budgets <= 3)
 #define SCG_MAX_SEEDS 4        // pigeonhole seeds of the constant-region scan (budgets <= 3)
-#define SCG_SEED_LEN 12        // constant bases per seed (at most)
+#define SCG_SEED_LEN 10        // constant bases per seed (at most)
 #define SCG_EMPTY_KEY (~0ull)
 
 #define SCG_MISSING (-1)
@@ -32,12 +32,25 @@
 // ScanTemplate reports (kaori/ScanTemplate.hpp:233-252); every candidate is then verified exactly.
 // Packed into dwords so that the whole description travels in the kernel-argument segment and
 // lives in SGPRs (gfx950 has no scalar byte loads).
+// For one (seed, base code): the walk along plane E[code].  Step k shifts the running copy of
+// the plane right by (byte & 31) bits and then ANDs it into the seed's match mask unless bit 7 is
+// set (a pure shift, used to split distances > 31).  Bytes are consumed from byte 0 of w[0] up.
+#define SCG_SEED_STEPS 16
+struct ScgSeedWalk {
+    uint32_t w[SCG_SEED_STEPS / 4];
+};
+
+struct ScgSeed {
+    int32_t len;                             // bases in the seed (0 => matches everywhere)
+    uint32_t nsteps;                         // byte c: number of steps of walk[c]
+    int32_t pad[2];
+    ScgSeedWalk walk[4];                     // per base code
+};
+
 struct ScgSeeds {
     int32_t nseeds;                          // 0 => every position is a candidate
-    int32_t len[SCG_MAX_SEEDS];              // bases in seed i (0 => matches everywhere)
-    int32_t first[SCG_MAX_SEEDS];            // template offset of the seed's first base
-    uint32_t codes[SCG_MAX_SEEDS];           // base j of the seed at bits 2j, 2j+1
-    uint32_t gaps[SCG_MAX_SEEDS][SCG_SEED_LEN / 4];   // byte j: offset(base j+1) - offset(base j)
+    int32_t pad[3];
+    ScgSeed seed[SCG_MAX_SEEDS];
 };
 
 // Everything the staged scan of one template needs, by value in the kernel arguments.
@@ -103,6 +116,7 @@ struct ScgReads {
     const uint32_t* offsets;  // n + 1 entries, or nullptr for fixed-length reads
     int32_t fixed_len;
     int32_t max_len;          // hint: upper bound on the read lengths (0 = unknown); picks the LDS tile shape only
+    int32_t ablate;           // profiling aid (SCG_ABLATE): 1 = skip phase C, 2 = skip phases B and C; 0 in production
 };
 
 struct ScgSingleParams {

@@ -209,11 +209,12 @@ __global__ __launch_bounds__(BLOCK) void dual_kernel(ScgDualParams P, ScgReads R
 // Staged kernels
 // =============================================================================================
 template<int NW, int NT>
-__device__ __forceinline__ int single_read_staged(const ScgSingleParams& P, const Tile<NW>& tile, const StagedRead& sr) {
+__device__ __forceinline__ int single_read_staged(const ScgSingleParams& P, const Tile<NW>& tile, const StagedRead& sr, int ablate = 0) {
     const ScgScan& T = P.scan;
     const int max_mm = P.max_mm;
     uint32_t candF[NW], candR[NW];
     scan_read<NW>(tile, sr, T, P.fwd != 0, P.rev != 0, candF, candR);
+    if (ablate == 1) return (candF[0] ^ candR[NW - 1]) == 0x12345u ? 0 : -1;
     int found = 0, index = -1, best = max_mm + 1;
     for (;;) {
         int pf = first_bit<NW>(candF), pr = first_bit<NW>(candR);
@@ -257,7 +258,11 @@ __global__ __launch_bounds__(STAGE_BLOCK) void single_staged_kernel(ScgSinglePar
         StagedRead sr;
         sr.bit = (int)((int64_t)(rd.p - R.seqs) - span0);
         sr.n = rd.n;
-        idx = single_read_staged<NW, NT>(P, tile, sr);
+        if (R.ablate >= 2) {
+            idx = (tile.p0[threadIdx.x] == 0xdeadbeefu) ? 0 : -1;
+        } else {
+            idx = single_read_staged<NW, NT>(P, tile, sr, R.ablate);
+        }
     } else {
         idx = single_read(P, rd);
     }

@@ -393,14 +393,30 @@ ScgScan build_scan(const ScgTemplate& t, int max_mm) {
             int a = static_cast<int>(static_cast<int64_t>(i) * t.nconst / want);
             int b = static_cast<int>(static_cast<int64_t>(i + 1) * t.nconst / want);
             int m = std::min(b - a, SCG_SEED_LEN);
-            S.len[i] = m;
-            S.first[i] = pos[a];
-            for (int j = 0; j < m; ++j) {
-                S.codes[i] |= static_cast<uint32_t>(code[a + j]) << (2 * j);
-                if (j + 1 < m) {
-                    uint32_t gap = static_cast<uint32_t>(pos[a + j + 1] - pos[a + j]);   // 1..255
-                    S.gaps[i][j >> 2] |= gap << (8 * (j & 3));
+            // Shrink the seed until every per-code walk fits its 16 step bytes (long shifts are
+            // split into <= 31-bit steps, so far-apart bases cost extra bytes).
+            for (;; --m) {
+                bool fits = true;
+                ScgSeed sd;
+                std::memset(&sd, 0, sizeof(sd));
+                sd.len = m;
+                for (int c = 0; c < 4 && fits; ++c) {
+                    uint8_t steps[64];
+                    int ns = 0, prev = 0;
+                    for (int j = 0; j < m; ++j) {
+                        if (code[a + j] != c) continue;
+                        int delta = pos[a + j] - prev;
+                        prev = pos[a + j];
+                        while (delta > 31) { steps[ns++] = 0x80 | 31; delta -= 31; }   // pure shifts
+                        steps[ns++] = static_cast<uint8_t>(delta);                     // shift (maybe 0) then AND
+                    }
+                    if (ns > SCG_SEED_STEPS) { fits = false; break; }
+                    for (int k = 0; k < ns; ++k) {
+                        sd.walk[c].w[k >> 2] |= static_cast<uint32_t>(steps[k]) << (8 * (k & 3));
+                    }
+                    sd.nsteps |= static_cast<uint32_t>(ns) << (8 * c);
                 }
+                if (fits || m == 0) { S.seed[i] = sd; break; }
             }
         }
     };

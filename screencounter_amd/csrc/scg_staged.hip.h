@@ -83,26 +83,42 @@ __device__ __forceinline__ bool stage_reads(const ScgReads& R, int64_t n_reads, 
     uint16_t* h0 = reinterpret_cast<uint16_t*>(tile.p0);
     uint16_t* h1 = reinterpret_cast<uint16_t*>(tile.p1);
     uint16_t* hv = reinterpret_cast<uint16_t*>(tile.v);
-    for (int c = threadIdx.x; c < nchunks; c += STAGE_BLOCK) {
-        int64_t cb = span0 + 16 * (int64_t)c;
-        uint4 x;
-        if (cb >= 0 && (uint64_t)(cb + 16) <= total) {
-            x = *reinterpret_cast<const uint4*>(R.seqs + cb);
-        } else {
-            // first / last chunk of the buffer: never touch bytes outside [0, total)
-            uint32_t t[4] = {0, 0, 0, 0};
-            for (int j = 0; j < 16; ++j) {
-                int64_t o = cb + j;
-                uint32_t byte = (o >= 0 && (uint64_t)o < total) ? R.seqs[o] : 0u;
-                t[j >> 2] |= byte << (8 * (j & 3));
+    // Loads are issued NW at a time before any of them is consumed, so that a lane has NW
+    // independent 16-byte requests in flight instead of one HBM round trip per chunk.
+    constexpr int BATCH = NW;
+    for (int c0 = threadIdx.x; c0 < nchunks; c0 += STAGE_BLOCK * BATCH) {
+        uint4 x[BATCH];
+#pragma unroll
+        for (int k = 0; k < BATCH; ++k) {
+            const int c = c0 + k * STAGE_BLOCK;
+            x[k] = make_uint4(0, 0, 0, 0);
+            if (c < nchunks) {
+                int64_t cb = span0 + 16 * (int64_t)c;
+                if (cb >= 0 && (uint64_t)(cb + 16) <= total) {
+                    x[k] = *reinterpret_cast<const uint4*>(R.seqs + cb);
+                } else {
+                    // first / last chunk of the buffer: never touch bytes outside [0, total)
+                    uint32_t t[4] = {0, 0, 0, 0};
+                    for (int j = 0; j < 16; ++j) {
+                        int64_t o = cb + j;
+                        uint32_t byte = (o >= 0 && (uint64_t)o < total) ? R.seqs[o] : 0u;
+                        t[j >> 2] |= byte << (8 * (j & 3));
+                    }
+                    x[k] = make_uint4(t[0], t[1], t[2], t[3]);
+                }
             }
-            x = make_uint4(t[0], t[1], t[2], t[3]);
         }
-        uint32_t p0, p1, v;
-        transpose_chunk(x, p0, p1, v);
-        h0[c] = (uint16_t)p0;
-        h1[c] = (uint16_t)p1;
-        hv[c] = (uint16_t)v;
+#pragma unroll
+        for (int k = 0; k < BATCH; ++k) {
+            const int c = c0 + k * STAGE_BLOCK;
+            if (c < nchunks) {
+                uint32_t p0, p1, v;
+                transpose_chunk(x[k], p0, p1, v);
+                h0[c] = (uint16_t)p0;
+                h1[c] = (uint16_t)p1;
+                hv[c] = (uint16_t)v;
+            }
+        }
     }
     return true;
 }
@@ -153,31 +169,14 @@ struct BasePlanes {
     uint32_t e[4][NW];     // e[code][word]: bit j set iff base j is a standard base with that code
 };
 
-template<int NW>
-__device__ __forceinline__ void and_code(uint32_t a[NW], const BasePlanes<NW>& E, int code) {
-    // `code` is wave-uniform: a scalar branch, static register indices
-    switch (code) {
-        case 0:
-#pragma unroll
-            for (int i = 0; i < NW; ++i) a[i] &= E.e[0][i];
-            break;
-        case 1:
-#pragma unroll
-            for (int i = 0; i < NW; ++i) a[i] &= E.e[1][i];
-            break;
-        case 2:
-#pragma unroll
-            for (int i = 0; i < NW; ++i) a[i] &= E.e[2][i];
-            break;
-        default:
-#pragma unroll
-            for (int i = 0; i < NW; ++i) a[i] &= E.e[3][i];
-            break;
-    }
-}
-
 // Phase B for one strand: positions p (bit p of cand) where at least one seed matches exactly
 // and p + T <= n.  The seed description is wave-uniform (kernel arguments, SGPRs).
+//
+// A seed with bases (t_j, c_j) matches at p iff  AND_j E[c_j][p + t_j].  The product is
+// evaluated one base CODE at a time: for a fixed (compile-time) code c a running copy of plane
+// E[c] is shifted along the seed's offsets and ANDed in wherever the seed asks for c (the walk is
+// precomputed on the host as step bytes).  Every register index is static, each seed base costs
+// one multi-word funnel shift and one multi-word 3-input bit op, branch-free.
 template<int NW>
 __device__ __forceinline__ void seed_candidates(const BasePlanes<NW>& E, const ScgSeeds& S, int tlen, int n,
                                                 uint32_t cand[NW]) {
@@ -190,25 +189,41 @@ __device__ __forceinline__ void seed_candidates(const BasePlanes<NW>& E, const S
     }
 #pragma unroll
     for (int i = 0; i < NW; ++i) cand[i] = 0;
+    for (int s = 0; s < S.nseeds; ++s) {
+        uint32_t g[NW];
 #pragma unroll
-    for (int s = 0; s < SCG_MAX_SEEDS; ++s) {
-        if (s >= S.nseeds) break;
-        uint32_t a[NW];
+        for (int i = 0; i < NW; ++i) g[i] = 0xFFFFFFFFu;
+        const uint32_t counts = S.seed[s].nsteps;
 #pragma unroll
-        for (int i = 0; i < NW; ++i) a[i] = 0xFFFFFFFFu;
-        const int m = S.len[s];
-        if (m > 0) {
-            const uint32_t codes = S.codes[s];
-            and_code<NW>(a, E, (codes >> (2 * (m - 1))) & 3);
-            for (int j = m - 2; j >= 0; --j) {
-                int gap = (S.gaps[s][j >> 2] >> (8 * (j & 3))) & 0xFF;
-                shift_right<NW>(a, gap);
-                and_code<NW>(a, E, (codes >> (2 * j)) & 3);
+        for (int c = 0; c < 4; ++c) {
+            int left = (int)((counts >> (8 * c)) & 0xFFu);
+            if (left == 0) continue;
+            uint32_t cur[NW];
+#pragma unroll
+            for (int wi = 0; wi < SCG_SEED_STEPS / 4; ++wi) {
+                if (left <= 0) break;
+                uint32_t word = S.seed[s].walk[c].w[wi];
+                const int cnt = left < 4 ? left : 4;
+                left -= 4;
+                for (int k = 0; k < cnt; ++k) {
+                    const int sh = (int)(word & 31u);
+                    const uint32_t keep = (word & 0x80u) ? 0xFFFFFFFFu : 0u;   // pure shift: AND is a no-op
+                    word >>= 8;
+                    if (wi == 0 && k == 0) {
+                        // first step reads the plane itself
+#pragma unroll
+                        for (int i = 0; i < NW - 1; ++i) cur[i] = __builtin_amdgcn_alignbit(E.e[c][i + 1], E.e[c][i], sh);
+                        cur[NW - 1] = E.e[c][NW - 1] >> sh;
+                    } else {
+                        shift_right_small<NW>(cur, sh);
+                    }
+#pragma unroll
+                    for (int i = 0; i < NW; ++i) g[i] &= (cur[i] | keep);
+                }
             }
-            shift_right<NW>(a, S.first[s]);
         }
 #pragma unroll
-        for (int i = 0; i < NW; ++i) cand[i] |= a[i];
+        for (int i = 0; i < NW; ++i) cand[i] |= g[i];
     }
 #pragma unroll
     for (int i = 0; i < NW; ++i) cand[i] &= ok[i];
