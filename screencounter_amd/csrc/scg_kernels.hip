@@ -243,7 +243,7 @@ __device__ __forceinline__ int single_read_staged(const ScgSingleParams& P, cons
 }
 
 template<int NW, int NT>
-__global__ __launch_bounds__(STAGE_BLOCK) void single_staged_kernel(ScgSingleParams P, ScgReads R, int64_t n_reads,
+__global__ __launch_bounds__(STAGE_BLOCK) __attribute__((amdgpu_num_sgpr(80))) void single_staged_kernel(ScgSingleParams P, ScgReads R, int64_t n_reads,
                                                                    int32_t* __restrict__ counts) {
     __shared__ Tile<NW> tile;
     const int64_t r0 = (int64_t)blockIdx.x * STAGE_BLOCK;
@@ -292,7 +292,7 @@ __device__ __forceinline__ bool combo_candidate_staged(const ScgComboParams& P, 
 }
 
 template<int NW, int NT>
-__global__ __launch_bounds__(STAGE_BLOCK) void combo_staged_kernel(ScgComboParams P, ScgReads R, int64_t n_reads,
+__global__ __launch_bounds__(STAGE_BLOCK) __attribute__((amdgpu_num_sgpr(80))) void combo_staged_kernel(ScgComboParams P, ScgReads R, int64_t n_reads,
                                                                   int32_t* __restrict__ cells) {
     __shared__ Tile<NW> tile;
     const int64_t r0 = (int64_t)blockIdx.x * STAGE_BLOCK;
@@ -388,7 +388,7 @@ __device__ __forceinline__ void dual_orientation_staged(const ScgDualParams& P,
 }
 
 template<int NW, int NT>
-__global__ __launch_bounds__(STAGE_BLOCK) void dual_staged_kernel(ScgDualParams P, ScgReads R1, ScgReads R2, int64_t n_pairs,
+__global__ __launch_bounds__(STAGE_BLOCK) __attribute__((amdgpu_num_sgpr(80))) void dual_staged_kernel(ScgDualParams P, ScgReads R1, ScgReads R2, int64_t n_pairs,
                                                                  int32_t* __restrict__ counts) {
     __shared__ Tile<NW> tile1;
     __shared__ Tile<NW> tile2;

@@ -85,7 +85,7 @@ __device__ __forceinline__ bool stage_reads(const ScgReads& R, int64_t n_reads, 
     uint16_t* hv = reinterpret_cast<uint16_t*>(tile.v);
     // Loads are issued NW at a time before any of them is consumed, so that a lane has NW
     // independent 16-byte requests in flight instead of one HBM round trip per chunk.
-    constexpr int BATCH = NW;
+    constexpr int BATCH = 2 * NW;
     for (int c0 = threadIdx.x; c0 < nchunks; c0 += STAGE_BLOCK * BATCH) {
         uint4 x[BATCH];
 #pragma unroll
