@@ -169,6 +169,7 @@ struct scg_plan {
     DevIndex tab[2];
     DevPairTable pairs;
     DevBuf own_counters;
+    DevBuf error_flag;   // set by a staged kernel that met a read longer than the declared maximum
     int32_t* counters = nullptr;
     int64_t n_counters = 0;
     int64_t total = 0;
@@ -196,6 +197,8 @@ struct scg_plan {
         own_counters.alloc(static_cast<size_t>(n_counters) * sizeof(int32_t));
         counters = own_counters.as<int32_t>();
         HIP_CHECK(hipMemset(counters, 0, static_cast<size_t>(n_counters) * sizeof(int32_t)));
+        error_flag.alloc(sizeof(int32_t));
+        HIP_CHECK(hipMemset(error_flag.p, 0, sizeof(int32_t)));
         // host copies are no longer needed
         for (auto& h : htab) { h = scg::HostIndex(); }
         hpairs = scg::HostPairTable();
@@ -344,7 +347,7 @@ void launch_batch(scg_plan* P, const ScgReads& R, int64_t n, hipStream_t stream)
         sp.index = P->tab[0].view;
         sp.max_mm = P->max_mm1; sp.use_first = P->use_first;
         sp.fwd = P->ht1.fwd; sp.rev = P->ht1.rev;
-        HIP_CHECK(scg::launch_single(sp, P->ht1.t.len, R, n, P->counters, stream));
+        HIP_CHECK(scg::launch_single(sp, P->ht1.t.len, R, n, P->counters, P->error_flag.as<int32_t>(), stream));
     } else {
         ScgComboParams cp;
         cp.scan = P->scan1;
@@ -353,7 +356,7 @@ void launch_batch(scg_plan* P, const ScgReads& R, int64_t n, hipStream_t stream)
         cp.n_pool[0] = P->n_pool[0]; cp.n_pool[1] = P->n_pool[1];
         cp.max_mm = P->max_mm1; cp.use_first = P->use_first;
         cp.fwd = P->ht1.fwd; cp.rev = P->ht1.rev;
-        HIP_CHECK(scg::launch_combo(cp, P->ht1.t.len, R, n, P->counters, stream));
+        HIP_CHECK(scg::launch_combo(cp, P->ht1.t.len, R, n, P->counters, P->error_flag.as<int32_t>(), stream));
     }
     timer.stop();
     P->total += n;
@@ -367,7 +370,7 @@ void launch_batch_paired(scg_plan* P, const ScgReads& R1, const ScgReads& R2, in
     dp.index1 = P->tab[0].view; dp.index2 = P->tab[1].view; dp.pairs = P->pairs.view;
     dp.rev1 = P->rev1; dp.rev2 = P->rev2; dp.max_mm1 = P->max_mm1; dp.max_mm2 = P->max_mm2;
     dp.randomized = P->randomized; dp.use_first = P->use_first;
-    HIP_CHECK(scg::launch_dual(dp, std::max(P->ht1.t.len, P->ht2.t.len), R1, R2, n, P->counters, stream));
+    HIP_CHECK(scg::launch_dual(dp, std::max(P->ht1.t.len, P->ht2.t.len), R1, R2, n, P->counters, P->error_flag.as<int32_t>(), stream));
     timer.stop();
     P->total += n;
 }
@@ -429,6 +432,11 @@ const int64_t BATCH_READS = int64_t(1) << 22;
 const int64_t BATCH_BYTES = int64_t(1) << 30;
 
 void read_counters(scg_plan* P, int32_t* counts_out) {
+    int32_t flag = 0;
+    HIP_CHECK(hipMemcpy(&flag, P->error_flag.p, sizeof(flag), hipMemcpyDeviceToHost));
+    if (flag) {
+        throw Error(SCG_ERR_INVALID, "a read is longer than the max_len declared for its batch: counts are incomplete");
+    }
     if (counts_out && P->n_counters) {
         HIP_CHECK(hipMemcpy(counts_out, P->counters, static_cast<size_t>(P->n_counters) * sizeof(int32_t), hipMemcpyDeviceToHost));
     }
@@ -546,6 +554,7 @@ int scg_plan_reset(scg_plan* plan, void* stream, char* err, size_t errcap) {
         if (!plan) throw Error(SCG_ERR_INVALID, "null plan");
         DeviceGuard g(plan->device);
         HIP_CHECK(hipMemsetAsync(plan->counters, 0, static_cast<size_t>(plan->n_counters) * sizeof(int32_t), static_cast<hipStream_t>(stream)));
+        HIP_CHECK(hipMemsetAsync(plan->error_flag.p, 0, sizeof(int32_t), static_cast<hipStream_t>(stream)));
         plan->total = 0;
     });
 }

@@ -244,7 +244,7 @@ __device__ __forceinline__ int single_read_staged(const ScgSingleParams& P, cons
 
 template<int NW, int NT>
 __global__ __launch_bounds__(STAGE_BLOCK) __attribute__((amdgpu_num_sgpr(80))) void single_staged_kernel(ScgSingleParams P, ScgReads R, int64_t n_reads,
-                                                                   int32_t* __restrict__ counts) {
+                                                                   int32_t* __restrict__ counts, int32_t* __restrict__ error_flag) {
     __shared__ Tile<NW> tile;
     const int64_t r0 = (int64_t)blockIdx.x * STAGE_BLOCK;
     const int nr = (int)((n_reads - r0) < STAGE_BLOCK ? (n_reads - r0) : STAGE_BLOCK);
@@ -253,18 +253,20 @@ __global__ __launch_bounds__(STAGE_BLOCK) __attribute__((amdgpu_num_sgpr(80))) v
     __syncthreads();
     if ((int)threadIdx.x >= nr) return;
     Read rd = get_read(R, r0 + threadIdx.x);
+    if (!staged || rd.n > 32 * NW) {
+        // The host picks the tile shape from the batch's maximum read length; landing here means
+        // that bound was wrong.  Flag it (reported by scg_plan_read) instead of guessing.
+        *error_flag = 1;
+        return;
+    }
+    StagedRead sr;
+    sr.bit = (int)((int64_t)(rd.p - R.seqs) - span0);
+    sr.n = rd.n;
     int idx;
-    if (staged && rd.n <= 32 * NW) {
-        StagedRead sr;
-        sr.bit = (int)((int64_t)(rd.p - R.seqs) - span0);
-        sr.n = rd.n;
-        if (R.ablate >= 2) {
-            idx = (tile.p0[threadIdx.x] == 0xdeadbeefu) ? 0 : -1;
-        } else {
-            idx = single_read_staged<NW, NT>(P, tile, sr, R.ablate);
-        }
+    if (R.ablate >= 2) {
+        idx = (tile.p0[threadIdx.x] == 0xdeadbeefu) ? 0 : -1;
     } else {
-        idx = single_read(P, rd);
+        idx = single_read_staged<NW, NT>(P, tile, sr, R.ablate);
     }
     if (idx >= 0) atomicAdd(&counts[idx], 1);
 }
@@ -293,7 +295,7 @@ __device__ __forceinline__ bool combo_candidate_staged(const ScgComboParams& P, 
 
 template<int NW, int NT>
 __global__ __launch_bounds__(STAGE_BLOCK) __attribute__((amdgpu_num_sgpr(80))) void combo_staged_kernel(ScgComboParams P, ScgReads R, int64_t n_reads,
-                                                                  int32_t* __restrict__ cells) {
+                                                                  int32_t* __restrict__ cells, int32_t* __restrict__ error_flag) {
     __shared__ Tile<NW> tile;
     const int64_t r0 = (int64_t)blockIdx.x * STAGE_BLOCK;
     const int nr = (int)((n_reads - r0) < STAGE_BLOCK ? (n_reads - r0) : STAGE_BLOCK);
@@ -304,7 +306,11 @@ __global__ __launch_bounds__(STAGE_BLOCK) __attribute__((amdgpu_num_sgpr(80))) v
     Read rd = get_read(R, r0 + threadIdx.x);
     int found = 0, best = P.max_mm + 1;
     int best_id[SCG_MAX_REGIONS] = {0, 0};
-    if (staged && rd.n <= 32 * NW) {
+    if (!staged || rd.n > 32 * NW) {
+        *error_flag = 1;
+        return;
+    }
+    {
         const ScgScan& T = P.scan;
         StagedRead sr;
         sr.bit = (int)((int64_t)(rd.p - R.seqs) - span0);
@@ -333,8 +339,6 @@ __global__ __launch_bounds__(STAGE_BLOCK) __attribute__((amdgpu_num_sgpr(80))) v
                 }
             }
         }
-    } else {
-        found = combo_read(P, rd, best_id);
     }
     if (found) atomicAdd(&cells[(int64_t)best_id[0] * P.n_pool[1] + best_id[1]], 1);
 }
@@ -389,7 +393,7 @@ __device__ __forceinline__ void dual_orientation_staged(const ScgDualParams& P,
 
 template<int NW, int NT>
 __global__ __launch_bounds__(STAGE_BLOCK) __attribute__((amdgpu_num_sgpr(80))) void dual_staged_kernel(ScgDualParams P, ScgReads R1, ScgReads R2, int64_t n_pairs,
-                                                                 int32_t* __restrict__ counts) {
+                                                                 int32_t* __restrict__ counts, int32_t* __restrict__ error_flag) {
     __shared__ Tile<NW> tile1;
     __shared__ Tile<NW> tile2;
     const int64_t r0 = (int64_t)blockIdx.x * STAGE_BLOCK;
@@ -402,7 +406,11 @@ __global__ __launch_bounds__(STAGE_BLOCK) __attribute__((amdgpu_num_sgpr(80))) v
     if ((int)threadIdx.x >= nr) return;
     Read a = get_read(R1, r0 + threadIdx.x), b = get_read(R2, r0 + threadIdx.x);
     int idx;
-    if (ok2 && a.n <= 32 * NW && b.n <= 32 * NW) {
+    if (!ok2 || a.n > 32 * NW || b.n > 32 * NW) {
+        *error_flag = 1;
+        return;
+    }
+    {
         StagedRead sa, sb;
         sa.bit = (int)((int64_t)(a.p - R1.seqs) - span1); sa.n = a.n;
         sb.bit = (int)((int64_t)(b.p - R2.seqs) - span2); sb.n = b.n;
@@ -419,8 +427,6 @@ __global__ __launch_bounds__(STAGE_BLOCK) __attribute__((amdgpu_num_sgpr(80))) v
                 else if (best == best2 && idx != idx2) { idx = -1; }
             }
         }
-    } else {
-        idx = dual_pair(P, a, b);
     }
     if (idx >= 0) atomicAdd(&counts[idx], 1);
 }
@@ -537,52 +543,57 @@ hipError_t dispatch_shape(int max_len, int tmpl_len, Args&&... args) {
 }
 
 template<int NW, int NT> struct LaunchSingle {
-    static hipError_t go(const ScgSingleParams& P, const ScgReads& R, int64_t n, int32_t* counts, hipStream_t stream) {
-        hipLaunchKernelGGL((single_staged_kernel<NW, NT>), dim3(grid_for(n)), dim3(STAGE_BLOCK), 0, stream, P, R, n, counts);
+    static hipError_t go(const ScgSingleParams& P, const ScgReads& R, int64_t n, int32_t* counts, int32_t* flag, hipStream_t stream) {
+        hipLaunchKernelGGL((single_staged_kernel<NW, NT>), dim3(grid_for(n)), dim3(STAGE_BLOCK), 0, stream, P, R, n, counts, flag);
         return hipGetLastError();
     }
 };
 template<int NW, int NT> struct LaunchCombo {
-    static hipError_t go(const ScgComboParams& P, const ScgReads& R, int64_t n, int32_t* cells, hipStream_t stream) {
-        hipLaunchKernelGGL((combo_staged_kernel<NW, NT>), dim3(grid_for(n)), dim3(STAGE_BLOCK), 0, stream, P, R, n, cells);
+    static hipError_t go(const ScgComboParams& P, const ScgReads& R, int64_t n, int32_t* cells, int32_t* flag, hipStream_t stream) {
+        hipLaunchKernelGGL((combo_staged_kernel<NW, NT>), dim3(grid_for(n)), dim3(STAGE_BLOCK), 0, stream, P, R, n, cells, flag);
         return hipGetLastError();
     }
 };
 template<int NW, int NT> struct LaunchDual {
-    static hipError_t go(const ScgDualParams& P, const ScgReads& R1, const ScgReads& R2, int64_t n, int32_t* counts, hipStream_t stream) {
-        hipLaunchKernelGGL((dual_staged_kernel<NW, NT>), dim3(grid_for(n)), dim3(STAGE_BLOCK), 0, stream, P, R1, R2, n, counts);
+    static hipError_t go(const ScgDualParams& P, const ScgReads& R1, const ScgReads& R2, int64_t n, int32_t* counts, int32_t* flag, hipStream_t stream) {
+        hipLaunchKernelGGL((dual_staged_kernel<NW, NT>), dim3(grid_for(n)), dim3(STAGE_BLOCK), 0, stream, P, R1, R2, n, counts, flag);
         return hipGetLastError();
     }
 };
 
 } // namespace
 
-hipError_t launch_single(const ScgSingleParams& P, int tmpl_len, const ScgReads& R, int64_t n, int32_t* counts, hipStream_t stream) {
+// The staged kernels need every read to fit a tile row (<= 320 bases); batches with longer reads
+// or an unknown maximum length take the byte-wise general kernels.
+static bool use_general(int max_len) { return force_general() || max_len <= 0 || max_len > 320; }
+
+hipError_t launch_single(const ScgSingleParams& P, int tmpl_len, const ScgReads& R, int64_t n, int32_t* counts, int32_t* flag, hipStream_t stream) {
     if (n <= 0) return hipSuccess;
-    if (force_general()) {
+    if (use_general(R.max_len)) {
         hipLaunchKernelGGL(single_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, stream, P, R, n, counts);
         return hipGetLastError();
     }
-    return dispatch_shape<LaunchSingle>(R.max_len, tmpl_len, P, R, n, counts, stream);
+    return dispatch_shape<LaunchSingle>(R.max_len, tmpl_len, P, R, n, counts, flag, stream);
 }
 
-hipError_t launch_combo(const ScgComboParams& P, int tmpl_len, const ScgReads& R, int64_t n, int32_t* cells, hipStream_t stream) {
+hipError_t launch_combo(const ScgComboParams& P, int tmpl_len, const ScgReads& R, int64_t n, int32_t* cells, int32_t* flag, hipStream_t stream) {
     if (n <= 0) return hipSuccess;
-    if (force_general()) {
+    if (use_general(R.max_len)) {
         hipLaunchKernelGGL(combo_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, stream, P, R, n, cells);
         return hipGetLastError();
     }
-    return dispatch_shape<LaunchCombo>(R.max_len, tmpl_len, P, R, n, cells, stream);
+    return dispatch_shape<LaunchCombo>(R.max_len, tmpl_len, P, R, n, cells, flag, stream);
 }
 
-hipError_t launch_dual(const ScgDualParams& P, int tmpl_len, const ScgReads& R1, const ScgReads& R2, int64_t n, int32_t* counts, hipStream_t stream) {
+hipError_t launch_dual(const ScgDualParams& P, int tmpl_len, const ScgReads& R1, const ScgReads& R2, int64_t n, int32_t* counts, int32_t* flag, hipStream_t stream) {
     if (n <= 0) return hipSuccess;
-    if (force_general()) {
+    const int lo_len = R1.max_len < R2.max_len ? R1.max_len : R2.max_len;
+    if (use_general(lo_len) || use_general(R1.max_len > R2.max_len ? R1.max_len : R2.max_len)) {
         hipLaunchKernelGGL(dual_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, stream, P, R1, R2, n, counts);
         return hipGetLastError();
     }
     const int max_len = R1.max_len > R2.max_len ? R1.max_len : R2.max_len;
-    return dispatch_shape<LaunchDual>(max_len, tmpl_len, P, R1, R2, n, counts, stream);
+    return dispatch_shape<LaunchDual>(max_len, tmpl_len, P, R1, R2, n, counts, flag, stream);
 }
 
 hipError_t launch_match(const ScgIndex& tab, const uint8_t* d_seqs, int32_t n, int cap, int reverse,

@@ -17,9 +17,10 @@
 //           from LDS), its variable region is cut out of the planes and matched through the
 //           segment index (scg_engine.hip.h).
 //
-// Reads longer than 32*NW bases, templates longer than 32*NT and workgroups whose byte span
-// exceeds the LDS tile are handled by the byte-wise general engine inside the same kernel, so
-// the result never depends on which path ran.
+// The host picks NW / NT from the batch's maximum read length and the template length, so every
+// read fits its tile row; batches with reads longer than 320 bases (or of unknown maximum length)
+// are counted by the byte-wise general kernels instead.  A staged kernel that nevertheless meets
+// an oversize read raises the plan's error flag rather than producing a wrong count.
 #ifndef SCG_STAGED_HIP_H
 #define SCG_STAGED_HIP_H
 
@@ -32,8 +33,9 @@ constexpr int STAGE_BLOCK = 256;      // lanes = reads per workgroup
 
 template<int NW>
 struct Tile {
-    static constexpr int CAP_BYTES = STAGE_BLOCK * 32 * NW;          // bytes (= bases) per tile
-    static constexpr int WORDS = CAP_BYTES / 32 + NW + 4;            // plane words incl. read-ahead slack
+    // 256 reads of up to 32*NW bases plus the <= 15 bytes the span starts before its first read
+    static constexpr int CAP_BYTES = STAGE_BLOCK * 32 * NW + 16;
+    static constexpr int WORDS = CAP_BYTES / 32 + NW + 5;            // plane words incl. read-ahead slack
     uint32_t p0[WORDS];
     uint32_t p1[WORDS];
     uint32_t v[WORDS];
@@ -95,7 +97,11 @@ __device__ __forceinline__ bool stage_reads(const ScgReads& R, int64_t n_reads, 
             if (c < nchunks) {
                 int64_t cb = span0 + 16 * (int64_t)c;
                 if (cb >= 0 && (uint64_t)(cb + 16) <= total) {
-                    x[k] = *reinterpret_cast<const uint4*>(R.seqs + cb);
+                    // streamed once: non-temporal, so the read bytes do not evict the library index from L2
+                    const uint32_t* src = reinterpret_cast<const uint32_t*>(R.seqs + cb);
+                    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                    u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src));
+                    x[k] = make_uint4(t.x, t.y, t.z, t.w);
                 } else {
                     // first / last chunk of the buffer: never touch bytes outside [0, total)
                     uint32_t t[4] = {0, 0, 0, 0};

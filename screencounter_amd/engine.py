@@ -33,6 +33,14 @@ def _dev_ptr(t) -> int:
     return 0 if t is None else int(t.data_ptr())
 
 
+def _max_len(offsets, n: int) -> int:
+    """Longest read of a ragged batch (one small device reduction + sync; callers that know the
+    bound pass max_len themselves)."""
+    import torch
+    o = offsets[: n + 1].to(torch.int64) & 0xFFFFFFFF
+    return int((o[1:] - o[:-1]).max().item()) if n > 0 else 0
+
+
 def _check_u8(t, name):
     import torch
     if t.dtype != torch.uint8 or not t.is_cuda or not t.is_contiguous():
@@ -144,6 +152,8 @@ class Plan:
         _check_offsets(offsets, "offsets")
         if offsets is not None:
             n = offsets.numel() - 1 if n_reads is None else n_reads
+            if max_len <= 0 and n > 0:
+                max_len = _max_len(offsets, n)
         else:
             if fixed_len <= 0:
                 raise ValueError("either offsets or a positive fixed_len is required")
@@ -175,6 +185,10 @@ class Plan:
             n_pairs = n1
         elif n_pairs > min(n1, n2):
             raise ValueError("n_pairs exceeds the batch")
+        if max_len <= 0 and n_pairs > 0:
+            m1 = fixed_len1 if offsets1 is None else _max_len(offsets1, n_pairs)
+            m2 = fixed_len2 if offsets2 is None else _max_len(offsets2, n_pairs)
+            max_len = max(m1, m2)
         err = errbuf()
         check(self._lib.scg_count_batch_paired(self._h, C.c_void_p(_dev_ptr(seqs1)), C.c_void_p(_dev_ptr(offsets1)), int(fixed_len1),
                                                C.c_void_p(_dev_ptr(seqs2)), C.c_void_p(_dev_ptr(offsets2)), int(fixed_len2),

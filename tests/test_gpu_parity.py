@@ -118,3 +118,56 @@ def test_match_random(sc, oracle, gpu, seed):
             continue
         got = sc.match_barcodes(case["sequences"], case["choices"], case["substitutions"], case["reverse"])
         assert np.array_equal(got[0], exp[0]) and np.array_equal(got[1], exp[1]), case
+
+
+def test_long_and_mixed_reads(sc, oracle, gpu):
+    """Reads beyond the staged tile rows (> 320 bases) route the batch to the byte-wise kernels."""
+    rng = random.Random(5150)
+    pool = gen.make_pool(rng, 50, 12, gen.BASES)
+    template = "ACGTTGCA" + "-" * 12 + "GGATCCAA"
+    reads = []
+    for i in range(300):
+        core = gen.mutate(rng, gen.fill_template(template, [rng.choice(pool)]), 0.02, 0.01, 0.05)
+        pad = rng.choice([10, 100, 400, 900]) if i % 3 == 0 else rng.choice([0, 20, 120])
+        r = gen.rand_seq(rng, rng.randint(0, pad)) + core + gen.rand_seq(rng, rng.randint(0, pad))
+        reads.append(gen.rc(r) if rng.random() < 0.5 else r)
+    assert max(len(r) for r in reads) > 320
+    exp = oracle.count_single(reads, template, 2, pool, 1, False)
+    case = dict(reads=reads, template=template, strand=2, pool=pool, mismatches=1, use_first=False)
+    got = run_single(sc, case, gpu)
+    assert got[1] == exp[1] and np.array_equal(got[0], exp[0])
+    # wide tile (161..320 bases) on the staged path
+    mid = [r for r in reads if len(r) <= 320]
+    assert max(len(r) for r in mid) > 160
+    exp = oracle.count_single(mid, template, 2, pool, 1, True)
+    case = dict(reads=mid, template=template, strand=2, pool=pool, mismatches=1, use_first=True)
+    got = run_single(sc, case, gpu)
+    assert got[1] == exp[1] and np.array_equal(got[0], exp[0])
+
+
+def test_wrong_max_len_hint_is_reported(sc, gpu, engine):
+    if engine == "general":
+        pytest.skip("the general kernels do not use the hint")
+    reads = ["ACGT" + "A" * 200 + "TGCA"] * 10
+    seqs, offs = sc.upload_reads(reads, gpu)
+    with sc.Plan.single("ACGT----TGCA", 0, ["AAAA"], 0, True) as plan:
+        plan.count(seqs, offs, max_len=100)     # a lie: the reads are 208 bases long
+        with pytest.raises(sc.ScgError, match="longer than the max_len"):
+            plan.read()
+
+
+def test_template_longer_than_64(sc, oracle, gpu):
+    """NT = 4 / 8 tiles: templates of 100 and 200 bases."""
+    rng = random.Random(99)
+    for flank in (40, 90):
+        pool = gen.make_pool(rng, 30, 20, gen.BASES)
+        template = gen.rand_seq(rng, flank) + "-" * 20 + gen.rand_seq(rng, flank)
+        reads = []
+        for _ in range(200):
+            core = gen.mutate(rng, gen.fill_template(template, [rng.choice(pool)]), 0.01, 0.005, 0.0)
+            r = gen.rand_seq(rng, rng.randint(0, 40)) + core + gen.rand_seq(rng, rng.randint(0, 40))
+            reads.append(gen.rc(r) if rng.random() < 0.5 else r)
+        for mm in (0, 2):
+            exp = oracle.count_single(reads, template, 2, pool, mm, True)
+            got = run_single(sc, dict(reads=reads, template=template, strand=2, pool=pool, mismatches=mm, use_first=True), gpu)
+            assert got[1] == exp[1] and np.array_equal(got[0], exp[0]), (flank, mm)
