@@ -89,7 +89,7 @@ struct ScgTemplate {
 // kaori/BarcodeSearch.hpp:243-251 and kaori/MismatchTrie.hpp:446-501 with the same
 // unique-minimum semantics.
 struct ScgIndex {
-    const uint4* entries;       // n_entries x {key lo, key hi, value, 0}
+    const uint4* entries;       // n_entries x {key lo, key hi, value, next entry of segment 0's chain}
     const int32_t* next;        // [nseg][n_entries] chain links (-1 ends a chain)
     const uint2* slots;         // [nseg][slot_mask + 1] {tag, head entry + 1} ; head 0 = empty
     uint32_t slot_mask;

@@ -145,7 +145,10 @@ __device__ __forceinline__ void index_search(const ScgIndex& X, const Query& q, 
         const uint2* slots = X.slots + (size_t)s * nslots;
         int e = -1;
         for (;;) {
-            uint2 sl = slots[pos];
+            const uint64_t raw = reinterpret_cast<const uint64_t*>(slots)[pos];   // {tag, head + 1} in one load
+            uint2 sl;
+            sl.x = (uint32_t)raw;
+            sl.y = (uint32_t)(raw >> 32);
             if (sl.y == 0) break;                 // empty slot: no entry shares this segment
             if (sl.x == h) {
                 uint4 head = X.entries[sl.y - 1];
@@ -158,7 +161,7 @@ __device__ __forceinline__ void index_search(const ScgIndex& X, const Query& q, 
             uint4 ent = X.entries[e];
             int d = query_distance(q, ent.x, ent.y, lm);
             if (d <= cap && f((int)ent.z, d)) return;
-            e = next[e];
+            e = (s == 0) ? (int)ent.w : next[e];   // segment 0's chain link rides in the entry itself
         }
     }
 }

@@ -225,7 +225,8 @@ __device__ __forceinline__ int single_read_staged(const ScgSingleParams& P, cons
         clear_bit<NW>(candR, rev ? p : -1);
         int c = window_mismatches<NW, NT>(tile, sr.bit + p, T, rev);
         if (c > max_mm) continue;
-        int start = rev ? T.rstart[0] : T.fstart[0];
+        const int fs = uniform(T.fstart[0]), rs = uniform(T.rstart[0]);
+        int start = rev ? rs : fs;
         Query q = region_query<NW>(tile, sr.bit + p + start, P.index.len, rev);
         int idx, d;
         index_match(P.index, q, max_mm - c, idx, d);
@@ -279,7 +280,8 @@ __device__ __forceinline__ bool combo_candidate_staged(const ScgComboParams& P, 
 #pragma unroll
     for (int r = 0; r < SCG_MAX_REGIONS; ++r) {
         int slot = reverse ? (SCG_MAX_REGIONS - 1 - r) : r;
-        int start = reverse ? T.rstart[r] : T.fstart[r];
+        const int fs = uniform(T.fstart[r]), rs = uniform(T.rstart[r]);
+        int start = reverse ? rs : fs;
         const ScgIndex& tab = P.index[slot];
         Query q = region_query<NW>(tile, sr.bit + p + start, tab.len, reverse);
         int idx, d;

@@ -219,7 +219,7 @@ void finish_index(HostIndex& X, const std::vector<uint64_t>& keys, const std::ve
         X.entries[4 * e] = static_cast<uint32_t>(keys[e]);
         X.entries[4 * e + 1] = static_cast<uint32_t>(keys[e] >> 32);
         X.entries[4 * e + 2] = static_cast<uint32_t>(vals[e]);
-        X.entries[4 * e + 3] = 0;
+        X.entries[4 * e + 3] = 0xFFFFFFFFu;   // no chain link (-1) until the segment tables are built
     }
     int nseg = max_mm + 1;
     if (nseg > SCG_MAX_SEGMENTS) {
@@ -241,6 +241,7 @@ void finish_index(HostIndex& X, const std::vector<uint64_t>& keys, const std::ve
         uint32_t* slots = X.slots.data() + static_cast<size_t>(sgm) * cap * 2;
         int32_t* next = X.next.data() + static_cast<size_t>(sgm) * keys.size();
         // Insert back to front so that every chain lists its entries in ascending order.
+        // (segment 0's links are also mirrored into word 3 of each entry, see below)
         for (size_t i = keys.size(); i-- > 0;) {
             uint64_t sk = keys[i] & mask;
             uint32_t h = scg_hash64(sk);
@@ -259,6 +260,9 @@ void finish_index(HostIndex& X, const std::vector<uint64_t>& keys, const std::ve
                 }
                 pos = (pos + 1) & X.slot_mask;
             }
+        }
+        if (sgm == 0) {
+            for (size_t e = 0; e < keys.size(); ++e) X.entries[4 * e + 3] = static_cast<uint32_t>(next[e]);
         }
     }
 }

@@ -31,6 +31,10 @@ namespace scgdev {
 
 constexpr int STAGE_BLOCK = 256;      // lanes = reads per workgroup
 
+// Marks a wave-uniform value as such (keeps it in an SGPR).
+__device__ __forceinline__ uint32_t uniform(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+__device__ __forceinline__ int uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
+
 template<int NW>
 struct Tile {
     // 256 reads of up to 32*NW bases plus the <= 15 bytes the span starts before its first read
@@ -241,7 +245,7 @@ __device__ __forceinline__ int first_bit(const uint32_t m[NW]) {
     int pos = 1 << 30;
 #pragma unroll
     for (int i = NW - 1; i >= 0; --i) {
-        if (m[i]) pos = 32 * i + (__ffs((int)m[i]) - 1);
+        if (m[i]) pos = 32 * i + __builtin_ctz(m[i]);
     }
     return pos;
 }
@@ -265,9 +269,14 @@ __device__ __forceinline__ int window_mismatches(const Tile<NW>& tile, int bit, 
     int mm = 0;
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
-        uint32_t t0 = reverse ? T.rplane0[i] : T.fplane0[i];
-        uint32_t t1 = reverse ? T.rplane1[i] : T.fplane1[i];
-        uint32_t cm = reverse ? T.rmask[i] : T.fmask[i];
+        // both strands' words are pinned in SGPRs first: selecting between two kernel-argument
+        // fields by a per-lane condition otherwise becomes a per-lane LOAD from the argument segment
+        const uint32_t f0 = uniform(T.fplane0[i]), r0 = uniform(T.rplane0[i]);
+        const uint32_t f1 = uniform(T.fplane1[i]), r1 = uniform(T.rplane1[i]);
+        const uint32_t fm = uniform(T.fmask[i]), rm = uniform(T.rmask[i]);
+        uint32_t t0 = reverse ? r0 : f0;
+        uint32_t t1 = reverse ? r1 : f1;
+        uint32_t cm = reverse ? rm : fm;
         uint32_t same = wv[i] & ~((w0[i] ^ t0) | (w1[i] ^ t1));
         mm += __popc(cm & ~same);
     }
