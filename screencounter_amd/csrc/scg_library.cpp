@@ -393,9 +393,13 @@ ScgScan build_scan(const ScgTemplate& t, int max_mm) {
             return;
         }
         S.nseeds = want;
+        // Seeds are the first `want` runs of m consecutive constant positions: any disjoint groups
+        // satisfy the pigeonhole argument, and groups near the template start keep every shift of
+        // the bit-parallel walk short.
+        const int per = std::min(SCG_SEED_LEN, t.nconst / want);
         for (int i = 0; i < want; ++i) {
-            int a = static_cast<int>(static_cast<int64_t>(i) * t.nconst / want);
-            int b = static_cast<int>(static_cast<int64_t>(i + 1) * t.nconst / want);
+            int a = i * per;
+            int b = a + per;
             int m = std::min(b - a, SCG_SEED_LEN);
             // Shrink the seed until every per-code walk fits its 16 step bytes (long shifts are
             // split into <= 31-bit steps, so far-apart bases cost extra bytes).

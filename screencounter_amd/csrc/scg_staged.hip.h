@@ -89,25 +89,32 @@ __device__ __forceinline__ bool stage_reads(const ScgReads& R, int64_t n_reads, 
     uint16_t* h0 = reinterpret_cast<uint16_t*>(tile.p0);
     uint16_t* h1 = reinterpret_cast<uint16_t*>(tile.p1);
     uint16_t* hv = reinterpret_cast<uint16_t*>(tile.v);
-    // Loads are issued NW at a time before any of them is consumed, so that a lane has NW
-    // independent 16-byte requests in flight instead of one HBM round trip per chunk.
-    constexpr int BATCH = 2 * NW;
+    // All of a lane's loads are issued before any is consumed, so that it has 2*NW independent
+    // 16-byte requests in flight instead of one HBM round trip per chunk.  Only the first and the
+    // last workgroup of a buffer can touch bytes outside [0, total); they take the guarded loop.
+    constexpr int BATCH = NW;
+    const bool edge = span0 < 0 || (uint64_t)(span0 + 16 * (int64_t)nchunks) > total;
     for (int c0 = threadIdx.x; c0 < nchunks; c0 += STAGE_BLOCK * BATCH) {
         uint4 x[BATCH];
+        const uint8_t* base = R.seqs + span0 + 16 * (int64_t)c0;
+        if (!edge) {
 #pragma unroll
-        for (int k = 0; k < BATCH; ++k) {
-            const int c = c0 + k * STAGE_BLOCK;
-            x[k] = make_uint4(0, 0, 0, 0);
-            if (c < nchunks) {
-                int64_t cb = span0 + 16 * (int64_t)c;
-                if (cb >= 0 && (uint64_t)(cb + 16) <= total) {
+            for (int k = 0; k < BATCH; ++k) {
+                x[k] = make_uint4(0, 0, 0, 0);
+                if (c0 + k * STAGE_BLOCK < nchunks) {
                     // streamed once: non-temporal, so the read bytes do not evict the library index from L2
-                    const uint32_t* src = reinterpret_cast<const uint32_t*>(R.seqs + cb);
                     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-                    u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src));
+                    u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(base + (size_t)k * STAGE_BLOCK * 16));
                     x[k] = make_uint4(t.x, t.y, t.z, t.w);
-                } else {
-                    // first / last chunk of the buffer: never touch bytes outside [0, total)
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < BATCH; ++k) {       // static k: x[] must stay in registers
+                x[k] = make_uint4(0, 0, 0, 0);
+                const int c = c0 + k * STAGE_BLOCK;
+                if (c < nchunks) {
+                    int64_t cb = span0 + 16 * (int64_t)c;
                     uint32_t t[4] = {0, 0, 0, 0};
                     for (int j = 0; j < 16; ++j) {
                         int64_t o = cb + j;
@@ -242,12 +249,16 @@ __device__ __forceinline__ void seed_candidates(const BasePlanes<NW>& E, const S
 // Lowest set bit of an NW-word mask, or 1 << 30 when empty.
 template<int NW>
 __device__ __forceinline__ int first_bit(const uint32_t m[NW]) {
-    int pos = 1 << 30;
+    // v_ffbl_b32 returns 0xFFFFFFFF for an empty word, which survives the OR and loses every min
+    uint32_t pos = 0xFFFFFFFFu;
 #pragma unroll
-    for (int i = NW - 1; i >= 0; --i) {
-        if (m[i]) pos = 32 * i + __builtin_ctz(m[i]);
+    for (int i = 0; i < NW; ++i) {
+        uint32_t r;
+        asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(m[i]));
+        r |= 32u * i;
+        pos = r < pos ? r : pos;
     }
-    return pos;
+    return pos >= (1u << 30) ? (1 << 30) : (int)pos;
 }
 
 template<int NW>
