@@ -60,6 +60,8 @@ struct ScgScan {
     int32_t fstart[SCG_MAX_REGIONS];          // variable-region starts, forward template
     int32_t rstart[SCG_MAX_REGIONS];          // ... on the reverse-complemented template
     ScgSeeds fseeds, rseeds;
+    int32_t compact_ok;                       // every seed starts below bit 32 and spans < 32 positions
+    int32_t pad[3];
     // bit planes of the constant bases (word w covers template positions 32w .. 32w+31)
     uint32_t fplane0[SCG_MAX_TEMPLATE / 32], fplane1[SCG_MAX_TEMPLATE / 32], fmask[SCG_MAX_TEMPLATE / 32];
     uint32_t rplane0[SCG_MAX_TEMPLATE / 32], rplane1[SCG_MAX_TEMPLATE / 32], rmask[SCG_MAX_TEMPLATE / 32];

@@ -208,21 +208,21 @@ __global__ __launch_bounds__(BLOCK) void dual_kernel(ScgDualParams P, ScgReads R
 // =============================================================================================
 // Staged kernels
 // =============================================================================================
-template<int NW, int NT>
+template<int NW, int NT, int NC>
 __device__ __forceinline__ int single_read_staged(const ScgSingleParams& P, const Tile<NW>& tile, const StagedRead& sr, int ablate = 0) {
     const ScgScan& T = P.scan;
     const int max_mm = P.max_mm;
-    uint32_t candF[NW], candR[NW];
-    scan_read<NW>(tile, sr, T, P.fwd != 0, P.rev != 0, candF, candR);
-    if (ablate == 1) return (candF[0] ^ candR[NW - 1]) == 0x12345u ? 0 : -1;
+    uint32_t candF[NC], candR[NC];
+    scan_read<NW, NC>(tile, sr, T, P.fwd != 0, P.rev != 0, candF, candR);
+    if (ablate == 1) return (candF[0] ^ candR[NC - 1]) == 0x12345u ? 0 : -1;
     int found = 0, index = -1, best = max_mm + 1;
     for (;;) {
-        int pf = first_bit<NW>(candF), pr = first_bit<NW>(candR);
+        int pf = first_bit<NC>(candF), pr = first_bit<NC>(candR);
         bool rev = pr < pf;                           // forward first on ties
         int p = rev ? pr : pf;
         if (p >= (1 << 30)) break;
-        clear_bit<NW>(candF, rev ? -1 : p);
-        clear_bit<NW>(candR, rev ? p : -1);
+        clear_bit<NC>(candF, rev ? -1 : p);
+        clear_bit<NC>(candR, rev ? p : -1);
         int c = window_mismatches<NW, NT>(tile, sr.bit + p, T, rev);
         if (c > max_mm) continue;
         const int fs = uniform(T.fstart[0]), rs = uniform(T.rstart[0]);
@@ -243,7 +243,8 @@ __device__ __forceinline__ int single_read_staged(const ScgSingleParams& P, cons
     return found ? index : -1;
 }
 
-template<int NW, int NT>
+// NC < NW ("compact"): candidate positions fit 32*NC bits and the plan's seeds allow it (ScgScan::compact_ok).
+template<int NW, int NT, int NC>
 __global__ __launch_bounds__(STAGE_BLOCK) __attribute__((amdgpu_num_sgpr(80))) void single_staged_kernel(ScgSingleParams P, ScgReads R, int64_t n_reads,
                                                                    int32_t* __restrict__ counts, int32_t* __restrict__ error_flag) {
     __shared__ Tile<NW> tile;
@@ -267,7 +268,7 @@ __global__ __launch_bounds__(STAGE_BLOCK) __attribute__((amdgpu_num_sgpr(80))) v
     if (R.ablate >= 2) {
         idx = (tile.p0[threadIdx.x] == 0xdeadbeefu) ? 0 : -1;
     } else {
-        idx = single_read_staged<NW, NT>(P, tile, sr, R.ablate);
+        idx = single_read_staged<NW, NT, NC>(P, tile, sr, R.ablate);
     }
     if (idx >= 0) atomicAdd(&counts[idx], 1);
 }
@@ -546,7 +547,12 @@ hipError_t dispatch_shape(int max_len, int tmpl_len, Args&&... args) {
 
 template<int NW, int NT> struct LaunchSingle {
     static hipError_t go(const ScgSingleParams& P, const ScgReads& R, int64_t n, int32_t* counts, int32_t* flag, hipStream_t stream) {
-        hipLaunchKernelGGL((single_staged_kernel<NW, NT>), dim3(grid_for(n)), dim3(STAGE_BLOCK), 0, stream, P, R, n, counts, flag);
+        // compact variant: all candidate positions (0 .. max_len - T) fit 3 words of a 5-word read
+        if (NW == 5 && P.scan.compact_ok && R.max_len - P.scan.len + 1 <= 96) {
+            hipLaunchKernelGGL((single_staged_kernel<NW, NT, (NW == 5 ? 3 : NW)>), dim3(grid_for(n)), dim3(STAGE_BLOCK), 0, stream, P, R, n, counts, flag);
+        } else {
+            hipLaunchKernelGGL((single_staged_kernel<NW, NT, NW>), dim3(grid_for(n)), dim3(STAGE_BLOCK), 0, stream, P, R, n, counts, flag);
+        }
         return hipGetLastError();
     }
 };

@@ -430,6 +430,21 @@ ScgScan build_scan(const ScgTemplate& t, int max_mm) {
     };
     fill(sc.fseeds, t.fpos, t.fcode);
     fill(sc.rseeds, t.rpos, t.rcode);
+    // The compact kernels keep only the candidate words plus one of the running planes: valid when
+    // no walk has to move a plane by 32 bits or more in total.
+    sc.compact_ok = 1;
+    auto check = [&](const ScgSeeds& S, const uint8_t* pos) {
+        const int per = S.nseeds > 0 ? std::min(SCG_SEED_LEN, t.nconst / S.nseeds) : 0;
+        for (int i = 0; i < S.nseeds; ++i) {
+            int m = S.seed[i].len;
+            if (m <= 0) continue;
+            int first = pos[i * per], last = pos[i * per + m - 1];
+            if (last >= 32) sc.compact_ok = 0;     // total shift of any walk = offset of its last base
+            (void)first;
+        }
+    };
+    check(sc.fseeds, t.fpos);
+    check(sc.rseeds, t.rpos);
     return sc;
 }
 

@@ -194,28 +194,33 @@ struct BasePlanes {
 // E[c] is shifted along the seed's offsets and ANDed in wherever the seed asks for c (the walk is
 // precomputed on the host as step bytes).  Every register index is static, each seed base costs
 // one multi-word funnel shift and one multi-word 3-input bit op, branch-free.
-template<int NW>
+//
+// NC = words of candidate positions kept (positions 0 .. 32*NC-1).  With NC < NW (the host
+// guarantees that every seed then starts below bit 32 and spans < 32 positions) only NC + 1
+// words of the running plane are ever needed.
+template<int NW, int NC>
 __device__ __forceinline__ void seed_candidates(const BasePlanes<NW>& E, const ScgSeeds& S, int tlen, int n,
-                                                uint32_t cand[NW]) {
-    uint32_t ok[NW];
-    low_bits<NW>(n - tlen + 1, ok);
+                                                uint32_t cand[NC]) {
+    constexpr int NS = (NC < NW) ? NC + 1 : NW;     // words of the running plane
+    uint32_t ok[NC];
+    low_bits<NC>(n - tlen + 1, ok);
     if (S.nseeds == 0) {
 #pragma unroll
-        for (int i = 0; i < NW; ++i) cand[i] = ok[i];
+        for (int i = 0; i < NC; ++i) cand[i] = ok[i];
         return;
     }
 #pragma unroll
-    for (int i = 0; i < NW; ++i) cand[i] = 0;
+    for (int i = 0; i < NC; ++i) cand[i] = 0;
     for (int s = 0; s < S.nseeds; ++s) {
-        uint32_t g[NW];
+        uint32_t g[NC];
 #pragma unroll
-        for (int i = 0; i < NW; ++i) g[i] = 0xFFFFFFFFu;
+        for (int i = 0; i < NC; ++i) g[i] = 0xFFFFFFFFu;
         const uint32_t counts = S.seed[s].nsteps;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             int left = (int)((counts >> (8 * c)) & 0xFFu);
             if (left == 0) continue;
-            uint32_t cur[NW];
+            uint32_t cur[NS];
 #pragma unroll
             for (int wi = 0; wi < SCG_SEED_STEPS / 4; ++wi) {
                 if (left <= 0) break;
@@ -229,21 +234,23 @@ __device__ __forceinline__ void seed_candidates(const BasePlanes<NW>& E, const S
                     if (wi == 0 && k == 0) {
                         // first step reads the plane itself
 #pragma unroll
-                        for (int i = 0; i < NW - 1; ++i) cur[i] = __builtin_amdgcn_alignbit(E.e[c][i + 1], E.e[c][i], sh);
-                        cur[NW - 1] = E.e[c][NW - 1] >> sh;
+                        for (int i = 0; i < NS; ++i) {
+                            cur[i] = (i + 1 < NW) ? __builtin_amdgcn_alignbit(E.e[c][i + 1 < NW ? i + 1 : i], E.e[c][i], sh)
+                                                  : (E.e[c][i] >> sh);
+                        }
                     } else {
-                        shift_right_small<NW>(cur, sh);
+                        shift_right_small<NS>(cur, sh);
                     }
 #pragma unroll
-                    for (int i = 0; i < NW; ++i) g[i] &= (cur[i] | keep);
+                    for (int i = 0; i < NC; ++i) g[i] &= (cur[i] | keep);
                 }
             }
         }
 #pragma unroll
-        for (int i = 0; i < NW; ++i) cand[i] |= g[i];
+        for (int i = 0; i < NC; ++i) cand[i] |= g[i];
     }
 #pragma unroll
-    for (int i = 0; i < NW; ++i) cand[i] &= ok[i];
+    for (int i = 0; i < NC; ++i) cand[i] &= ok[i];
 }
 
 // Lowest set bit of an NW-word mask, or 1 << 30 when empty.
@@ -317,9 +324,9 @@ struct StagedRead {
 };
 
 // Phase B for both strands of one template.
-template<int NW>
+template<int NW, int NC = NW>
 __device__ __forceinline__ void scan_read(const Tile<NW>& tile, const StagedRead& sr, const ScgScan& T,
-                                          bool fwd, bool rev, uint32_t candF[NW], uint32_t candR[NW]) {
+                                          bool fwd, bool rev, uint32_t candF[NC], uint32_t candR[NC]) {
     BasePlanes<NW> E;
     {
         uint32_t p0[NW], p1[NW], v[NW], lim[NW];
@@ -337,16 +344,16 @@ __device__ __forceinline__ void scan_read(const Tile<NW>& tile, const StagedRead
         }
     }
     if (fwd) {
-        seed_candidates<NW>(E, T.fseeds, T.len, sr.n, candF);
+        seed_candidates<NW, NC>(E, T.fseeds, T.len, sr.n, candF);
     } else {
 #pragma unroll
-        for (int i = 0; i < NW; ++i) candF[i] = 0;
+        for (int i = 0; i < NC; ++i) candF[i] = 0;
     }
     if (rev) {
-        seed_candidates<NW>(E, T.rseeds, T.len, sr.n, candR);
+        seed_candidates<NW, NC>(E, T.rseeds, T.len, sr.n, candR);
     } else {
 #pragma unroll
-        for (int i = 0; i < NW; ++i) candR[i] = 0;
+        for (int i = 0; i < NC; ++i) candR[i] = 0;
     }
 }
 
