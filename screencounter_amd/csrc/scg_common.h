@@ -22,6 +22,7 @@
 #define SCG_MAX_SEEDS 4        // pigeonhole seeds of the constant-region scan (budgets <= 3)
 #define SCG_SEED_LEN 10        // constant bases per seed (at most)
 #define SCG_EMPTY_KEY (~0ull)
+#define SCG_SLOT_EMPTY 0xFFFFFFFEu
 
 #define SCG_MISSING (-1)
 #define SCG_AMBIGUOUS (-2)
@@ -94,6 +95,9 @@ struct ScgIndex {
     const uint4* entries;       // n_entries x {key lo, key hi, value, next entry of segment 0's chain}
     const int32_t* next;        // [nseg][n_entries] chain links (-1 ends a chain)
     const uint2* slots;         // [nseg][slot_mask + 1] {tag, head entry + 1} ; head 0 = empty
+    const uint4* table0;        // segment 0 only: [slot_mask + 1] copy of the chain's head entry in the slot
+                                // itself ({lo, hi, value, next}; next == SCG_SLOT_EMPTY marks a free slot), so
+                                // that an exact hit costs one memory access
     uint32_t slot_mask;
     int32_t n_entries;
     int32_t len;                // bases per key

@@ -132,36 +132,57 @@ __device__ __forceinline__ void index_search(const ScgIndex& X, const Query& q, 
         return;
     }
     // any cap + 1 segments suffice: at most cap of them can hold a mismatch
-    int nwalk = cap + 1 < X.nseg ? cap + 1 : X.nseg;
+    const int nwalk = cap + 1 < X.nseg ? cap + 1 : X.nseg;
     const uint64_t qkey = ((uint64_t)q.hi << 32) | q.lo;
     const uint64_t qother = ((uint64_t)q.other << 32) | q.other;
     const uint32_t nslots = X.slot_mask + 1u;
-    for (int s = 0; s < nwalk; ++s) {
-        uint64_t mask = X.segmask[s];
+#pragma unroll
+    for (int s = 0; s < SCG_MAX_SEGMENTS; ++s) {
+        if (s >= nwalk) break;
+        const uint64_t mask = X.segmask[s];
         if (qother & mask) continue;              // a non-ACGT byte spoils this segment
-        uint64_t sk = qkey & mask;
-        uint32_t h = scg_hash64(sk);
+        const uint64_t sk = qkey & mask;
+        const uint32_t h = scg_hash64(sk);
         uint32_t pos = h & X.slot_mask;
-        const uint2* slots = X.slots + (size_t)s * nslots;
         int e = -1;
-        for (;;) {
-            const uint64_t raw = reinterpret_cast<const uint64_t*>(slots)[pos];   // {tag, head + 1} in one load
-            uint2 sl;
-            sl.x = (uint32_t)raw;
-            sl.y = (uint32_t)(raw >> 32);
-            if (sl.y == 0) break;                 // empty slot: no entry shares this segment
-            if (sl.x == h) {
-                uint4 head = X.entries[sl.y - 1];
-                if (((((uint64_t)head.y << 32) | head.x) & mask) == sk) { e = (int)sl.y - 1; break; }
+        if (s == 0) {
+            // segment 0: the slot holds the chain's head entry itself -> an exact hit is one access
+            for (;;) {
+                const uint4 ent = X.table0[pos];
+                if (ent.w == SCG_SLOT_EMPTY) break;
+                if (((((uint64_t)ent.y << 32) | ent.x) & mask) == sk) {
+                    int d = query_distance(q, ent.x, ent.y, lm);
+                    if (d <= cap && f((int)ent.z, d)) return;
+                    e = (int)ent.w;
+                    break;
+                }
+                pos = (pos + 1) & X.slot_mask;
             }
-            pos = (pos + 1) & X.slot_mask;
-        }
-        const int32_t* next = X.next + (size_t)s * (size_t)X.n_entries;
-        while (e >= 0) {
-            uint4 ent = X.entries[e];
-            int d = query_distance(q, ent.x, ent.y, lm);
-            if (d <= cap && f((int)ent.z, d)) return;
-            e = (s == 0) ? (int)ent.w : next[e];   // segment 0's chain link rides in the entry itself
+            while (e >= 0) {
+                const uint4 ent = X.entries[e];
+                int d = query_distance(q, ent.x, ent.y, lm);
+                if (d <= cap && f((int)ent.z, d)) return;
+                e = (int)ent.w;
+            }
+        } else {
+            const uint2* slots = X.slots + (size_t)s * nslots;
+            for (;;) {
+                const uint64_t raw = reinterpret_cast<const uint64_t*>(slots)[pos];   // {tag, head + 1} in one load
+                const uint32_t tag = (uint32_t)raw, head1 = (uint32_t)(raw >> 32);
+                if (head1 == 0) break;            // empty slot: no entry shares this segment
+                if (tag == h) {
+                    const uint4 head = X.entries[head1 - 1];
+                    if (((((uint64_t)head.y << 32) | head.x) & mask) == sk) { e = (int)head1 - 1; break; }
+                }
+                pos = (pos + 1) & X.slot_mask;
+            }
+            const int32_t* next = X.next + (size_t)s * (size_t)X.n_entries;
+            while (e >= 0) {
+                const uint4 ent = X.entries[e];
+                int d = query_distance(q, ent.x, ent.y, lm);
+                if (d <= cap && f((int)ent.z, d)) return;
+                e = next[e];
+            }
         }
     }
 }

@@ -43,6 +43,7 @@ struct HostIndex {
     std::vector<uint32_t> entries;   // 4 words per entry: key lo, key hi, value, 0
     std::vector<int32_t> next;       // [nseg][n_entries]
     std::vector<uint32_t> slots;     // 2 words per slot: tag, head + 1 ; [nseg][slot_mask + 1]
+    std::vector<uint32_t> table0;    // 4 words per slot: the head entry of segment 0's chain, inline
 };
 
 // max_mm is the plan's mismatch budget for this pool: the index gets max_mm + 1 segments

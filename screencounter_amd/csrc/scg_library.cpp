@@ -263,6 +263,16 @@ void finish_index(HostIndex& X, const std::vector<uint64_t>& keys, const std::ve
         }
         if (sgm == 0) {
             for (size_t e = 0; e < keys.size(); ++e) X.entries[4 * e + 3] = static_cast<uint32_t>(next[e]);
+            // inline table: the slot of a chain holds a copy of its head entry
+            X.table0.assign(static_cast<size_t>(cap) * 4, 0);
+            for (uint32_t pos = 0; pos < cap; ++pos) {
+                uint32_t head = slots[2 * pos + 1];
+                if (head == 0) {
+                    X.table0[4 * pos + 3] = SCG_SLOT_EMPTY;
+                } else {
+                    for (int w = 0; w < 4; ++w) X.table0[4 * pos + w] = X.entries[4 * (head - 1) + w];
+                }
+            }
         }
     }
 }
