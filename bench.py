@@ -118,6 +118,17 @@ def main() -> None:
         avg_kernel_s = kernel_ms / 1e3 / max(launches, 1)
         algo_bytes = n * w.bytes_per_unit   # per launch: sum of read lengths
         achieved = algo_bytes / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
+        # HBM-side bytes per launch from the PMC passes recorded under profiles/ (FETCH_SIZE + WRITE_SIZE,
+        # separate rocprofv3 --pmc runs of this same command, gfx950 correction applied: DESIGN.md section 5)
+        traffic, traffic_source = None, None
+        try:
+            with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+                rec = json.load(f).get(str(args.config))
+            if rec and rec.get("bytes_per_read"):
+                traffic = round(rec["bytes_per_read"] * n)
+                traffic_source = rec["source"]
+        except (OSError, ValueError):
+            pass
         out = {
             "metric": "Mreads/s (whole node) + achieved HBM GB/s, 100M x 150bp vs 100k barcodes <=1mm",
             "value": round(value, 3),
@@ -135,15 +146,15 @@ def main() -> None:
                        "max_mismatches": w.mismatches, "strand": ["forward", "reverse", "both"][w.strand] if w.entry != "dual" else "original/original",
                        "parallelism": f"read-sharded x{world}" + (" + RCCL all-reduce of counts" if world > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                         "kernel": f"{w.entry}_kernel", "avg_kernel_ms": round(avg_kernel_s * 1e3, 4), "launches": launches,
-                         "algorithmic_bytes_per_launch": algo_bytes},
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "kernel": f"{w.entry}_staged_kernel", "avg_kernel_ms": round(avg_kernel_s * 1e3, 4), "launches": launches,
+                         "algorithmic_bytes_per_launch": algo_bytes, "traffic_source": traffic_source},
             "mapped_fraction": round(mapped / (n * world), 5),
         }
 
         sample = args.cpu_sample
         if sample is None:
-            sample = min(n, 10_000_000 if w.entry != "dual" else 5_000_000)
+            sample = min(n, 30_000_000 if w.entry != "dual" else 10_000_000)
         if world == 1 and sample > 0:
             sys.path.insert(0, ROOT)
             from oracle import cpu_baseline
