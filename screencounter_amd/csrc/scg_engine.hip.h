@@ -214,6 +214,28 @@ __device__ __forceinline__ int pair_probe(const ScgPairTable& t, int u1, int u2)
     }
 }
 
+// Up to K distinct neighbours (value, distance) of a query within cap; returns false on overflow.
+template<int K>
+__device__ __forceinline__ bool index_neighbours(const ScgIndex& X, const Query& q, int cap, int val[K], int dist[K], int& n) {
+    n = 0;
+    bool overflow = false;
+    index_search(X, q, cap, [&](int v, int d) -> bool {
+        bool seen = false;
+#pragma unroll
+        for (int i = 0; i < K; ++i) seen |= (i < n && val[i] == v);
+        if (!seen) {
+            if (n == K) { overflow = true; return true; }
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                if (i == n) { val[i] = v; dist[i] = d; }
+            }
+            ++n;
+        }
+        return false;
+    });
+    return !overflow;
+}
+
 // pair_match((q1,q2),(cap1,cap2)): among valid pairs whose two halves are within their own caps,
 // the unique one with the smallest total distance.
 __device__ __forceinline__ void pair_match(const ScgIndex& X1, const ScgIndex& X2, const ScgPairTable& P,
@@ -222,30 +244,52 @@ __device__ __forceinline__ void pair_match(const ScgIndex& X1, const ScgIndex& X
     index = SCG_MISSING; total = 0;
     if (q1.n_other > cap1 || q2.n_other > cap2) return;
     int best = cap1 + cap2 + 1, cur = SCG_MISSING;
+    auto consider = [&](int u1, int d1, int u2, int d2) {
+        int tot = d1 + d2;
+        if (tot > best) return;
+        int v = pair_probe(P, u1, u2);
+        if (v >= 0) {
+            if (tot < best) { best = tot; cur = v; }
+            else if (cur != v) { cur = SCG_AMBIGUOUS; }
+        }
+    };
     if (X1.nseg != 0 && X2.nseg != 0) {
-        index_search(X1, q1, cap1, [&](int u1, int d1) -> bool {
-            index_search(X2, q2, cap2, [&](int u2, int d2) -> bool {
-                int tot = d1 + d2;
-                if (tot > best) return false;
-                int v = pair_probe(P, u1, u2);
-                if (v >= 0) {
-                    if (tot < best) { best = tot; cur = v; }
-                    else if (cur != v) { cur = SCG_AMBIGUOUS; }
+        // The neighbourhoods of the two halves are gathered once each (they hold one or two
+        // sequences in practice) and crossed; only a pathological library overflows the small
+        // arrays, in which case the halves are searched nested.
+        constexpr int K = 4;
+        int v1[K], d1[K], n1, v2[K], d2[K], n2;
+        const bool ok1 = index_neighbours<K>(X1, q1, cap1, v1, d1, n1);
+        if (ok1 && n1 == 0) return;
+        const bool ok2 = index_neighbours<K>(X2, q2, cap2, v2, d2, n2);
+        if (ok2 && n2 == 0) return;
+        if (ok1 && ok2) {
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+#pragma unroll
+                for (int j = 0; j < K; ++j) {
+                    if (i < n1 && j < n2) consider(v1[i], d1[i], v2[j], d2[j]);
                 }
+            }
+        } else {
+            index_search(X1, q1, cap1, [&](int u1, int e1) -> bool {
+                index_search(X2, q2, cap2, [&](int u2, int e2) -> bool {
+                    consider(u1, e1, u2, e2);
+                    return false;
+                });
                 return false;
             });
-            return false;
-        });
+        }
     } else {
         uint32_t lm1 = low_mask(X1.len), lm2 = low_mask(X2.len);
         for (int i = 0; i < P.n_entries; ++i) {
             uint64_t k1 = P.list_key1[i];
-            int d1 = query_distance(q1, (uint32_t)k1, (uint32_t)(k1 >> 32), lm1);
-            if (d1 > cap1) continue;
+            int e1 = query_distance(q1, (uint32_t)k1, (uint32_t)(k1 >> 32), lm1);
+            if (e1 > cap1) continue;
             uint64_t k2 = P.list_key2[i];
-            int d2 = query_distance(q2, (uint32_t)k2, (uint32_t)(k2 >> 32), lm2);
-            if (d2 > cap2) continue;
-            int tot = d1 + d2, v = P.list_vals[i];
+            int e2 = query_distance(q2, (uint32_t)k2, (uint32_t)(k2 >> 32), lm2);
+            if (e2 > cap2) continue;
+            int tot = e1 + e2, v = P.list_vals[i];
             if (tot < best) { best = tot; cur = v; }
             else if (tot == best && cur != v) { cur = SCG_AMBIGUOUS; }
         }

@@ -347,8 +347,8 @@ __global__ __launch_bounds__(STAGE_BLOCK) __attribute__((amdgpu_num_sgpr(80))) v
 }
 
 // One orientation of a staged pair: template 1 on (ta, a), template 2 on (tb, b).
-template<int NW, int NT, bool BEST>
-__device__ __forceinline__ void dual_orientation_staged(const ScgDualParams& P,
+template<int NW, int NT>
+__device__ __forceinline__ void dual_orientation_staged(const ScgDualParams& P, const bool BEST,
                                                         const Tile<NW>& ta, const StagedRead& a,
                                                         const Tile<NW>& tb, const StagedRead& b,
                                                         int& chosen, int& best) {
@@ -395,7 +395,7 @@ __device__ __forceinline__ void dual_orientation_staged(const ScgDualParams& P,
 }
 
 template<int NW, int NT>
-__global__ __launch_bounds__(STAGE_BLOCK) __attribute__((amdgpu_num_sgpr(80))) void dual_staged_kernel(ScgDualParams P, ScgReads R1, ScgReads R2, int64_t n_pairs,
+__global__ __launch_bounds__(STAGE_BLOCK) void dual_staged_kernel(ScgDualParams P, ScgReads R1, ScgReads R2, int64_t n_pairs,
                                                                  int32_t* __restrict__ counts, int32_t* __restrict__ error_flag) {
     __shared__ Tile<NW> tile1;
     __shared__ Tile<NW> tile2;
@@ -417,17 +417,26 @@ __global__ __launch_bounds__(STAGE_BLOCK) __attribute__((amdgpu_num_sgpr(80))) v
         StagedRead sa, sb;
         sa.bit = (int)((int64_t)(a.p - R1.seqs) - span1); sa.n = a.n;
         sb.bit = (int)((int64_t)(b.p - R2.seqs) - span2); sb.n = b.n;
-        int best;
-        if (P.use_first) {
-            dual_orientation_staged<NW, NT, false>(P, tile1, sa, tile2, sb, idx, best);
-            if (idx < 0 && P.randomized) dual_orientation_staged<NW, NT, false>(P, tile2, sb, tile1, sa, idx, best);
-        } else {
-            dual_orientation_staged<NW, NT, true>(P, tile1, sa, tile2, sb, idx, best);
-            if (P.randomized) {
-                int idx2, best2;
-                dual_orientation_staged<NW, NT, true>(P, tile2, sb, tile1, sa, idx2, best2);
-                if (idx < 0 || best > best2) { idx = idx2; best = best2; }
-                else if (best == best2 && idx != idx2) { idx = -1; }
+        // One body for both orientations (template 1 on mate 1 / on mate 2 when randomized) and
+        // both policies: DualBarcodesPairedEnd.hpp:353-381.
+        const bool best_mode = !P.use_first;
+        const int norient = P.randomized ? 2 : 1;
+        int best = 0;
+        idx = -1;
+        for (int o = 0; o < norient; ++o) {
+            const Tile<NW>* ta = o ? &tile2 : &tile1;
+            const Tile<NW>* tb = o ? &tile1 : &tile2;
+            const StagedRead ra = o ? sb : sa, rb = o ? sa : sb;
+            int ci, cb;
+            dual_orientation_staged<NW, NT>(P, best_mode, *ta, ra, *tb, rb, ci, cb);
+            if (!best_mode) {
+                idx = ci;
+                if (ci >= 0) break;                      // :356-360
+            } else if (o == 0) {
+                idx = ci; best = cb;
+            } else {                                     // :363-371
+                if (idx < 0 || best > cb) { idx = ci; best = cb; }
+                else if (best == cb && idx != ci) { idx = -1; }
             }
         }
     }
