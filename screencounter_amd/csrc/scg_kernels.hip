@@ -296,7 +296,7 @@ __device__ __forceinline__ bool combo_candidate_staged(const ScgComboParams& P, 
     return true;
 }
 
-template<int NW, int NT>
+template<int NW, int NT, int NC>
 __global__ __launch_bounds__(STAGE_BLOCK) __attribute__((amdgpu_num_sgpr(80))) void combo_staged_kernel(ScgComboParams P, ScgReads R, int64_t n_reads,
                                                                   int32_t* __restrict__ cells, int32_t* __restrict__ error_flag) {
     __shared__ Tile<NW> tile;
@@ -318,15 +318,15 @@ __global__ __launch_bounds__(STAGE_BLOCK) __attribute__((amdgpu_num_sgpr(80))) v
         StagedRead sr;
         sr.bit = (int)((int64_t)(rd.p - R.seqs) - span0);
         sr.n = rd.n;
-        uint32_t candF[NW], candR[NW];
-        scan_read<NW>(tile, sr, T, P.fwd != 0, P.rev != 0, candF, candR);
+        uint32_t candF[NC], candR[NC];
+        scan_read<NW, NC>(tile, sr, T, P.fwd != 0, P.rev != 0, candF, candR);
         for (;;) {
-            int pf = first_bit<NW>(candF), pr = first_bit<NW>(candR);
+            int pf = first_bit<NC>(candF), pr = first_bit<NC>(candR);
             bool rev = pr < pf;
             int p = rev ? pr : pf;
             if (p >= (1 << 30)) break;
-            clear_bit<NW>(candF, rev ? -1 : p);
-            clear_bit<NW>(candR, rev ? p : -1);
+            clear_bit<NC>(candF, rev ? -1 : p);
+            clear_bit<NC>(candR, rev ? p : -1);
             int c = window_mismatches<NW, NT>(tile, sr.bit + p, T, rev);
             if (c > P.max_mm) continue;
             int cand[SCG_MAX_REGIONS], tot;
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(STAGE_BLOCK) __attribute__((amdgpu_num_sgpr(80))) v
 }
 
 // One orientation of a staged pair: template 1 on (ta, a), template 2 on (tb, b).
-template<int NW, int NT>
+template<int NW, int NT, int NC>
 __device__ __forceinline__ void dual_orientation_staged(const ScgDualParams& P, const bool BEST,
                                                         const Tile<NW>& ta, const StagedRead& a,
                                                         const Tile<NW>& tb, const StagedRead& b,
@@ -359,26 +359,26 @@ __device__ __forceinline__ void dual_orientation_staged(const ScgDualParams& P, 
     const int s2 = rev2 ? T2.rstart[0] : T2.fstart[0];
     chosen = -1;
     best = P.max_mm1 + P.max_mm2 + 1;
-    uint32_t c1[NW], c2[NW], unused[NW];
-    if (rev1) scan_read<NW>(ta, a, T1, false, true, unused, c1); else scan_read<NW>(ta, a, T1, true, false, c1, unused);
-    if (rev2) scan_read<NW>(tb, b, T2, false, true, unused, c2); else scan_read<NW>(tb, b, T2, true, false, c2, unused);
+    uint32_t c1[NC], c2[NC], unused[NC];
+    if (rev1) scan_read<NW, NC>(ta, a, T1, false, true, unused, c1); else scan_read<NW, NC>(ta, a, T1, true, false, c1, unused);
+    if (rev2) scan_read<NW, NC>(tb, b, T2, false, true, unused, c2); else scan_read<NW, NC>(tb, b, T2, true, false, c2, unused);
     for (;;) {
-        int p1 = first_bit<NW>(c1);
+        int p1 = first_bit<NC>(c1);
         if (p1 >= (1 << 30)) break;
-        clear_bit<NW>(c1, p1);
+        clear_bit<NC>(c1, p1);
         int m1 = window_mismatches<NW, NT>(ta, a.bit + p1, T1, rev1);
         if (m1 > P.max_mm1) continue;
         Query q1 = region_query<NW>(ta, a.bit + p1 + s1, P.index1.len, rev1);
-        uint32_t w2[NW];
+        uint32_t w2[NC];
 #pragma unroll
-        for (int i = 0; i < NW; ++i) w2[i] = c2[i];
+        for (int i = 0; i < NC; ++i) w2[i] = c2[i];
         for (;;) {
-            int p2 = first_bit<NW>(w2);
+            int p2 = first_bit<NC>(w2);
             if (p2 >= (1 << 30)) break;
-            clear_bit<NW>(w2, p2);
+            clear_bit<NC>(w2, p2);
             int m2 = window_mismatches<NW, NT>(tb, b.bit + p2, T2, rev2);
             if (m2 > P.max_mm2) {
-                clear_bit<NW>(c2, p2);      // never a hit of mate 2: drop it for later outer iterations
+                clear_bit<NC>(c2, p2);      // never a hit of mate 2: drop it for later outer iterations
                 continue;
             }
             Query q2 = region_query<NW>(tb, b.bit + p2 + s2, P.index2.len, rev2);
@@ -394,7 +394,7 @@ __device__ __forceinline__ void dual_orientation_staged(const ScgDualParams& P, 
     }
 }
 
-template<int NW, int NT>
+template<int NW, int NT, int NC>
 __global__ __launch_bounds__(STAGE_BLOCK) void dual_staged_kernel(ScgDualParams P, ScgReads R1, ScgReads R2, int64_t n_pairs,
                                                                  int32_t* __restrict__ counts, int32_t* __restrict__ error_flag) {
     __shared__ Tile<NW> tile1;
@@ -428,7 +428,7 @@ __global__ __launch_bounds__(STAGE_BLOCK) void dual_staged_kernel(ScgDualParams 
             const Tile<NW>* tb = o ? &tile1 : &tile2;
             const StagedRead ra = o ? sb : sa, rb = o ? sa : sb;
             int ci, cb;
-            dual_orientation_staged<NW, NT>(P, best_mode, *ta, ra, *tb, rb, ci, cb);
+            dual_orientation_staged<NW, NT, NC>(P, best_mode, *ta, ra, *tb, rb, ci, cb);
             if (!best_mode) {
                 idx = ci;
                 if (ci >= 0) break;                      // :356-360
@@ -567,13 +567,23 @@ template<int NW, int NT> struct LaunchSingle {
 };
 template<int NW, int NT> struct LaunchCombo {
     static hipError_t go(const ScgComboParams& P, const ScgReads& R, int64_t n, int32_t* cells, int32_t* flag, hipStream_t stream) {
-        hipLaunchKernelGGL((combo_staged_kernel<NW, NT>), dim3(grid_for(n)), dim3(STAGE_BLOCK), 0, stream, P, R, n, cells, flag);
+        if (NW == 5 && P.scan.compact_ok && R.max_len - P.scan.len + 1 <= 96) {
+            hipLaunchKernelGGL((combo_staged_kernel<NW, NT, (NW == 5 ? 3 : NW)>), dim3(grid_for(n)), dim3(STAGE_BLOCK), 0, stream, P, R, n, cells, flag);
+        } else {
+            hipLaunchKernelGGL((combo_staged_kernel<NW, NT, NW>), dim3(grid_for(n)), dim3(STAGE_BLOCK), 0, stream, P, R, n, cells, flag);
+        }
         return hipGetLastError();
     }
 };
 template<int NW, int NT> struct LaunchDual {
     static hipError_t go(const ScgDualParams& P, const ScgReads& R1, const ScgReads& R2, int64_t n, int32_t* counts, int32_t* flag, hipStream_t stream) {
-        hipLaunchKernelGGL((dual_staged_kernel<NW, NT>), dim3(grid_for(n)), dim3(STAGE_BLOCK), 0, stream, P, R1, R2, n, counts, flag);
+        const int max_len = R1.max_len > R2.max_len ? R1.max_len : R2.max_len;
+        const int min_t = P.scan1.len < P.scan2.len ? P.scan1.len : P.scan2.len;
+        if (NW == 5 && P.scan1.compact_ok && P.scan2.compact_ok && max_len - min_t + 1 <= 96) {
+            hipLaunchKernelGGL((dual_staged_kernel<NW, NT, (NW == 5 ? 3 : NW)>), dim3(grid_for(n)), dim3(STAGE_BLOCK), 0, stream, P, R1, R2, n, counts, flag);
+        } else {
+            hipLaunchKernelGGL((dual_staged_kernel<NW, NT, NW>), dim3(grid_for(n)), dim3(STAGE_BLOCK), 0, stream, P, R1, R2, n, counts, flag);
+        }
         return hipGetLastError();
     }
 };
