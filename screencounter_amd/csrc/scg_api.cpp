@@ -432,6 +432,40 @@ struct Stager {
 const int64_t BATCH_READS = int64_t(1) << 22;
 const int64_t BATCH_BYTES = int64_t(1) << 30;
 
+// FASTQ file -> counters for single-end plans.  Plain 4-line FASTQ is parsed by several host
+// threads (ParallelFastq); gzip input, and any file the parallel reader finds unusual, goes
+// through the sequential reader, which reproduces the reference's parse and errors exactly.
+void count_single_end_file(scg_plan* P, const char* path, scg::FastqStream& fq, int nthreads) {
+    Stager st;
+    const int threads = scg::default_host_threads(nthreads);
+    if (threads > 1 && scg::ParallelFastq::is_plain_file(path)) {
+        scg::ParallelFastq pf(path, threads);
+        std::vector<scg::ReadBatch> window;
+        while (pf.next_window(window)) {
+            for (auto& b : window) {
+                if (b.size() == 0) continue;
+                auto& s = st.acquire();
+                ScgReads R = st.stage(s, 0, b);
+                launch_batch(P, R, b.size(), s.stream);
+                s.busy = true;
+            }
+        }
+        st.drain();
+        if (!pf.unusual()) return;
+        // start over with the reference-exact sequential reader
+        HIP_CHECK(hipMemset(P->counters, 0, static_cast<size_t>(P->n_counters) * sizeof(int32_t)));
+        P->total = 0;
+    }
+    scg::ReadBatch b;
+    while (fq.next_batch(b, BATCH_READS, BATCH_BYTES)) {
+        auto& s = st.acquire();
+        ScgReads R = st.stage(s, 0, b);
+        launch_batch(P, R, b.size(), s.stream);
+        s.busy = true;
+    }
+    st.drain();
+}
+
 void read_counters(scg_plan* P, int32_t* counts_out) {
     int32_t flag = 0;
     HIP_CHECK(hipMemcpy(&flag, P->error_flag.p, sizeof(flag), hipMemcpyDeviceToHost));
@@ -485,7 +519,22 @@ int scg_parse_fastq(const char* path, char** seqs_out, uint64_t** offsets_out, i
         scg::FastqStream fq(path);
         scg::ReadBatch all, b;
         all.clear();
-        while (fq.next_batch(b, BATCH_READS, BATCH_BYTES)) {
+        bool done = false;
+        const int threads = scg::default_host_threads(1);
+        if (threads > 1 && scg::ParallelFastq::is_plain_file(path)) {
+            scg::ParallelFastq pf(path, threads);
+            std::vector<scg::ReadBatch> window;
+            while (pf.next_window(window)) {
+                for (auto& w : window) {
+                    uint64_t base = all.seqs.size();
+                    all.seqs.insert(all.seqs.end(), w.seqs.begin(), w.seqs.end());
+                    for (int64_t i = 1; i <= w.size(); ++i) all.offsets.push_back(base + w.offsets[i]);
+                }
+            }
+            done = !pf.unusual();
+            if (!done) all.clear();
+        }
+        while (!done && fq.next_batch(b, BATCH_READS, BATCH_BYTES)) {
             uint64_t base = all.seqs.size();
             all.seqs.insert(all.seqs.end(), b.seqs.begin(), b.seqs.end());
             for (int64_t i = 1; i <= b.size(); ++i) all.offsets.push_back(base + b.offsets[i]);
@@ -631,22 +680,13 @@ int scg_plan_kernel_stats(scg_plan* plan, double* total_ms_out, int64_t* launche
 int scg_count_single_barcodes(const char* path, const char* constant, int strand, const char* const* pool, int32_t n_pool,
                               int mismatches, int use_first, int nthreads, int32_t* counts_out, int32_t* total_out,
                               char* err, size_t errcap) {
-    (void)nthreads;
     return guarded(err, errcap, [&] {
         if (!path || !counts_out || !total_out) throw Error(SCG_ERR_INVALID, "null argument");
         scg::FastqStream fq(path);                                           // src/count_single_barcodes.cpp:30
         auto P = compile_single(constant, strand, pool, n_pool, mismatches, use_first);   // :31-47
         P->to_device(-1);
         DeviceGuard g(P->device);
-        Stager st;
-        scg::ReadBatch b;
-        while (fq.next_batch(b, BATCH_READS, BATCH_BYTES)) {
-            auto& s = st.acquire();
-            ScgReads R = st.stage(s, 0, b);
-            launch_batch(P.get(), R, b.size(), s.stream);
-            s.busy = true;
-        }
-        st.drain();
+        count_single_end_file(P.get(), path, fq, nthreads);
         read_counters(P.get(), counts_out);
         *total_out = static_cast<int32_t>(P->total);
     });
@@ -657,22 +697,13 @@ int scg_count_combo_barcodes_single(const char* path, const char* constant, int 
                                     int mismatches, int use_first, int nthreads,
                                     int32_t** indices_out, int32_t** freq_out, int64_t* k_out, int32_t* total_out,
                                     char* err, size_t errcap) {
-    (void)nthreads;
     return guarded(err, errcap, [&] {
         if (!path || !indices_out || !freq_out || !k_out || !total_out) throw Error(SCG_ERR_INVALID, "null argument");
         scg::FastqStream fq(path);
         auto P = compile_combo(constant, strand, pool0, n_pool0, pool1, n_pool1, mismatches, use_first);
         P->to_device(-1);
         DeviceGuard g(P->device);
-        Stager st;
-        scg::ReadBatch b;
-        while (fq.next_batch(b, BATCH_READS, BATCH_BYTES)) {
-            auto& s = st.acquire();
-            ScgReads R = st.stage(s, 0, b);
-            launch_batch(P.get(), R, b.size(), s.stream);
-            s.busy = true;
-        }
-        st.drain();
+        count_single_end_file(P.get(), path, fq, nthreads);
         std::vector<int32_t> cells(static_cast<size_t>(P->n_counters) + 1);
         read_counters(P.get(), cells.data());
         combo_compact(cells.data(), n_pool0, n_pool1, indices_out, freq_out, k_out);

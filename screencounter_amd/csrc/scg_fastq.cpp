@@ -16,8 +16,12 @@
 
 #include <cctype>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <thread>
 #include <unistd.h>
 #include <zlib.h>
 
@@ -180,6 +184,183 @@ bool FastqStream::next_batch(ReadBatch& out, int64_t max_reads, int64_t max_byte
         out.offsets.push_back(out.seqs.size());
     }
     return out.size() > 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// ParallelFastq
+// ---------------------------------------------------------------------------------------------
+int default_host_threads(int requested) {
+    // R's num.threads defaults to 1 and is advisory; the stager sizes itself from the machine
+    // unless SCG_HOST_THREADS says otherwise.
+    const char* env = std::getenv("SCG_HOST_THREADS");
+    if (env && *env) {
+        int v = std::atoi(env);
+        if (v >= 1) return v;
+    }
+    unsigned hw = std::thread::hardware_concurrency();
+    int n = hw ? static_cast<int>(hw) : 1;
+    if (n > 16) n = 16;
+    if (requested > n) n = requested > 64 ? 64 : requested;
+    return n < 1 ? 1 : n;
+}
+
+struct ParallelFastq::Impl {
+    int fd = -1;
+    const char* data = nullptr;
+    size_t size = 0;
+    size_t pos = 0;          // verified record start (or EOF)
+    int nthreads = 1;
+    bool odd = false;
+    size_t window = 0;
+
+    // If a strict 4-line record starts at p, returns the offset just past it (== size for a final
+    // record without trailing newline); otherwise 0.
+    size_t record_end(size_t p, const char** seq_out = nullptr, size_t* seq_len_out = nullptr) const {
+        if (p >= size || data[p] != '@') return 0;
+        const char* e = data + size;
+        const char* l1 = static_cast<const char*>(std::memchr(data + p, '\n', size - p));
+        if (!l1) return 0;
+        const char* s0 = l1 + 1;
+        const char* l2 = s0 < e ? static_cast<const char*>(std::memchr(s0, '\n', e - s0)) : nullptr;
+        if (!l2) return 0;
+        if (std::memchr(s0, '+', l2 - s0)) return 0;            // '+' would end the sequence early
+        const char* p0 = l2 + 1;
+        if (p0 >= e || *p0 != '+') return 0;
+        const char* l3 = static_cast<const char*>(std::memchr(p0, '\n', e - p0));
+        if (!l3) return 0;
+        const char* q0 = l3 + 1;
+        size_t seq_len = static_cast<size_t>(l2 - s0);
+        const char* l4 = q0 < e ? static_cast<const char*>(std::memchr(q0, '\n', e - q0)) : nullptr;
+        size_t qual_len = l4 ? static_cast<size_t>(l4 - q0) : static_cast<size_t>(e - q0);
+        if (qual_len != seq_len) return 0;
+        if (seq_len == 0 && !l4) return 0;                      // leave EOF corner cases to the sequential parser
+        if (seq_out) { *seq_out = s0; *seq_len_out = seq_len; }
+        return l4 ? static_cast<size_t>(l4 + 1 - data) : size;
+    }
+
+    // First position >= from that starts two consecutive strict records (or one ending at EOF).
+    size_t find_start(size_t from, size_t limit) const {
+        size_t p = from;
+        if (p > 0 && data[p - 1] != '\n') {
+            const char* nl = static_cast<const char*>(std::memchr(data + p, '\n', size - p));
+            if (!nl) return size;
+            p = static_cast<size_t>(nl + 1 - data);
+        }
+        while (p < limit) {
+            size_t e1 = record_end(p);
+            if (e1 && (e1 == size || record_end(e1))) return p;
+            const char* nl = static_cast<const char*>(std::memchr(data + p, '\n', size - p));
+            if (!nl) return size;
+            p = static_cast<size_t>(nl + 1 - data);
+        }
+        return p < size ? p : size;
+    }
+};
+
+bool ParallelFastq::is_plain_file(const char* path) {
+    struct stat st;
+    if (::stat(path, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size < 4) return false;
+    unsigned char h[2] = {0, 0};
+    FILE* f = std::fopen(path, "rb");
+    if (!f) return false;
+    size_t got = std::fread(h, 1, 2, f);
+    std::fclose(f);
+    return !(got == 2 && h[0] == 0x1f && h[1] == 0x8b);
+}
+
+ParallelFastq::ParallelFastq(const char* path, int nthreads) : impl(new Impl) {
+    impl->fd = ::open(path, O_RDONLY);
+    if (impl->fd < 0) { delete impl; throw Error(SCG_ERR_IO, std::string("failed to open file at '") + path + "'"); }
+    struct stat st;
+    if (::fstat(impl->fd, &st) != 0) { ::close(impl->fd); delete impl; throw Error(SCG_ERR_IO, "failed to stat the FASTQ file"); }
+    impl->size = static_cast<size_t>(st.st_size);
+    if (impl->size) {
+        void* m = ::mmap(nullptr, impl->size, PROT_READ, MAP_PRIVATE, impl->fd, 0);
+        if (m == MAP_FAILED) { ::close(impl->fd); delete impl; throw Error(SCG_ERR_IO, "failed to map the FASTQ file"); }
+        ::madvise(m, impl->size, MADV_SEQUENTIAL);
+        impl->data = static_cast<const char*>(m);
+    }
+    impl->nthreads = nthreads < 1 ? 1 : nthreads;
+    size_t piece = size_t(32) << 20;
+    if (const char* env = std::getenv("SCG_FASTQ_PIECE_KB")) {      // test hook: tiny pieces force many hand-overs
+        long kb = std::atol(env);
+        if (kb > 0) piece = static_cast<size_t>(kb) << 10;
+    }
+    impl->window = static_cast<size_t>(impl->nthreads) * piece;
+    // the file must open with a strict record for this reader to apply at all
+    if (impl->size && !impl->record_end(0)) impl->odd = true;
+}
+
+ParallelFastq::~ParallelFastq() {
+    if (impl->data) ::munmap(const_cast<char*>(impl->data), impl->size);
+    if (impl->fd >= 0) ::close(impl->fd);
+    delete impl;
+}
+
+bool ParallelFastq::unusual() const { return impl->odd; }
+
+bool ParallelFastq::next_window(std::vector<ReadBatch>& out) {
+    Impl& I = *impl;
+    out.assign(static_cast<size_t>(I.nthreads), ReadBatch());
+    for (auto& b : out) b.clear();
+    if (I.odd || I.pos >= I.size) return false;
+    const size_t a = I.pos;
+    const size_t b = std::min(I.size, a + I.window);
+    const int T = I.nthreads;
+    const size_t piece = (b - a + T - 1) / T;
+    // tentative starts: worker 0 at the verified boundary, the others wherever two records line up
+    std::vector<size_t> start(T + 1);
+    start[0] = a;
+    for (int k = 1; k < T; ++k) start[k] = 0;
+    std::vector<size_t> landed(T, 0);
+    std::vector<char> bad(T, 0);
+    auto work = [&](int k) {
+        size_t lo = (k == 0) ? a : I.find_start(std::min(b, a + k * piece), b);
+        start[k] = lo;
+        // parse until the next worker's nominal piece begins (exact hand-over is checked afterwards)
+        const size_t nominal_end = (k == T - 1) ? b : std::min(b, a + (k + 1) * piece);
+        ReadBatch& rb = out[k];
+        size_t p = lo;
+        while (p < I.size && p < nominal_end) {
+            const char* sq = nullptr;
+            size_t sl = 0;
+            size_t e = I.record_end(p, &sq, &sl);
+            if (!e) break;
+            if (k == T - 1 && e > b && b < I.size) break;       // record crosses the window: next window
+            rb.seqs.insert(rb.seqs.end(), sq, sq + sl);         // sequence = line 2
+            rb.offsets.push_back(rb.seqs.size());
+            p = e;
+        }
+        landed[k] = p;
+        // stopping early inside the piece (other than at EOF) means a record failed the strict test
+        if (p < nominal_end && p < I.size && !(k == T - 1)) bad[k] = 1;
+        if (k == T - 1 && p < nominal_end && p < I.size) {
+            // the last worker may stop before b only because the next record crosses the window
+            size_t e = I.record_end(p);
+            if (!e || e <= b) bad[k] = 1;
+        }
+    };
+    std::vector<std::thread> th;
+    for (int k = 1; k < T; ++k) th.emplace_back(work, k);
+    work(0);
+    for (auto& t : th) t.join();
+    // hand-over check: worker k must land exactly where worker k+1 started
+    for (int k = 0; k < T; ++k) {
+        if (bad[k]) { I.odd = true; break; }
+        if (k + 1 < T && landed[k] != start[k + 1]) { I.odd = true; break; }
+    }
+    if (I.odd) {
+        for (auto& rb : out) rb.clear();
+        return false;
+    }
+    if (landed[T - 1] == a) {
+        // no progress: a single record larger than the window, or an unparseable tail
+        I.odd = true;
+        for (auto& rb : out) rb.clear();
+        return false;
+    }
+    I.pos = landed[T - 1];
+    return true;
 }
 
 } // namespace scg

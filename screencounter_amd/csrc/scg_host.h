@@ -100,6 +100,41 @@ private:
     Impl* impl;
 };
 
+// ---------------------------------------------------------------------------------------------
+// Parallel staging of plain (uncompressed) FASTQ files made of ordinary 4-line records.
+//
+// The file is mapped and cut into windows; inside a window every worker thread starts at a
+// position that *looks like* a record start and parses strict 4-line records up to the next
+// worker's start.  A worker's start is only trusted once its predecessor has landed on it exactly,
+// and the first worker starts on a verified boundary, so by induction the result equals the
+// sequential reference parse (kaori/FastqReader.hpp:42-110) whenever every record satisfies:
+// '@' first, no '+' inside the sequence line, '+' line third, quality as long as the sequence.
+// Anything else (multi-line records, malformed input, a missed landing) makes `unusual()` return
+// true, and the caller redoes the file with the sequential FastqStream, which reproduces the
+// reference's behaviour and error messages exactly.
+// ---------------------------------------------------------------------------------------------
+class ParallelFastq {
+public:
+    // Throws Error(SCG_ERR_IO) if the file cannot be opened / mapped.
+    ParallelFastq(const char* path, int nthreads);
+    ~ParallelFastq();
+    ParallelFastq(const ParallelFastq&) = delete;
+    ParallelFastq& operator=(const ParallelFastq&) = delete;
+
+    static bool is_plain_file(const char* path);   // exists, regular, not gzip
+
+    // Parses the next window into one batch per worker (empty batches possible).
+    // Returns false when the file is exhausted or the input turned out to be unusual.
+    bool next_window(std::vector<ReadBatch>& out);
+    bool unusual() const;
+
+private:
+    struct Impl;
+    Impl* impl;
+};
+
+int default_host_threads(int requested);
+
 } // namespace scg
 
 #endif

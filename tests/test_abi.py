@@ -179,3 +179,42 @@ def test_r_level_helpers(sc):
     combos, mat = sc.combineComboCounts(a, b)
     assert combos == {"first": [1, 2, 3], "second": [1, 1, 2]}
     assert mat.tolist() == [[3, 0], [4, 5], [0, 6]]
+
+
+@pytest.mark.parametrize("piece_kb", [1, 7, 64])
+def test_parallel_fastq_reader_equals_sequential(sc, oracle, tmp_path, monkeypatch, piece_kb):
+    """Plain 4-line FASTQ through the multi-threaded reader (tiny pieces => thousands of hand-overs
+    between workers) equals the sequential parse; unusual files fall back and still agree."""
+    rng = np.random.default_rng(11)
+    letters = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    recs = []
+    for i in range(30000):
+        n = int(rng.integers(0, 200))
+        s = letters[rng.integers(0, 5, n)].tobytes()
+        q = bytes(rng.integers(33, 75, n, dtype=np.uint8))       # qualities full of '@' and '+'
+        recs.append(b"@r%d\n" % i + s + b"\n+\n" + q + b"\n")
+    strict = tmp_path / "strict.fastq"
+    strict.write_bytes(b"".join(recs))
+    nofinal = tmp_path / "nofinal.fastq"
+    nofinal.write_bytes(b"".join(recs)[:-1])
+    multi = tmp_path / "multi.fastq"
+    odd = list(recs)
+    odd[17000] = b"@multi\nACGT\nACGT\n+\nIIII\nIIII\n"           # one multi-line record deep inside
+    multi.write_bytes(b"".join(odd))
+    broken = tmp_path / "broken.fastq"
+    bad = list(recs)
+    bad[23000] = b"@short\nACGT\n+\nII\n"
+    broken.write_bytes(b"".join(bad))
+
+    monkeypatch.setenv("SCG_HOST_THREADS", "5")
+    monkeypatch.setenv("SCG_FASTQ_PIECE_KB", str(piece_kb))
+    for path in (strict, nofinal, multi):
+        s1, o1 = sc.parse_fastq(str(path))
+        s2, o2 = oracle.parse_fastq(str(path))
+        assert np.array_equal(o1, o2) and np.array_equal(s1, s2), path.name
+    from oracle.pyoracle import OracleError
+    with pytest.raises(OracleError) as e_ref:
+        oracle.parse_fastq(str(broken))
+    with pytest.raises(sc.ScgError) as e_got:
+        sc.parse_fastq(str(broken))
+    assert str(e_got.value) == str(e_ref.value)
