@@ -154,7 +154,7 @@ def main() -> None:
 
         sample = args.cpu_sample
         if sample is None:
-            sample = min(n, 30_000_000 if w.entry != "dual" else 10_000_000)
+            sample = min(n, 50_000_000 if w.entry != "dual" else 20_000_000)
         if world == 1 and sample > 0:
             sys.path.insert(0, ROOT)
             from oracle import cpu_baseline
