@@ -142,6 +142,26 @@ def fuzz_dual(rng, ora, ref, tmpdir, it, hazard_free=True):
     return "ok"
 
 
+def fuzz_dual_diag(rng, ora, ref, tmpdir, it):
+    from tests import gen
+    c = gen.random_dual_case(rng, hazard_free=True, max_mm=2)
+    # the diagnostics path searches each pool on its own with DuplicateAction::FIRST: feed it
+    # pools with repeated barcodes (pairs stay unique) every now and then -- that is what
+    # random_dual_case produces whenever a barcode takes part in several pairs.
+    fq1 = os.path.join(tmpdir, f"g{it}_1.fastq")
+    fq2 = os.path.join(tmpdir, f"g{it}_2.fastq")
+    write_fastq(fq1, c["reads1"])
+    write_fastq(fq2, c["reads2"])
+    exp = ref.count_dual_diag(fq1, c["template1"], c["reverse1"], c["mismatches1"], c["pool1"],
+                              fq2, c["template2"], c["reverse2"], c["mismatches2"], c["pool2"], c["randomized"], c["use_first"], 1)
+    got = ora.count_dual_diag(c["reads1"], c["reads2"], c["template1"], c["reverse1"], c["mismatches1"], c["pool1"],
+                              c["template2"], c["reverse2"], c["mismatches2"], c["pool2"], c["randomized"], c["use_first"])
+    for key in exp:
+        if not np.array_equal(np.asarray(exp[key]), np.asarray(got[key])):
+            raise AssertionError(f"dual-diag mismatch in {key}: {c}\nexp={exp}\ngot={got}")
+    return "ok"
+
+
 def fuzz_match(rng, ora, ref):
     vlen = rng.choice([3, 5, 8, 12])
     alphabet = rng.choice(["AC", BASES])
@@ -180,6 +200,7 @@ def main():
                              ("combo", lambda: fuzz_combo(rng, ora, ref, tmp, it)),
                              ("dual", lambda: fuzz_dual(rng, ora, ref, tmp, it, True)),
                              ("dual-hazard", lambda: fuzz_dual(rng, ora, ref, tmp, it, False)),
+                             ("dual-diag", lambda: fuzz_dual_diag(rng, ora, ref, tmp, it)),
                              ("match", lambda: fuzz_match(rng, ora, ref))):
                 res = fn()
                 tally[f"{name}:{res}"] = tally.get(f"{name}:{res}", 0) + 1

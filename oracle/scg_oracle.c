@@ -251,7 +251,11 @@ static int check_duplicates(const int8_t *sets, int n, int len, errbuf *e) {
 }
 
 /* Build from per-position sets (already strand-adjusted). */
+static int lib_from_sets_opt(lib_t *L, const int8_t *sets, int n, int len, int check_dups, errbuf *e);
 static int lib_from_sets(lib_t *L, const int8_t *sets, int n, int len, errbuf *e) {
+    return lib_from_sets_opt(L, sets, n, len, 1, e);
+}
+static int lib_from_sets_opt(lib_t *L, const int8_t *sets, int n, int len, int check_dups, errbuf *e) {
     L->n = n; L->len = len; L->words = (len + 63) / 64; if (L->words == 0) L->words = 1;
     L->planes = (uint64_t *)calloc((size_t)n * 4 * L->words + 1, sizeof(uint64_t));
     if (!L->planes) return fail(e, "oracle: out of memory");
@@ -263,7 +267,7 @@ static int lib_from_sets(lib_t *L, const int8_t *sets, int n, int len, errbuf *e
             }
         }
     }
-    return check_duplicates(sets, n, len, e);
+    return check_dups ? check_duplicates(sets, n, len, e) : 0;
 }
 
 /* Convert a pool of NUL-terminated strings into per-position sets; all must share one length
@@ -332,7 +336,15 @@ static int entry_distance(const lib_t *L, int i, const uint64_t *qp, int from, i
 /* match(q, cap): unique nearest entry within Hamming distance cap.
  * MismatchTrie.hpp:446-501 (AnyMismatches::search), :266-343 (tie => STATUS_AMBIGUOUS),
  * BarcodeSearch.hpp:243-251.  Caches there are semantics-neutral. */
+static void lib_match_policy(const lib_t *L, const char *q, int cap, int keep_first, int *index, int *mm);
 static void lib_match(const lib_t *L, const char *q, int cap, int *index, int *mm) {
+    lib_match_policy(L, q, cap, 0, index, mm);
+}
+
+/* keep_first != 0 restates DuplicateAction::FIRST (MismatchTrie.hpp:109-110, :273-276, :311-314): among
+ * the entries at the minimum distance the smallest index wins instead of the match being ambiguous
+ * (used by the include.invalid=TRUE path, DualBarcodesPairedEndWithDiagnostics.hpp:68). */
+static void lib_match_policy(const lib_t *L, const char *q, int cap, int keep_first, int *index, int *mm) {
     uint64_t qp[4 * 4];
     uint64_t *qpp = qp, *heap = NULL;
     if (L->words > 4) { heap = (uint64_t *)malloc(sizeof(uint64_t) * 4 * L->words); qpp = heap; }
@@ -341,7 +353,7 @@ static void lib_match(const lib_t *L, const char *q, int cap, int *index, int *m
     for (int i = 0; i < L->n; ++i) {
         int d = entry_distance(L, i, qpp, 0, L->len);
         if (d < best) { best = d; idx = i; }
-        else if (d == best && d <= cap) { idx = SCGO_AMBIG; }
+        else if (d == best && d <= cap && !keep_first) { idx = SCGO_AMBIG; }
     }
     free(heap);
     *index = idx; *mm = best;
@@ -714,6 +726,162 @@ int scgo_count_dual(const char *seqs1, const uint64_t *offs1, const char *seqs2,
     *total = tot;
     free(h1); free(h2); free(comb);
     lib_free(&D.L);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * countDualBarcodes(include.invalid=TRUE): handlers/DualBarcodesPairedEndWithDiagnostics.hpp:115-120
+ * = the dual search above, and for pairs it rejects, CombinatorialBarcodesPairedEnd::process
+ * (handlers/CombinatorialBarcodesPairedEnd.hpp:167-242): each mate searched on its own with
+ * SimpleSingleMatch (DuplicateAction::FIRST), tallying invalid pairs, barcode1-only, barcode2-only.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct { int found, index, mm; } smatch_t;
+
+/* SimpleSingleMatch::search_first / search_best for one template on one strand set. */
+static smatch_t single_search(const tmpl_t *T, const lib_t *F, const lib_t *R, const char *read, int n,
+                              int max_mm, int use_first, int keep_first) {
+    smatch_t out = {0, -1, 0};
+    int best = max_mm + 1;
+    for (int p = 0; p + T->len <= n; ++p) {
+        for (int s = 0; s < 2; ++s) {
+            if (s == 0 ? !T->fwd : !T->rev) continue;
+            int c = const_mm(T, read, p, s);
+            if (c > max_mm) continue;
+            const char *q = read + p + (s ? T->rstart[0] : T->fstart[0]);
+            int idx, d;
+            lib_match_policy(s ? R : F, q, max_mm - c, keep_first, &idx, &d);
+            if (idx < 0) continue;
+            int tmm = c + d;
+            if (use_first) {
+                out.found = 1; out.index = idx; out.mm = tmm;
+                return out;
+            }
+            if (tmm == best) {
+                if (out.index != idx) { out.found = 0; out.index = -1; }
+            } else if (tmm < best) {
+                out.found = 1; best = tmm; out.index = idx; out.mm = tmm;
+            }
+        }
+    }
+    return out;
+}
+
+int scgo_count_dual_diag(const char *seqs1, const uint64_t *offs1, const char *seqs2, const uint64_t *offs2, int64_t n_pairs,
+                         const char *tmpl1, int tmpl_len1, int reverse1, int mm1, const char *const *pool1,
+                         const char *tmpl2, int tmpl_len2, int reverse2, int mm2, const char *const *pool2,
+                         int n_pool, int randomized, int use_first,
+                         int32_t *counts /* n_pool */, int32_t *tuples /* capacity 2*n_pairs */, int64_t *n_tuples,
+                         int32_t *total, int32_t *barcode1_only, int32_t *barcode2_only,
+                         char *err, size_t errcap) {
+    errbuf e = {err, errcap};
+    /* the valid-pair search, exactly as scgo_count_dual builds it */
+    dual_t D;
+    memset(&D, 0, sizeof(D));
+    int8_t *s1 = NULL, *s2 = NULL;
+    if (pool_to_sets(pool1, n_pool, reverse1, &s1, &D.len1, &e)) return 1;
+    if (pool_to_sets(pool2, n_pool, reverse2, &s2, &D.len2, &e)) { free(s1); return 1; }
+    int rc = 0;
+    if (!rc) rc = tmpl_init(&D.T1, tmpl1, tmpl_len1, reverse1 ? 1 : 0, &e);
+    if (!rc) rc = tmpl_init(&D.T2, tmpl2, tmpl_len2, reverse2 ? 1 : 0, &e);
+    if (!rc && D.T1.nreg != 1) rc = fail(&e, "expected one variable region in the first constant template");
+    if (!rc && D.T1.fend[0] - D.T1.fstart[0] != D.len1)
+        rc = fail(&e, "length of variable sequences (%d) should be the same as the variable region (%d)", D.len1, D.T1.fend[0] - D.T1.fstart[0]);
+    if (!rc && D.T2.nreg != 1) rc = fail(&e, "expected one variable region in the second constant template");
+    if (!rc && D.T2.fend[0] - D.T2.fstart[0] != D.len2)
+        rc = fail(&e, "length of variable sequences (%d) should be the same as the variable region (%d)", D.len2, D.T2.fend[0] - D.T2.fstart[0]);
+    if (rc) { free(s1); free(s2); return 1; }
+    D.rev1 = reverse1 != 0; D.rev2 = reverse2 != 0; D.mm1 = mm1; D.mm2 = mm2;
+    int clen = D.len1 + D.len2;
+    int8_t *sc = (int8_t *)malloc((size_t)n_pool * (clen ? clen : 1) + 1);
+    for (int i = 0; i < n_pool; ++i) {
+        memcpy(sc + (size_t)i * clen, s1 + (size_t)i * D.len1, D.len1);
+        memcpy(sc + (size_t)i * clen + D.len1, s2 + (size_t)i * D.len2, D.len2);
+    }
+    rc = lib_from_sets(&D.L, sc, n_pool, clen, &e);
+    free(sc);
+    /* the per-mate libraries (strand-adjusted sets are already in s1 / s2), duplicates allowed */
+    lib_t L1 = {0}, L2 = {0};
+    if (!rc) rc = lib_from_sets_opt(&L1, s1, n_pool, D.len1, 0, &e);
+    if (!rc) rc = lib_from_sets_opt(&L2, s2, n_pool, D.len2, 0, &e);
+    free(s1); free(s2);
+    if (rc) { lib_free(&D.L); lib_free(&L1); lib_free(&L2); return 1; }
+
+    uint64_t maxlen = 1;
+    for (int64_t r = 0; r < n_pairs; ++r) {
+        uint64_t a = offs1[r + 1] - offs1[r], b = offs2[r + 1] - offs2[r];
+        if (a > maxlen) maxlen = a;
+        if (b > maxlen) maxlen = b;
+    }
+    hit_t *h1 = (hit_t *)malloc(sizeof(hit_t) * (maxlen + 1)), *h2 = (hit_t *)malloc(sizeof(hit_t) * (maxlen + 1));
+    char *comb = (char *)malloc((size_t)clen + 1);
+    memset(counts, 0, sizeof(int32_t) * (size_t)n_pool);
+    int32_t tot = 0, b1o = 0, b2o = 0;
+    int64_t nt = 0;
+#define S1(read, n) single_search(&D.T1, &L1, &L1, read, n, mm1, use_first, 1)
+#define S2(read, n) single_search(&D.T2, &L2, &L2, read, n, mm2, use_first, 1)
+#define EMIT(x, y) do { tuples[2 * nt] = (x); tuples[2 * nt + 1] = (y); ++nt; } while (0)
+    for (int64_t r = 0; r < n_pairs; ++r) {
+        const char *a = seqs1 + offs1[r]; int na = (int)(offs1[r + 1] - offs1[r]);
+        const char *b = seqs2 + offs2[r]; int nb = (int)(offs2[r + 1] - offs2[r]);
+        int valid;
+        if (use_first) {
+            valid = dual_first(&D, a, na, b, nb, h1, h2, comb);
+            if (valid < 0 && randomized) valid = dual_first(&D, b, nb, a, na, h1, h2, comb);
+        } else {
+            int c1, bb1;
+            dual_best(&D, a, na, b, nb, h1, h2, comb, &c1, &bb1);
+            if (randomized) {
+                int c2, bb2;
+                dual_best(&D, b, nb, a, na, h1, h2, comb, &c2, &bb2);
+                if (c1 < 0 || bb1 > bb2) { c1 = c2; bb1 = bb2; }
+                else if (bb1 == bb2 && c1 != c2) { c1 = -1; }
+            }
+            valid = c1;
+        }
+        ++tot;
+        if (valid >= 0) { ++counts[valid]; continue; }
+        /* CombinatorialBarcodesPairedEnd.hpp:167-242 */
+        smatch_t m1 = S1(a, na), m2 = S2(b, nb);
+        if (use_first) {
+            if (m1.found && m2.found) {
+                EMIT(m1.index, m2.index);
+            } else if (randomized) {
+                smatch_t n1 = S1(b, nb), n2 = S2(a, na);
+                if (n1.found && n2.found) EMIT(n1.index, n2.index);
+                else if (m1.found || n1.found) ++b1o;
+                else if (m2.found || n2.found) ++b2o;
+            } else {
+                if (m1.found) ++b1o;
+                else if (m2.found) ++b2o;
+            }
+        } else if (!randomized) {
+            if (m1.found && m2.found) EMIT(m1.index, m2.index);
+            else if (m1.found) ++b1o;
+            else if (m2.found) ++b2o;
+        } else if (m1.found && m2.found) {
+            int mism = m1.mm + m2.mm;
+            smatch_t n1 = S1(b, nb), n2 = S2(a, na);
+            if (n1.found && n2.found) {
+                int rmism = n1.mm + n2.mm;
+                if (mism > rmism) EMIT(n1.index, n2.index);
+                else if (mism < rmism) EMIT(m1.index, m2.index);
+                else if (m1.index == n1.index && m2.index == n2.index) EMIT(m1.index, m2.index);
+            } else {
+                EMIT(m1.index, m2.index);
+            }
+        } else {
+            smatch_t n1 = S1(b, nb), n2 = S2(a, na);
+            if (n1.found && n2.found) EMIT(n1.index, n2.index);
+            else if (m1.found || n1.found) ++b1o;
+            else if (m2.found || n2.found) ++b2o;
+        }
+    }
+#undef S1
+#undef S2
+#undef EMIT
+    *n_tuples = nt; *total = tot; *barcode1_only = b1o; *barcode2_only = b2o;
+    free(h1); free(h2); free(comb);
+    lib_free(&D.L); lib_free(&L1); lib_free(&L2);
     return 0;
 }
 
