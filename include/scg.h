@@ -78,9 +78,10 @@ int scg_count_combo_barcodes_single(const char* path, const char* constant, int 
                                     int32_t** indices_out, int32_t** freq_out, int64_t* k_out,
                                     int32_t* total_out, char* err, size_t errcap);
 
-/* countDualBarcodes hot path, paired-end.  Replaces src/count_dual_barcodes.cpp:74-117
- * (non-diagnostic branch :38-51; diagnostics != 0 is reported as SCG_ERR_UNSUPPORTED).
- * pool1[i] / pool2[i] form valid pair i; counts_out has n_pool entries. */
+/* countDualBarcodes hot path, paired-end.  Replaces src/count_dual_barcodes.cpp:74-117,
+ * non-diagnostic branch (:38-51).  pool1[i] / pool2[i] form valid pair i; counts_out has n_pool
+ * entries.  diagnostics must be 0 here: the include.invalid=TRUE branch returns more outputs and
+ * is scg_count_dual_barcodes_diagnostics below. */
 int scg_count_dual_barcodes(const char* path1, const char* constant1, int reverse1, int mismatches1,
                             const char* const* pool1,
                             const char* path2, const char* constant2, int reverse2, int mismatches2,
@@ -88,6 +89,22 @@ int scg_count_dual_barcodes(const char* path1, const char* constant1, int revers
                             int randomized, int use_first, int diagnostics, int nthreads,
                             int32_t* counts_out, int32_t* total_out,
                             char* err, size_t errcap);
+
+/* countDualBarcodes(include.invalid=TRUE).  Replaces the diagnostics branch of
+ * src/count_dual_barcodes.cpp:52-71 (kaori::DualBarcodesPairedEndWithDiagnostics): besides the valid-pair
+ * counts, pairs whose two barcodes are both known but do not form a valid combination are
+ * reported as a malloc'd 2 x K matrix of 0-based (pool1 index, pool2 index) columns sorted by
+ * (first, second) with K frequencies (release with scg_free), plus the numbers of pairs where only
+ * barcode 1 / only barcode 2 was found.  Mirrors List(counts, List(indices, freq), total, b1, b2). */
+int scg_count_dual_barcodes_diagnostics(const char* path1, const char* constant1, int reverse1, int mismatches1,
+                                        const char* const* pool1,
+                                        const char* path2, const char* constant2, int reverse2, int mismatches2,
+                                        const char* const* pool2, int32_t n_pool,
+                                        int randomized, int use_first, int nthreads,
+                                        int32_t* counts_out, int32_t** invalid_indices_out, int32_t** invalid_freq_out,
+                                        int64_t* k_out, int32_t* total_out,
+                                        int32_t* barcode1_only_out, int32_t* barcode2_only_out,
+                                        char* err, size_t errcap);
 
 /* matchBarcodes.  Replaces src/match_barcodes.cpp:6-37.  index_out[i] is the 0-based index of the
  * unique best choice within `substitutions` mismatches or -1 (R: NA); mismatches_out likewise. */
@@ -129,13 +146,14 @@ int scg_plan_combo(scg_plan** plan_out, const char* constant, int strand,
 int scg_plan_dual(scg_plan** plan_out,
                   const char* constant1, int reverse1, int mismatches1, const char* const* pool1,
                   const char* constant2, int reverse2, int mismatches2, const char* const* pool2,
-                  int32_t n_pool, int randomized, int use_first,
+                  int32_t n_pool, int randomized, int use_first, int diagnostics,
                   int device, char* err, size_t errcap);
 
 void scg_plan_destroy(scg_plan* plan);
 
 /* Number of int32 counters the plan accumulates into: n_pool (single, dual) or
- * n_pool0 * n_pool1 (combo; dense histogram, cell = first * n_pool1 + second). */
+ * n_pool0 * n_pool1 (combo; dense histogram, cell = first * n_pool1 + second); dual plans with
+ * diagnostics add 2 + n_uid1 * n_uid2 counters behind the n_pool pair counts. */
 int64_t scg_plan_num_counters(const scg_plan* plan);
 
 /* Device pointer to those counters (for an RCCL all-reduce across ranks) and, optionally, a
@@ -165,6 +183,13 @@ int scg_count_batch_paired(scg_plan* plan,
  * so far to the host.  Either output may be NULL. */
 int scg_plan_read(scg_plan* plan, int32_t* counts_out, int64_t* total_out, void* stream,
                   char* err, size_t errcap);
+
+/* Dual plans built with diagnostics != 0: the five outputs of the include.invalid=TRUE branch
+ * (see scg_count_dual_barcodes_diagnostics) from the plan's counters; synchronises `stream`. */
+int scg_plan_read_diagnostics(scg_plan* plan, int32_t* counts_out, int32_t** invalid_indices_out,
+                              int32_t** invalid_freq_out, int64_t* k_out, int64_t* total_out,
+                              int32_t* barcode1_only_out, int32_t* barcode2_only_out, void* stream,
+                              char* err, size_t errcap);
 
 /* Combo plans: sorted run-length form of a dense histogram (host-side, pure function):
  * cells[n0*n1] -> malloc'd 2 x K indices + K frequencies, as scg_count_combo_barcodes_single. */

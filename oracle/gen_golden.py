@@ -61,6 +61,15 @@ def run_case(ref: KaoriRef, case: dict, tmp: str) -> dict:
                                            f2, case["template2"], case["reverse2"], case["mismatches2"], case["pool2"],
                                            case["randomized"], case["use_first"], 1)
             out["expect"] = {"counts": counts.tolist(), "total": total}
+        elif k == "dual_diag":
+            f1, f2 = os.path.join(tmp, "g1.fastq"), os.path.join(tmp, "g2.fastq")
+            write_fastq(f1, case["reads1"])
+            write_fastq(f2, case["reads2"])
+            d = ref.count_dual_diag(f1, case["template1"], case["reverse1"], case["mismatches1"], case["pool1"],
+                                    f2, case["template2"], case["reverse2"], case["mismatches2"], case["pool2"],
+                                    case["randomized"], case["use_first"], 1)
+            out["expect"] = {"counts": d["counts"].tolist(), "indices": d["indices"].tolist(), "freq": d["freq"].tolist(),
+                             "total": d["total"], "barcode1_only": d["barcode1_only"], "barcode2_only": d["barcode2_only"]}
         elif k == "match":
             idx, mm = ref.match_barcodes(case["sequences"], case["choices"], case["substitutions"], case["reverse"])
             out["expect"] = {"index": idx.tolist(), "mismatches": mm.tolist()}
@@ -222,6 +231,10 @@ def main() -> None:
             rnd.append(run_case(ref, gen.random_dual_case(rng, hazard_free=True, sizes=small, max_mm=3), tmp))
         for _ in range(30):
             rnd.append(run_case(ref, gen.random_match_case(rng), tmp))
+        for _ in range(40):
+            c = gen.random_dual_case(rng, hazard_free=True, sizes=small, max_mm=2)
+            c["kind"] = "dual_diag"
+            rnd.append(run_case(ref, c, tmp))
         with open(os.path.join(OUT, "kaori_random.json"), "w") as f:
             json.dump({"generator": "oracle/gen_golden.py", "reference": "kaori v1.1.1 (screenCounter 1.5.1)", "seed": 20261003, "cases": rnd}, f)
 

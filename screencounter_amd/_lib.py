@@ -64,7 +64,13 @@ SIGNATURES = {
     "scg_plan_combo": (C.c_int, [C.POINTER(C.c_void_p), C.c_char_p, C.c_int, c_str_p, C.c_int32, c_str_p, C.c_int32, C.c_int, C.c_int,
                                  C.c_int, C.c_char_p, C.c_size_t]),
     "scg_plan_dual": (C.c_int, [C.POINTER(C.c_void_p), C.c_char_p, C.c_int, C.c_int, c_str_p, C.c_char_p, C.c_int, C.c_int, c_str_p,
-                                C.c_int32, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_size_t]),
+                                C.c_int32, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_size_t]),
+    "scg_count_dual_barcodes_diagnostics": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_int, c_str_p,
+                                                      C.c_char_p, C.c_char_p, C.c_int, C.c_int, c_str_p, C.c_int32,
+                                                      C.c_int, C.c_int, C.c_int, i32_p, C.POINTER(i32_p), C.POINTER(i32_p), i64_p,
+                                                      i32_p, i32_p, i32_p, C.c_char_p, C.c_size_t]),
+    "scg_plan_read_diagnostics": (C.c_int, [C.c_void_p, i32_p, C.POINTER(i32_p), C.POINTER(i32_p), i64_p, i64_p, i32_p, i32_p,
+                                            C.c_void_p, C.c_char_p, C.c_size_t]),
     "scg_plan_destroy": (None, [C.c_void_p]),
     "scg_plan_num_counters": (C.c_int64, [C.c_void_p]),
     "scg_plan_device_counters": (C.c_void_p, [C.c_void_p]),

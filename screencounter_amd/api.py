@@ -78,11 +78,34 @@ def count_combo_barcodes_single(path: str, constant: str, strand: int, pool: Seq
 def count_dual_barcodes(path1: str, constant1: str, reverse1: bool, mismatches1: int, pool1: Sequence[str],
                         path2: str, constant2: str, reverse2: bool, mismatches2: int, pool2: Sequence[str],
                         randomized: bool, use_first: bool, diagnostics: bool = False, nthreads: int = 1):
-    """src/count_dual_barcodes.cpp:74-117 (non-diagnostic branch) -> (counts int32[n pairs], total)."""
+    """src/count_dual_barcodes.cpp:74-117 -> (counts int32[n pairs], total), or with diagnostics=True the
+    five outputs of the include.invalid=TRUE branch: (counts, (indices int32[2, K] 0-based, freq), total,
+    barcode1_only, barcode2_only)."""
     if len(pool1) != len(pool2):
         # kaori/handlers/DualBarcodesPairedEnd.hpp:106-109
         raise ScgError(_lib.SCG_ERR_INVALID, "both barcode pools should be of the same length")
     L = _lib.load()
+    if diagnostics:
+        counts = np.zeros(max(len(pool1), 1), dtype=np.int32)
+        idx_p, freq_p = _lib.i32_p(), _lib.i32_p()
+        k = C.c_int64(0)
+        total, b1, b2 = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        err = errbuf()
+        p1, _k1 = cstr_array(pool1)
+        p2, _k2 = cstr_array(pool2)
+        check(L.scg_count_dual_barcodes_diagnostics(os.fspath(path1).encode(), constant1.encode(), int(bool(reverse1)), int(mismatches1), p1,
+                                                    os.fspath(path2).encode(), constant2.encode(), int(bool(reverse2)), int(mismatches2), p2,
+                                                    len(pool1), int(bool(randomized)), int(bool(use_first)), int(nthreads),
+                                                    counts.ctypes.data_as(_lib.i32_p), C.byref(idx_p), C.byref(freq_p), C.byref(k),
+                                                    C.byref(total), C.byref(b1), C.byref(b2), err, _lib.ERRCAP), err)
+        K = int(k.value)
+        try:
+            idx = np.ctypeslib.as_array(idx_p, shape=(max(2 * K, 1),))[:2 * K].reshape(K, 2).T.copy()
+            freq = np.ctypeslib.as_array(freq_p, shape=(max(K, 1),))[:K].copy()
+        finally:
+            L.scg_free(idx_p)
+            L.scg_free(freq_p)
+        return counts[:len(pool1)].copy(), (idx.astype(np.int32), freq.astype(np.int32)), int(total.value), int(b1.value), int(b2.value)
     counts = np.zeros(max(len(pool1), 1), dtype=np.int32)
     total = C.c_int32(0)
     err = errbuf()
@@ -150,10 +173,16 @@ class ComboCounts:
 
 @dataclass
 class DualCounts:
-    """countDualBarcodes(): `choices` with a counts column + metadata$npairs."""
+    """countDualBarcodes(): `choices` with a counts column + metadata$npairs.  With include.invalid=TRUE the
+    invalid combinations are appended as extra rows (`valid` False) and the metadata gains barcode1.only,
+    barcode2.only, invalid.pair (R/countDualBarcodes.R:152-159)."""
     choices: Dict[str, List[str]]
     counts: np.ndarray
     npairs: int
+    valid: Optional[List[bool]] = None
+    barcode1_only: Optional[int] = None
+    barcode2_only: Optional[int] = None
+    invalid_pair: Optional[int] = None
 
 
 @dataclass
@@ -290,10 +319,19 @@ def countDualBarcodes(fastq: Sequence[str], choices, flank5=None, flank3=None, t
     for s in strands:                                               # :176-182
         if s not in ("original", "reverse"):
             raise ValueError("'strand' should be one of 'original', 'reverse'")
-    counts, total = count_dual_barcodes(fastq[0], template1, strands[0] == "reverse", int(subs[0]), col1,
-                                        fastq[1], template2, strands[1] == "reverse", int(subs[1]), col2,
-                                        randomized, not find_best, include_invalid, num_threads)
-    return DualCounts(choices={names[0]: col1, names[1]: col2}, counts=counts, npairs=total)
+    out = count_dual_barcodes(fastq[0], template1, strands[0] == "reverse", int(subs[0]), col1,
+                              fastq[1], template2, strands[1] == "reverse", int(subs[1]), col2,
+                              randomized, not find_best, include_invalid, num_threads)
+    if not include_invalid:
+        counts, total = out
+        return DualCounts(choices={names[0]: col1, names[1]: col2}, counts=counts, npairs=total)
+    counts, (idx, freq), total, b1, b2 = out                      # R/countDualBarcodes.R:152-159, :184-198
+    inv1 = [col1[i] for i in idx[0]]
+    inv2 = [col2[j] for j in idx[1]]
+    return DualCounts(choices={names[0]: col1 + inv1, names[1]: col2 + inv2},
+                      counts=np.concatenate([counts, freq]).astype(np.int32), npairs=total,
+                      valid=[True] * len(col1) + [False] * len(inv1),
+                      barcode1_only=b1, barcode2_only=b2, invalid_pair=int(freq.sum()))
 
 
 def matrixOfDualBarcodes(files: Sequence[Sequence[str]], choices, withDimnames: bool = True, **kwargs) -> CountMatrix:

@@ -164,6 +164,8 @@ struct scg_plan {
     int32_t n_pool[2] = {0, 0};
     int max_mm1 = 0, max_mm2 = 0;
     bool rev1 = false, rev2 = false, randomized = false, use_first = true;
+    bool diagnostics = false;
+    std::vector<int32_t> first1, first2;   // sequence uid -> first pool index (DuplicateAction::FIRST)
 
     // device state
     DevBuf d_tmpl1, d_tmpl2;
@@ -304,7 +306,7 @@ std::unique_ptr<scg_plan> compile_combo(const char* constant, int strand,
 
 std::unique_ptr<scg_plan> compile_dual(const char* constant1, int reverse1, int mismatches1, const char* const* pool1,
                                        const char* constant2, int reverse2, int mismatches2, const char* const* pool2,
-                                       int32_t n_pool, int randomized, int use_first) {
+                                       int32_t n_pool, int randomized, int use_first, int diagnostics = 0) {
     if (!constant1 || !constant2 || (n_pool > 0 && (!pool1 || !pool2)) || n_pool < 0) throw Error(SCG_ERR_INVALID, "null argument");
     std::unique_ptr<scg_plan> P(new scg_plan);
     P->kind = scg_plan::DUAL;
@@ -332,6 +334,24 @@ std::unique_ptr<scg_plan> compile_dual(const char* constant1, int reverse1, int 
     P->hpairs = scg::build_pair_table(exp1, uk1, exp2, uk2);   // :138-178 (duplicate pairs => error)
     P->n_pool[0] = P->n_pool[1] = n_pool;
     P->n_counters = n_pool;
+    if (diagnostics) {
+        // uid -> index of the first barcode that contains the sequence
+        auto firsts = [&](const std::vector<std::vector<int32_t> >& exp, size_t n_uid) {
+            std::vector<int32_t> f(n_uid, -1);
+            for (size_t i = 0; i < exp.size(); ++i) {
+                for (int32_t u : exp[i]) if (f[u] < 0) f[u] = static_cast<int32_t>(i);
+            }
+            return f;
+        };
+        P->first1 = firsts(exp1, uk1.size());
+        P->first2 = firsts(exp2, uk2.size());
+        int64_t cells = static_cast<int64_t>(uk1.size()) * static_cast<int64_t>(uk2.size());
+        if (cells > (int64_t(1) << 28)) {
+            throw Error(SCG_ERR_UNSUPPORTED, "include.invalid=TRUE needs n_unique1 x n_unique2 <= 2^28 cells in this engine");
+        }
+        P->diagnostics = true;
+        P->n_counters = static_cast<int64_t>(n_pool) + 2 + cells;
+    }
     P->max_mm1 = mismatches1; P->max_mm2 = mismatches2;
     P->rev1 = reverse1 != 0; P->rev2 = reverse2 != 0;
     P->randomized = randomized != 0;
@@ -371,6 +391,7 @@ void launch_batch_paired(scg_plan* P, const ScgReads& R1, const ScgReads& R2, in
     dp.index1 = P->tab[0].view; dp.index2 = P->tab[1].view; dp.pairs = P->pairs.view;
     dp.rev1 = P->rev1; dp.rev2 = P->rev2; dp.max_mm1 = P->max_mm1; dp.max_mm2 = P->max_mm2;
     dp.randomized = P->randomized; dp.use_first = P->use_first;
+    dp.diagnostics = P->diagnostics; dp.n_pool = P->n_pool[0]; dp.n_uid2 = static_cast<int32_t>(P->first2.size());
     HIP_CHECK(scg::launch_dual(dp, std::max(P->ht1.t.len, P->ht2.t.len), R1, R2, n, P->counters, P->error_flag.as<int32_t>(), stream));
     timer.stop();
     P->total += n;
@@ -496,6 +517,62 @@ void combo_compact(const int32_t* cells, int32_t n0, int32_t n1, int32_t** indic
     *indices_out = idx; *freq_out = freq; *k_out = k;
 }
 
+// [n_pool valid][b1][b2][uid1 x uid2] -> the reference's outputs: invalid combinations by first pool
+// index, merged (several uids of one IUPAC barcode share an index), sorted by (first, second).
+void diagnostics_from_counters(const scg_plan* P, const std::vector<int32_t>& all, int32_t* counts_out,
+                               int32_t** idx_out, int32_t** freq_out, int64_t* k_out, int32_t* b1, int32_t* b2) {
+    const int32_t n_pool = P->n_pool[0];
+    if (counts_out) std::copy(all.begin(), all.begin() + n_pool, counts_out);
+    *b1 = all[n_pool];
+    *b2 = all[n_pool + 1];
+    const int32_t* cells = all.data() + n_pool + 2;
+    const size_t nu1 = P->first1.size(), nu2 = P->first2.size();
+    std::vector<std::pair<std::pair<int32_t, int32_t>, int32_t> > found;
+    for (size_t u1 = 0; u1 < nu1; ++u1) {
+        for (size_t u2 = 0; u2 < nu2; ++u2) {
+            int32_t c = cells[u1 * nu2 + u2];
+            if (c) found.push_back(std::make_pair(std::make_pair(P->first1[u1], P->first2[u2]), c));
+        }
+    }
+    std::sort(found.begin(), found.end());
+    std::vector<int32_t> idx, freq;
+    for (size_t i = 0; i < found.size(); ++i) {
+        if (i && found[i].first == found[i - 1].first) {
+            freq.back() += found[i].second;
+        } else {
+            idx.push_back(found[i].first.first);
+            idx.push_back(found[i].first.second);
+            freq.push_back(found[i].second);
+        }
+    }
+    int32_t* oi = static_cast<int32_t*>(std::malloc(sizeof(int32_t) * (idx.size() + 1)));
+    int32_t* of = static_cast<int32_t*>(std::malloc(sizeof(int32_t) * (freq.size() + 1)));
+    if (!oi || !of) { std::free(oi); std::free(of); throw std::bad_alloc(); }
+    std::copy(idx.begin(), idx.end(), oi);
+    std::copy(freq.begin(), freq.end(), of);
+    *idx_out = oi; *freq_out = of; *k_out = static_cast<int64_t>(freq.size());
+}
+
+// Both FASTQ files of a paired-end run, in lock-step by read count (process_data.hpp:246-290).
+void count_paired_files(scg_plan* P, scg::FastqStream& fq1, scg::FastqStream& fq2) {
+    Stager st;
+    scg::ReadBatch b1, b2;
+    for (;;) {
+        bool more1 = fq1.next_batch(b1, BATCH_READS / 4, INT64_MAX);
+        bool more2 = fq2.next_batch(b2, BATCH_READS / 4, INT64_MAX);
+        if (b1.size() != b2.size()) {
+            throw Error(SCG_ERR_IO, "different number of reads in paired FASTQ files");   // process_data.hpp:284-285
+        }
+        if (!more1 && !more2) break;
+        auto& s = st.acquire();
+        ScgReads R1 = st.stage(s, 0, b1);
+        ScgReads R2 = st.stage(s, 1, b2);
+        launch_batch_paired(P, R1, R2, b1.size(), s.stream);
+        s.busy = true;
+    }
+    st.drain();
+}
+
 } // namespace
 
 // -------------------------------------------------------------------------------------------------
@@ -571,10 +648,10 @@ int scg_plan_combo(scg_plan** plan_out, const char* constant, int strand, const 
 
 int scg_plan_dual(scg_plan** plan_out, const char* constant1, int reverse1, int mismatches1, const char* const* pool1,
                   const char* constant2, int reverse2, int mismatches2, const char* const* pool2,
-                  int32_t n_pool, int randomized, int use_first, int device, char* err, size_t errcap) {
+                  int32_t n_pool, int randomized, int use_first, int diagnostics, int device, char* err, size_t errcap) {
     return guarded(err, errcap, [&] {
         if (!plan_out) throw Error(SCG_ERR_INVALID, "null argument");
-        auto P = compile_dual(constant1, reverse1, mismatches1, pool1, constant2, reverse2, mismatches2, pool2, n_pool, randomized, use_first);
+        auto P = compile_dual(constant1, reverse1, mismatches1, pool1, constant2, reverse2, mismatches2, pool2, n_pool, randomized, use_first, diagnostics);
         P->to_device(device);
         *plan_out = P.release();
     });
@@ -721,30 +798,56 @@ int scg_count_dual_barcodes(const char* path1, const char* constant1, int revers
         scg::FastqStream fq1(path1);                                         // src/count_dual_barcodes.cpp:93-97
         scg::FastqStream fq2(path2);
         if (diagnostics) {
-            throw Error(SCG_ERR_UNSUPPORTED, "include.invalid=TRUE (diagnostics) is not implemented by this engine yet");
+            throw Error(SCG_ERR_INVALID, "diagnostics requested: call scg_count_dual_barcodes_diagnostics, which returns the extra outputs");
         }
         auto P = compile_dual(constant1, reverse1, mismatches1, pool1, constant2, reverse2, mismatches2, pool2, n_pool, randomized, use_first);
         P->to_device(-1);
         DeviceGuard g(P->device);
-        Stager st;
-        scg::ReadBatch b1, b2;
-        for (;;) {
-            // Both files advance in lock-step by read count (process_data.hpp:246-290).
-            bool more1 = fq1.next_batch(b1, BATCH_READS / 4, INT64_MAX);
-            bool more2 = fq2.next_batch(b2, BATCH_READS / 4, INT64_MAX);
-            if (b1.size() != b2.size()) {
-                throw Error(SCG_ERR_IO, "different number of reads in paired FASTQ files");   // process_data.hpp:284-285
-            }
-            if (!more1 && !more2) break;
-            auto& s = st.acquire();
-            ScgReads R1 = st.stage(s, 0, b1);
-            ScgReads R2 = st.stage(s, 1, b2);
-            launch_batch_paired(P.get(), R1, R2, b1.size(), s.stream);
-            s.busy = true;
-        }
-        st.drain();
+        count_paired_files(P.get(), fq1, fq2);
         read_counters(P.get(), counts_out);
         *total_out = static_cast<int32_t>(P->total);
+    });
+}
+
+int scg_count_dual_barcodes_diagnostics(const char* path1, const char* constant1, int reverse1, int mismatches1, const char* const* pool1,
+                                        const char* path2, const char* constant2, int reverse2, int mismatches2, const char* const* pool2,
+                                        int32_t n_pool, int randomized, int use_first, int nthreads,
+                                        int32_t* counts_out, int32_t** invalid_indices_out, int32_t** invalid_freq_out, int64_t* k_out,
+                                        int32_t* total_out, int32_t* barcode1_only_out, int32_t* barcode2_only_out,
+                                        char* err, size_t errcap) {
+    (void)nthreads;
+    return guarded(err, errcap, [&] {
+        if (!path1 || !path2 || !counts_out || !invalid_indices_out || !invalid_freq_out || !k_out || !total_out ||
+            !barcode1_only_out || !barcode2_only_out) {
+            throw Error(SCG_ERR_INVALID, "null argument");
+        }
+        scg::FastqStream fq1(path1);
+        scg::FastqStream fq2(path2);
+        auto P = compile_dual(constant1, reverse1, mismatches1, pool1, constant2, reverse2, mismatches2, pool2, n_pool, randomized, use_first, 1);
+        P->to_device(-1);
+        DeviceGuard g(P->device);
+        count_paired_files(P.get(), fq1, fq2);
+        std::vector<int32_t> all(static_cast<size_t>(P->n_counters) + 1);
+        read_counters(P.get(), all.data());
+        diagnostics_from_counters(P.get(), all, counts_out, invalid_indices_out, invalid_freq_out, k_out, barcode1_only_out, barcode2_only_out);
+        *total_out = static_cast<int32_t>(P->total);
+    });
+}
+
+int scg_plan_read_diagnostics(scg_plan* plan, int32_t* counts_out, int32_t** invalid_indices_out, int32_t** invalid_freq_out,
+                              int64_t* k_out, int64_t* total_out, int32_t* barcode1_only_out, int32_t* barcode2_only_out,
+                              void* stream, char* err, size_t errcap) {
+    return guarded(err, errcap, [&] {
+        if (!plan || !invalid_indices_out || !invalid_freq_out || !k_out || !barcode1_only_out || !barcode2_only_out) {
+            throw Error(SCG_ERR_INVALID, "null argument");
+        }
+        if (plan->kind != scg_plan::DUAL || !plan->diagnostics) throw Error(SCG_ERR_INVALID, "not a dual plan with diagnostics");
+        DeviceGuard g(plan->device);
+        HIP_CHECK(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+        std::vector<int32_t> all(static_cast<size_t>(plan->n_counters) + 1);
+        read_counters(plan, all.data());
+        diagnostics_from_counters(plan, all, counts_out, invalid_indices_out, invalid_freq_out, k_out, barcode1_only_out, barcode2_only_out);
+        if (total_out) *total_out = plan->total;
     });
 }
 

@@ -154,6 +154,12 @@ struct ScgDualParams {
     int32_t max_mm1, max_mm2;
     int32_t randomized;
     int32_t use_first;
+    // include.invalid=TRUE (handlers/DualBarcodesPairedEndWithDiagnostics.hpp): pairs without a valid
+    // combination are searched mate by mate; counters = [n_pool valid][barcode1-only][barcode2-only]
+    // [n_uid1 x n_uid2 invalid combinations by sequence uid]
+    int32_t diagnostics;
+    int32_t n_pool;
+    int32_t n_uid2;
 };
 
 static inline

@@ -190,12 +190,17 @@ __device__ __forceinline__ void index_search(const ScgIndex& X, const Query& q, 
 // match(q, cap): the unique library entry at the minimum Hamming distance <= cap.
 // index >= 0 on a hit; SCG_MISSING if nothing within cap; SCG_AMBIGUOUS on a tie between
 // different entries.  `mm` receives the distance of a hit.
-__device__ __forceinline__ void index_match(const ScgIndex& X, const Query& q, int cap, int& index, int& mm) {
+//
+// keep_first = DuplicateAction::FIRST (MismatchTrie.hpp:109-110, :273-276, :311-314): a tie goes to
+// the smallest value instead of being ambiguous.  Used by the include.invalid=TRUE path, where
+// the values are sequence uids numbered in order of first appearance in the pool.
+__device__ __forceinline__ void index_match(const ScgIndex& X, const Query& q, int cap, int& index, int& mm,
+                                            bool keep_first = false) {
     int best = cap + 1, cur = SCG_MISSING;
     index_search(X, q, cap, [&](int v, int d) -> bool {
         if (d < best) { best = d; cur = v; }
-        else if (d == best && cur != v) { cur = SCG_AMBIGUOUS; }
-        return d == 0;      // an exact entry is unique (duplicates are construction errors)
+        else if (d == best && cur != v) { cur = keep_first ? (v < cur ? v : cur) : SCG_AMBIGUOUS; }
+        return d == 0;      // an exact entry is unique (one entry per concrete sequence)
     });
     index = cur; mm = best;
 }

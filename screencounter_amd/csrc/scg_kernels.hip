@@ -178,6 +178,79 @@ __device__ __forceinline__ void dual_best(const ScgDualParams& P, const Read& a,
     }
 }
 
+// SimpleSingleMatch::search_first / search_best of one mate on one strand (byte-wise), with the
+// FIRST duplicate policy of the diagnostics path.  Returns found; index = sequence uid.
+__device__ __forceinline__ bool mate_search(const ScgTemplate* T, const ScgIndex& X, bool reverse, int max_mm, bool use_first,
+                                            const Read& rd, int& index, int& mism) {
+    bool found = false;
+    index = -1; mism = 0;
+    int best = max_mm + 1;
+    const int start = reverse ? T->rstart[0] : T->fstart[0];
+    for (int p = 0; p + T->len <= rd.n; ++p) {
+        int c = const_mismatches(T, reverse, rd.p, p, max_mm);
+        if (c > max_mm) continue;
+        Query q = pack_region(rd.p + p + start, X.len, reverse);
+        int idx, d;
+        index_match(X, q, max_mm - c, idx, d, true);
+        if (idx < 0) continue;
+        int tot = c + d;
+        if (use_first) { index = idx; mism = tot; return true; }
+        if (tot == best) {
+            if (index != idx) { found = false; index = -1; }
+        } else if (tot < best) {
+            found = true; best = tot; index = idx; mism = tot;
+        }
+    }
+    return found;
+}
+
+// CombinatorialBarcodesPairedEnd::process (handlers/CombinatorialBarcodesPairedEnd.hpp:167-242) on a
+// pair the dual search rejected.  S1(x)/S2(x) = search of template 1 / 2 on mate x (0 = a, 1 = b).
+template<class S1, class S2>
+__device__ __forceinline__ void diagnose_pair(const ScgDualParams& P, S1 s1, S2 s2, int32_t* __restrict__ counters) {
+    int32_t* b1_only = counters + P.n_pool;
+    int32_t* b2_only = b1_only + 1;
+    int32_t* cells = b2_only + 1;
+    auto emit = [&](int u1, int u2) { atomicAdd(&cells[(int64_t)u1 * P.n_uid2 + u2], 1); };
+    int i1, m1, i2, m2;
+    const bool f1 = s1(0, i1, m1), f2 = s2(1, i2, m2);
+    if (P.use_first) {
+        if (f1 && f2) {
+            emit(i1, i2);
+        } else if (P.randomized) {
+            int j1, n1, j2, n2;
+            const bool g1 = s1(1, j1, n1), g2 = s2(0, j2, n2);
+            if (g1 && g2) emit(j1, j2);
+            else if (f1 || g1) atomicAdd(b1_only, 1);
+            else if (f2 || g2) atomicAdd(b2_only, 1);
+        } else {
+            if (f1) atomicAdd(b1_only, 1);
+            else if (f2) atomicAdd(b2_only, 1);
+        }
+    } else if (!P.randomized) {
+        if (f1 && f2) emit(i1, i2);
+        else if (f1) atomicAdd(b1_only, 1);
+        else if (f2) atomicAdd(b2_only, 1);
+    } else if (f1 && f2) {
+        int j1, n1, j2, n2;
+        const bool g1 = s1(1, j1, n1), g2 = s2(0, j2, n2);
+        if (g1 && g2) {
+            int mism = m1 + m2, rmism = n1 + n2;
+            if (mism > rmism) emit(j1, j2);
+            else if (mism < rmism) emit(i1, i2);
+            else if (i1 == j1 && i2 == j2) emit(i1, i2);
+        } else {
+            emit(i1, i2);
+        }
+    } else {
+        int j1, n1, j2, n2;
+        const bool g1 = s1(1, j1, n1), g2 = s2(0, j2, n2);
+        if (g1 && g2) emit(j1, j2);
+        else if (f1 || g1) atomicAdd(b1_only, 1);
+        else if (f2 || g2) atomicAdd(b2_only, 1);
+    }
+}
+
 __device__ __forceinline__ int dual_pair(const ScgDualParams& P, const Read& a, const Read& b) {
     int idx;
     if (P.use_first) {                                  // :356-360
@@ -202,7 +275,14 @@ __global__ __launch_bounds__(BLOCK) void dual_kernel(ScgDualParams P, ScgReads R
     if (i >= n_pairs) return;
     Read a = get_read(R1, i), b = get_read(R2, i);
     int idx = dual_pair(P, a, b);
-    if (idx >= 0) atomicAdd(&counts[idx], 1);
+    if (idx >= 0) {
+        atomicAdd(&counts[idx], 1);
+    } else if (P.diagnostics) {
+        diagnose_pair(P,
+            [&](int which, int& index, int& mism) { return mate_search(P.tmpl1, P.index1, P.rev1 != 0, P.max_mm1, P.use_first != 0, which ? b : a, index, mism); },
+            [&](int which, int& index, int& mism) { return mate_search(P.tmpl2, P.index2, P.rev2 != 0, P.max_mm2, P.use_first != 0, which ? b : a, index, mism); },
+            counts);
+    }
 }
 
 // =============================================================================================
@@ -346,6 +426,37 @@ __global__ __launch_bounds__(STAGE_BLOCK) __attribute__((amdgpu_num_sgpr(80))) v
     if (found) atomicAdd(&cells[(int64_t)best_id[0] * P.n_pool[1] + best_id[1]], 1);
 }
 
+// Staged counterpart of mate_search.
+template<int NW, int NT, int NC>
+__device__ __forceinline__ bool mate_search_staged(const Tile<NW>& tile, const StagedRead& sr, const ScgScan& T, const ScgIndex& X,
+                                                   bool reverse, int max_mm, bool use_first, int& index, int& mism) {
+    bool found = false;
+    index = -1; mism = 0;
+    int best = max_mm + 1;
+    uint32_t cand[NC], unused[NC];
+    if (reverse) scan_read<NW, NC>(tile, sr, T, false, true, unused, cand); else scan_read<NW, NC>(tile, sr, T, true, false, cand, unused);
+    const int start = reverse ? T.rstart[0] : T.fstart[0];
+    for (;;) {
+        int p = first_bit<NC>(cand);
+        if (p >= (1 << 30)) break;
+        clear_bit<NC>(cand, p);
+        int c = window_mismatches<NW, NT>(tile, sr.bit + p, T, reverse);
+        if (c > max_mm) continue;
+        Query q = region_query<NW>(tile, sr.bit + p + start, X.len, reverse);
+        int idx, d;
+        index_match(X, q, max_mm - c, idx, d, true);
+        if (idx < 0) continue;
+        int tot = c + d;
+        if (use_first) { index = idx; mism = tot; return true; }
+        if (tot == best) {
+            if (index != idx) { found = false; index = -1; }
+        } else if (tot < best) {
+            found = true; best = tot; index = idx; mism = tot;
+        }
+    }
+    return found;
+}
+
 // One orientation of a staged pair: template 1 on (ta, a), template 2 on (tb, b).
 template<int NW, int NT, int NC>
 __device__ __forceinline__ void dual_orientation_staged(const ScgDualParams& P, const bool BEST,
@@ -394,7 +505,9 @@ __device__ __forceinline__ void dual_orientation_staged(const ScgDualParams& P, 
     }
 }
 
-template<int NW, int NT, int NC>
+// DIAG: include.invalid=TRUE -- rejected pairs are also searched mate by mate (separate instantiation so
+// that the ordinary kernel does not pay for it).
+template<int NW, int NT, int NC, bool DIAG>
 __global__ __launch_bounds__(STAGE_BLOCK) void dual_staged_kernel(ScgDualParams P, ScgReads R1, ScgReads R2, int64_t n_pairs,
                                                                  int32_t* __restrict__ counts, int32_t* __restrict__ error_flag) {
     __shared__ Tile<NW> tile1;
@@ -438,6 +551,18 @@ __global__ __launch_bounds__(STAGE_BLOCK) void dual_staged_kernel(ScgDualParams 
                 if (idx < 0 || best > cb) { idx = ci; best = cb; }
                 else if (best == cb && idx != ci) { idx = -1; }
             }
+        }
+        if (DIAG && idx < 0) {
+            diagnose_pair(P,
+                [&](int which, int& index, int& mism) {
+                    return mate_search_staged<NW, NT, NC>(which ? tile2 : tile1, which ? sb : sa, P.scan1, P.index1, P.rev1 != 0,
+                                                          P.max_mm1, P.use_first != 0, index, mism);
+                },
+                [&](int which, int& index, int& mism) {
+                    return mate_search_staged<NW, NT, NC>(which ? tile2 : tile1, which ? sb : sa, P.scan2, P.index2, P.rev2 != 0,
+                                                          P.max_mm2, P.use_first != 0, index, mism);
+                },
+                counts);
         }
     }
     if (idx >= 0) atomicAdd(&counts[idx], 1);
@@ -579,10 +704,13 @@ template<int NW, int NT> struct LaunchDual {
     static hipError_t go(const ScgDualParams& P, const ScgReads& R1, const ScgReads& R2, int64_t n, int32_t* counts, int32_t* flag, hipStream_t stream) {
         const int max_len = R1.max_len > R2.max_len ? R1.max_len : R2.max_len;
         const int min_t = P.scan1.len < P.scan2.len ? P.scan1.len : P.scan2.len;
-        if (NW == 5 && P.scan1.compact_ok && P.scan2.compact_ok && max_len - min_t + 1 <= 96) {
-            hipLaunchKernelGGL((dual_staged_kernel<NW, NT, (NW == 5 ? 3 : NW)>), dim3(grid_for(n)), dim3(STAGE_BLOCK), 0, stream, P, R1, R2, n, counts, flag);
+        const bool compact = NW == 5 && P.scan1.compact_ok && P.scan2.compact_ok && max_len - min_t + 1 <= 96;
+        if (P.diagnostics) {
+            if (compact) hipLaunchKernelGGL((dual_staged_kernel<NW, NT, (NW == 5 ? 3 : NW), true>), dim3(grid_for(n)), dim3(STAGE_BLOCK), 0, stream, P, R1, R2, n, counts, flag);
+            else hipLaunchKernelGGL((dual_staged_kernel<NW, NT, NW, true>), dim3(grid_for(n)), dim3(STAGE_BLOCK), 0, stream, P, R1, R2, n, counts, flag);
         } else {
-            hipLaunchKernelGGL((dual_staged_kernel<NW, NT, NW>), dim3(grid_for(n)), dim3(STAGE_BLOCK), 0, stream, P, R1, R2, n, counts, flag);
+            if (compact) hipLaunchKernelGGL((dual_staged_kernel<NW, NT, (NW == 5 ? 3 : NW), false>), dim3(grid_for(n)), dim3(STAGE_BLOCK), 0, stream, P, R1, R2, n, counts, flag);
+            else hipLaunchKernelGGL((dual_staged_kernel<NW, NT, NW, false>), dim3(grid_for(n)), dim3(STAGE_BLOCK), 0, stream, P, R1, R2, n, counts, flag);
         }
         return hipGetLastError();
     }

@@ -94,7 +94,8 @@ class Plan:
     @classmethod
     def dual(cls, template1: str, reverse1: bool, mismatches1: int, pool1: Sequence[str],
              template2: str, reverse2: bool, mismatches2: int, pool2: Sequence[str],
-             randomized: bool = False, use_first: bool = True, device: int = -1) -> "Plan":
+             randomized: bool = False, use_first: bool = True, device: int = -1, diagnostics: bool = False) -> "Plan":
+        """diagnostics=True builds the include.invalid=TRUE variant (read with read_diagnostics())."""
         if len(pool1) != len(pool2):
             # kaori/handlers/DualBarcodesPairedEnd.hpp:106-109
             raise ScgError(_lib.SCG_ERR_INVALID, "both barcode pools should be of the same length")
@@ -105,7 +106,7 @@ class Plan:
         p2, _k2 = cstr_array(pool2)
         check(L.scg_plan_dual(C.byref(h), template1.encode(), int(bool(reverse1)), int(mismatches1), p1,
                               template2.encode(), int(bool(reverse2)), int(mismatches2), p2, len(pool1),
-                              int(bool(randomized)), int(bool(use_first)), int(device), err, _lib.ERRCAP), err)
+                              int(bool(randomized)), int(bool(use_first)), int(bool(diagnostics)), int(device), err, _lib.ERRCAP), err)
         return cls(h.value, "dual", (len(pool1),), device)
 
     def close(self) -> None:
@@ -202,6 +203,27 @@ class Plan:
         check(self._lib.scg_plan_read(self._h, counts.ctypes.data_as(_lib.i32_p), C.byref(total),
                                       C.c_void_p(_stream_handle(stream)), err, _lib.ERRCAP), err)
         return counts[:self.num_counters], int(total.value)
+
+    def read_diagnostics(self, stream=None):
+        """Dual plans built with diagnostics=True -> dict(counts, indices int32[2, K], freq, total,
+        barcode1_only, barcode2_only), the outputs of src/count_dual_barcodes.cpp:64-70."""
+        counts = np.zeros(max(self.n_pool[0], 1), dtype=np.int32)
+        idx_p, freq_p = _lib.i32_p(), _lib.i32_p()
+        k, total = C.c_int64(0), C.c_int64(0)
+        b1, b2 = C.c_int32(0), C.c_int32(0)
+        err = errbuf()
+        check(self._lib.scg_plan_read_diagnostics(self._h, counts.ctypes.data_as(_lib.i32_p), C.byref(idx_p), C.byref(freq_p),
+                                                  C.byref(k), C.byref(total), C.byref(b1), C.byref(b2),
+                                                  C.c_void_p(_stream_handle(stream)), err, _lib.ERRCAP), err)
+        K = int(k.value)
+        try:
+            idx = np.ctypeslib.as_array(idx_p, shape=(max(2 * K, 1),))[:2 * K].reshape(K, 2).T.copy()
+            freq = np.ctypeslib.as_array(freq_p, shape=(max(K, 1),))[:K].copy()
+        finally:
+            self._lib.scg_free(idx_p)
+            self._lib.scg_free(freq_p)
+        return dict(counts=counts[:self.n_pool[0]].copy(), indices=idx.astype(np.int32), freq=freq.astype(np.int32),
+                    total=int(total.value), barcode1_only=int(b1.value), barcode2_only=int(b2.value))
 
     def read_combo(self, stream=None):
         """Combo plans: (indices int32[2, K] sorted by (first, second), freq int32[K], total)."""

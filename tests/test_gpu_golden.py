@@ -35,6 +35,15 @@ def run_file_level(sc, c, tmp_path, gz=False):
                                                f2, c["template2"], c["reverse2"], c["mismatches2"], c["pool2"],
                                                c["randomized"], c["use_first"], False, 1)
         return {"counts": counts.tolist(), "total": total}
+    if k == "dual_diag":
+        f1, f2 = str(tmp_path / ("g1" + ext)), str(tmp_path / ("g2" + ext))
+        write_fastq(f1, c["reads1"], gz=gz)
+        write_fastq(f2, c["reads2"], gz=gz)
+        counts, (idx, freq), total, b1, b2 = sc.count_dual_barcodes(f1, c["template1"], c["reverse1"], c["mismatches1"], c["pool1"],
+                                                                    f2, c["template2"], c["reverse2"], c["mismatches2"], c["pool2"],
+                                                                    c["randomized"], c["use_first"], True, 1)
+        return {"counts": counts.tolist(), "indices": idx.tolist(), "freq": freq.tolist(), "total": total,
+                "barcode1_only": b1, "barcode2_only": b2}
     idx, mm = sc.match_barcodes(c["sequences"], c["choices"], c["substitutions"], c["reverse"])
     return {"index": idx.tolist(), "mismatches": mm.tolist()}
 

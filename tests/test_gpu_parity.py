@@ -171,3 +171,22 @@ def test_template_longer_than_64(sc, oracle, gpu):
             exp = oracle.count_single(reads, template, 2, pool, mm, True)
             got = run_single(sc, dict(reads=reads, template=template, strand=2, pool=pool, mismatches=mm, use_first=True), gpu)
             assert got[1] == exp[1] and np.array_equal(got[0], exp[0]), (flank, mm)
+
+
+@pytest.mark.parametrize("seed", range(5))
+def test_dual_diagnostics_random(sc, oracle, gpu, seed):
+    """include.invalid=TRUE: valid-pair counts, invalid combinations, barcode1/2-only tallies."""
+    rng = random.Random(6000 + seed)
+    for _ in range(20):
+        case = gen.random_dual_case(rng, hazard_free=True, max_mm=2)
+        exp = oracle.count_dual_diag(case["reads1"], case["reads2"], case["template1"], case["reverse1"], case["mismatches1"], case["pool1"],
+                                     case["template2"], case["reverse2"], case["mismatches2"], case["pool2"], case["randomized"], case["use_first"])
+        s1, o1 = sc.upload_reads(case["reads1"], gpu)
+        s2, o2 = sc.upload_reads(case["reads2"], gpu)
+        with sc.Plan.dual(case["template1"], case["reverse1"], case["mismatches1"], case["pool1"],
+                          case["template2"], case["reverse2"], case["mismatches2"], case["pool2"],
+                          case["randomized"], case["use_first"], diagnostics=True) as plan:
+            plan.count_paired(s1, s2, o1, o2)
+            got = plan.read_diagnostics()
+        for key in exp:
+            assert np.array_equal(np.asarray(exp[key]), np.asarray(got[key])), (key, case, exp, got)
