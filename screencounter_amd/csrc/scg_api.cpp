@@ -134,6 +134,7 @@ struct DevIndex {
         view.table0 = table0.as<uint4>();
         view.slot_mask = h.slot_mask; view.n_entries = h.n_entries; view.len = h.len; view.nseg = h.nseg;
         for (int s = 0; s < SCG_MAX_SEGMENTS; ++s) view.segmask[s] = h.segmask[s];
+        for (int c = 0; c < 4; ++c) view.nwalk[c] = h.nwalk[c];
     }
 };
 

@@ -18,7 +18,7 @@
 #define SCG_MAX_TEMPLATE 256   // reference: src/count_single_barcodes.cpp:37-47
 #define SCG_MAX_REGIONS 2      // reference: src/count_combo_barcodes_single.cpp:44-46
 #define SCG_MAX_BARCODE 32     // bases per variable region handled by the packed-key engine
-#define SCG_MAX_SEGMENTS 4     // pigeonhole segments of the library index (mismatch budgets <= 3)
+#define SCG_MAX_SEGMENTS 6     // hash tables ("segment groups") of the library index (mismatch budgets <= 3)
 #define SCG_MAX_SEEDS 4        // pigeonhole seeds of the constant-region scan (budgets <= 3)
 #define SCG_SEED_LEN 10        // constant bases per seed (at most)
 #define SCG_EMPTY_KEY (~0ull)
@@ -84,11 +84,16 @@ struct ScgTemplate {
     uint8_t rcode[SCG_MAX_TEMPLATE];
 };
 
-// Library index: every concrete barcode (IUPAC codes expanded) once, reachable through
-// nseg = budget + 1 hash tables keyed by disjoint segments of the barcode.  An entry within
-// Hamming distance <= c of a query agrees with it exactly on at least one of any c+1 segments,
-// so walking c+1 short chains and verifying each member by XOR + popcount finds every
-// neighbour.  Replaces the exact std::unordered_map + mismatch trie + per-thread caches of
+// Library index: every concrete barcode (IUPAC codes expanded) once, reachable through several hash
+// tables, each keyed by a GROUP of barcode positions (a plane-split mask).  The groups are chosen so
+// that an entry within Hamming distance <= c of a query agrees with it exactly on at least one of
+// the first nwalk[c] groups (pigeonhole):
+//   budget 0: the whole key;            budget 1: two halves;
+//   budget 2: the six pairs of four quarters, ordered {01},{23},{02},{13},{03},{12}
+//             (c = 0 needs one, c = 1 the first two, c = 2 all six; 10-base keys keep chains ~1 long);
+//   budget 3: four quarters (c + 1 of them);   wider budgets: no tables, dense scans.
+// Walking those short chains and verifying each member by XOR + popcount finds every neighbour.
+// Replaces the exact std::unordered_map + mismatch trie + per-thread caches of
 // kaori/BarcodeSearch.hpp:243-251 and kaori/MismatchTrie.hpp:446-501 with the same
 // unique-minimum semantics.
 struct ScgIndex {
@@ -101,8 +106,9 @@ struct ScgIndex {
     uint32_t slot_mask;
     int32_t n_entries;
     int32_t len;                // bases per key
-    int32_t nseg;               // 0 => no index (budget too wide): dense scan of `entries`
-    uint64_t segmask[SCG_MAX_SEGMENTS];   // plane-split mask of segment s
+    int32_t nseg;               // number of tables; 0 => budget too wide: dense scan of `entries`
+    int32_t nwalk[4];           // tables to walk for a query cap of 0..3
+    uint64_t segmask[SCG_MAX_SEGMENTS];   // plane-split position mask of table s
 };
 
 // (uid1, uid2) -> valid pair index, for dual barcodes (kaori/handlers/DualBarcodesPairedEnd.hpp:138-178).

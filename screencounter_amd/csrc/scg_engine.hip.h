@@ -131,8 +131,11 @@ __device__ __forceinline__ void index_search(const ScgIndex& X, const Query& q, 
         }
         return;
     }
-    // any cap + 1 segments suffice: at most cap of them can hold a mismatch
-    const int nwalk = cap + 1 < X.nseg ? cap + 1 : X.nseg;
+    // the first nwalk[cap] position groups suffice for a budget of cap (ScgIndex)
+    // (selected from SGPR copies: indexing the kernel-argument array with a per-lane cap would be a vector load)
+    const int w0 = __builtin_amdgcn_readfirstlane(X.nwalk[0]), w1 = __builtin_amdgcn_readfirstlane(X.nwalk[1]);
+    const int w2 = __builtin_amdgcn_readfirstlane(X.nwalk[2]), w3 = __builtin_amdgcn_readfirstlane(X.nwalk[3]);
+    const int nwalk = cap <= 0 ? w0 : (cap == 1 ? w1 : (cap == 2 ? w2 : w3));
     const uint64_t qkey = ((uint64_t)q.hi << 32) | q.lo;
     const uint64_t qother = ((uint64_t)q.other << 32) | q.other;
     const uint32_t nslots = X.slot_mask + 1u;

@@ -39,7 +39,8 @@ struct HostIndex {
     int32_t n_entries = 0;
     int32_t nseg = 0;
     uint32_t slot_mask = 0;
-    uint64_t segmask[SCG_MAX_SEGMENTS] = {0, 0, 0, 0};
+    int32_t nwalk[4] = {0, 0, 0, 0};
+    uint64_t segmask[SCG_MAX_SEGMENTS] = {0, 0, 0, 0, 0, 0};
     std::vector<uint32_t> entries;   // 4 words per entry: key lo, key hi, value, 0
     std::vector<int32_t> next;       // [nseg][n_entries]
     std::vector<uint32_t> slots;     // 2 words per slot: tag, head + 1 ; [nseg][slot_mask + 1]

@@ -221,11 +221,33 @@ void finish_index(HostIndex& X, const std::vector<uint64_t>& keys, const std::ve
         X.entries[4 * e + 2] = static_cast<uint32_t>(vals[e]);
         X.entries[4 * e + 3] = 0xFFFFFFFFu;   // no chain link (-1) until the segment tables are built
     }
-    int nseg = max_mm + 1;
-    if (nseg > SCG_MAX_SEGMENTS) {
+    // position groups (see ScgIndex): masks over `parts` equal slices of the barcode
+    auto slice = [&](int part, int parts) -> uint64_t {
+        int a = static_cast<int>(static_cast<int64_t>(part) * len / parts);
+        int b = static_cast<int>(static_cast<int64_t>(part + 1) * len / parts);
+        uint64_t m32 = (b - a >= 32) ? 0xFFFFFFFFull : (((1ull << (b - a)) - 1ull) << a);
+        return m32 | (m32 << 32);
+    };
+    std::vector<uint64_t> groups;
+    if (max_mm == 0) {
+        groups.push_back(slice(0, 1));
+        X.nwalk[0] = X.nwalk[1] = X.nwalk[2] = X.nwalk[3] = 1;
+    } else if (max_mm == 1) {
+        groups.push_back(slice(0, 2));
+        groups.push_back(slice(1, 2));
+        X.nwalk[0] = 1; X.nwalk[1] = X.nwalk[2] = X.nwalk[3] = 2;
+    } else if (max_mm == 2) {
+        static const int pairs[6][2] = {{0, 1}, {2, 3}, {0, 2}, {1, 3}, {0, 3}, {1, 2}};
+        for (auto& pr : pairs) groups.push_back(slice(pr[0], 4) | slice(pr[1], 4));
+        X.nwalk[0] = 1; X.nwalk[1] = 2; X.nwalk[2] = X.nwalk[3] = 6;
+    } else if (max_mm == 3) {
+        for (int q = 0; q < 4; ++q) groups.push_back(slice(q, 4));
+        X.nwalk[0] = 1; X.nwalk[1] = 2; X.nwalk[2] = 3; X.nwalk[3] = 4;
+    } else {
         X.nseg = 0;            // budget too wide for pigeonhole tables: dense scans
         return;
     }
+    const int nseg = static_cast<int>(groups.size());
     X.nseg = nseg;
     uint32_t cap = 16;
     while (cap < keys.size() * 2) cap <<= 1;
@@ -233,10 +255,7 @@ void finish_index(HostIndex& X, const std::vector<uint64_t>& keys, const std::ve
     X.slots.assign(static_cast<size_t>(nseg) * cap * 2, 0);
     X.next.assign(static_cast<size_t>(nseg) * keys.size(), -1);
     for (int sgm = 0; sgm < nseg; ++sgm) {
-        int a = static_cast<int>(static_cast<int64_t>(sgm) * len / nseg);
-        int b = static_cast<int>(static_cast<int64_t>(sgm + 1) * len / nseg);
-        uint64_t m32 = (b - a >= 32) ? 0xFFFFFFFFull : (((1ull << (b - a)) - 1ull) << a);
-        uint64_t mask = m32 | (m32 << 32);
+        const uint64_t mask = groups[sgm];
         X.segmask[sgm] = mask;
         uint32_t* slots = X.slots.data() + static_cast<size_t>(sgm) * cap * 2;
         int32_t* next = X.next.data() + static_cast<size_t>(sgm) * keys.size();
