@@ -173,6 +173,8 @@ struct scg_plan {
     DevIndex tab[2];
     DevPairTable pairs;
     DevBuf own_counters;
+    DevBuf replicas;     // privatised counter copies (ScgCounters); empty when n_counters is large
+    int replica_shift = 0;   // log2(replicas)
     DevBuf error_flag;   // set by a staged kernel that met a read longer than the declared maximum
     int32_t* counters = nullptr;
     int64_t n_counters = 0;
@@ -201,6 +203,13 @@ struct scg_plan {
         own_counters.alloc(static_cast<size_t>(n_counters) * sizeof(int32_t));
         counters = own_counters.as<int32_t>();
         HIP_CHECK(hipMemset(counters, 0, static_cast<size_t>(n_counters) * sizeof(int32_t)));
+        // enough replicas that ~2^20 distinct addresses take the atomics
+        replica_shift = 0;
+        while (replica_shift < 12 && (n_counters << (replica_shift + 1)) <= (int64_t(1) << 20)) ++replica_shift;
+        if (replica_shift > 0) {
+            replicas.alloc((static_cast<size_t>(n_counters) << replica_shift) * sizeof(int32_t));
+            HIP_CHECK(hipMemset(replicas.p, 0, replicas.bytes));
+        }
         error_flag.alloc(sizeof(int32_t));
         HIP_CHECK(hipMemset(error_flag.p, 0, sizeof(int32_t)));
         // host copies are no longer needed
@@ -360,6 +369,24 @@ std::unique_ptr<scg_plan> compile_dual(const char* constant1, int reverse1, int 
     return P;
 }
 
+ScgCounters plan_counters(const scg_plan* P) {
+    ScgCounters c;
+    if (P->replica_shift > 0) {
+        c.base = P->replicas.as<int32_t>();
+        c.replica_shift = static_cast<uint32_t>(P->replica_shift);
+        c.replica_mask = (1u << P->replica_shift) - 1u;
+    } else {
+        c.base = P->counters; c.replica_mask = 0; c.replica_shift = 0;
+    }
+    return c;
+}
+
+void fold_replicas(scg_plan* P, hipStream_t stream) {
+    if (P->replica_shift > 0) {
+        HIP_CHECK(scg::launch_fold(P->replicas.as<int32_t>(), P->replica_shift, P->n_counters, P->counters, stream));
+    }
+}
+
 void launch_batch(scg_plan* P, const ScgReads& R, int64_t n, hipStream_t stream) {
     scg_plan::Timer timer(P, stream);
     if (P->kind == scg_plan::SINGLE) {
@@ -369,7 +396,7 @@ void launch_batch(scg_plan* P, const ScgReads& R, int64_t n, hipStream_t stream)
         sp.index = P->tab[0].view;
         sp.max_mm = P->max_mm1; sp.use_first = P->use_first;
         sp.fwd = P->ht1.fwd; sp.rev = P->ht1.rev;
-        HIP_CHECK(scg::launch_single(sp, P->ht1.t.len, R, n, P->counters, P->error_flag.as<int32_t>(), stream));
+        HIP_CHECK(scg::launch_single(sp, P->ht1.t.len, R, n, plan_counters(P), P->error_flag.as<int32_t>(), stream));
     } else {
         ScgComboParams cp;
         cp.scan = P->scan1;
@@ -378,9 +405,10 @@ void launch_batch(scg_plan* P, const ScgReads& R, int64_t n, hipStream_t stream)
         cp.n_pool[0] = P->n_pool[0]; cp.n_pool[1] = P->n_pool[1];
         cp.max_mm = P->max_mm1; cp.use_first = P->use_first;
         cp.fwd = P->ht1.fwd; cp.rev = P->ht1.rev;
-        HIP_CHECK(scg::launch_combo(cp, P->ht1.t.len, R, n, P->counters, P->error_flag.as<int32_t>(), stream));
+        HIP_CHECK(scg::launch_combo(cp, P->ht1.t.len, R, n, plan_counters(P), P->error_flag.as<int32_t>(), stream));
     }
     timer.stop();
+    fold_replicas(P, stream);
     P->total += n;
 }
 
@@ -393,8 +421,9 @@ void launch_batch_paired(scg_plan* P, const ScgReads& R1, const ScgReads& R2, in
     dp.rev1 = P->rev1; dp.rev2 = P->rev2; dp.max_mm1 = P->max_mm1; dp.max_mm2 = P->max_mm2;
     dp.randomized = P->randomized; dp.use_first = P->use_first;
     dp.diagnostics = P->diagnostics; dp.n_pool = P->n_pool[0]; dp.n_uid2 = static_cast<int32_t>(P->first2.size());
-    HIP_CHECK(scg::launch_dual(dp, std::max(P->ht1.t.len, P->ht2.t.len), R1, R2, n, P->counters, P->error_flag.as<int32_t>(), stream));
+    HIP_CHECK(scg::launch_dual(dp, std::max(P->ht1.t.len, P->ht2.t.len), R1, R2, n, plan_counters(P), P->error_flag.as<int32_t>(), stream));
     timer.stop();
+    fold_replicas(P, stream);
     P->total += n;
 }
 

@@ -123,6 +123,20 @@ struct ScgPairTable {
     const int32_t* list_vals;
 };
 
+// Where a kernel's atomic increments go.  Hot counters (small libraries, skewed screens, the
+// barcode1-only tally) would serialise tens of millions of atomics on a few addresses, so the
+// plan keeps `replicas` privatised copies of the counter array; a lane adds to the copy picked by
+// its global id and a fold kernel sums the copies into the plan's counters after every launch.
+// Copies of one counter are adjacent (element (i, r) at i * replicas + r), so the lanes of a wave
+// that hit the same hot counter add into one contiguous 256-byte run -- the shape global atomics
+// run fastest at -- and the fold reads each counter's copies as one coalesced segment.
+// replica_shift == 0 means the counter array is large enough to be used directly.
+struct ScgCounters {
+    int32_t* base;
+    uint32_t replica_mask;      // replicas - 1 (power of two)
+    uint32_t replica_shift;     // log2(replicas)
+};
+
 struct ScgReads {
     const uint8_t* seqs;
     const uint32_t* offsets;  // n + 1 entries, or nullptr for fixed-length reads

@@ -34,6 +34,12 @@ struct Read {
     int n;
 };
 
+// One increment of counter i (see ScgCounters).
+__device__ __forceinline__ void count_one(const ScgCounters& C, int64_t i) {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    atomicAdd(C.base + ((i << C.replica_shift) | (int64_t)(gid & C.replica_mask)), 1);
+}
+
 __device__ __forceinline__ Read get_read(const ScgReads& R, int64_t i) {
     Read r;
     if (R.offsets) {

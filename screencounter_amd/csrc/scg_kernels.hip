@@ -57,12 +57,12 @@ __device__ __forceinline__ int single_read(const ScgSingleParams& P, const Read&
 }
 
 __global__ __launch_bounds__(BLOCK) void single_kernel(ScgSingleParams P, ScgReads R, int64_t n_reads,
-                                                        int32_t* __restrict__ counts) {
+                                                        ScgCounters counts) {
     int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n_reads) return;
     Read rd = get_read(R, i);
     int idx = single_read(P, rd);
-    if (idx >= 0) atomicAdd(&counts[idx], 1);
+    if (idx >= 0) count_one(counts, idx);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -117,12 +117,12 @@ __device__ __forceinline__ int combo_read(const ScgComboParams& P, const Read& r
 }
 
 __global__ __launch_bounds__(BLOCK) void combo_kernel(ScgComboParams P, ScgReads R, int64_t n_reads,
-                                                       int32_t* __restrict__ cells) {
+                                                       ScgCounters cells) {
     int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n_reads) return;
     Read rd = get_read(R, i);
     int best_id[SCG_MAX_REGIONS] = {0, 0};
-    if (combo_read(P, rd, best_id)) atomicAdd(&cells[(int64_t)best_id[0] * P.n_pool[1] + best_id[1]], 1);
+    if (combo_read(P, rd, best_id)) count_one(cells, (int64_t)best_id[0] * P.n_pool[1] + best_id[1]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -207,11 +207,9 @@ __device__ __forceinline__ bool mate_search(const ScgTemplate* T, const ScgIndex
 // CombinatorialBarcodesPairedEnd::process (handlers/CombinatorialBarcodesPairedEnd.hpp:167-242) on a
 // pair the dual search rejected.  S1(x)/S2(x) = search of template 1 / 2 on mate x (0 = a, 1 = b).
 template<class S1, class S2>
-__device__ __forceinline__ void diagnose_pair(const ScgDualParams& P, S1 s1, S2 s2, int32_t* __restrict__ counters) {
-    int32_t* b1_only = counters + P.n_pool;
-    int32_t* b2_only = b1_only + 1;
-    int32_t* cells = b2_only + 1;
-    auto emit = [&](int u1, int u2) { atomicAdd(&cells[(int64_t)u1 * P.n_uid2 + u2], 1); };
+__device__ __forceinline__ void diagnose_pair(const ScgDualParams& P, S1 s1, S2 s2, const ScgCounters& counters) {
+    const int64_t b1_only = P.n_pool, b2_only = b1_only + 1, cells = b2_only + 1;
+    auto emit = [&](int u1, int u2) { count_one(counters, cells + (int64_t)u1 * P.n_uid2 + u2); };
     int i1, m1, i2, m2;
     const bool f1 = s1(0, i1, m1), f2 = s2(1, i2, m2);
     if (P.use_first) {
@@ -221,16 +219,16 @@ __device__ __forceinline__ void diagnose_pair(const ScgDualParams& P, S1 s1, S2 
             int j1, n1, j2, n2;
             const bool g1 = s1(1, j1, n1), g2 = s2(0, j2, n2);
             if (g1 && g2) emit(j1, j2);
-            else if (f1 || g1) atomicAdd(b1_only, 1);
-            else if (f2 || g2) atomicAdd(b2_only, 1);
+            else if (f1 || g1) count_one(counters, b1_only);
+            else if (f2 || g2) count_one(counters, b2_only);
         } else {
-            if (f1) atomicAdd(b1_only, 1);
-            else if (f2) atomicAdd(b2_only, 1);
+            if (f1) count_one(counters, b1_only);
+            else if (f2) count_one(counters, b2_only);
         }
     } else if (!P.randomized) {
         if (f1 && f2) emit(i1, i2);
-        else if (f1) atomicAdd(b1_only, 1);
-        else if (f2) atomicAdd(b2_only, 1);
+        else if (f1) count_one(counters, b1_only);
+        else if (f2) count_one(counters, b2_only);
     } else if (f1 && f2) {
         int j1, n1, j2, n2;
         const bool g1 = s1(1, j1, n1), g2 = s2(0, j2, n2);
@@ -246,8 +244,8 @@ __device__ __forceinline__ void diagnose_pair(const ScgDualParams& P, S1 s1, S2 
         int j1, n1, j2, n2;
         const bool g1 = s1(1, j1, n1), g2 = s2(0, j2, n2);
         if (g1 && g2) emit(j1, j2);
-        else if (f1 || g1) atomicAdd(b1_only, 1);
-        else if (f2 || g2) atomicAdd(b2_only, 1);
+        else if (f1 || g1) count_one(counters, b1_only);
+        else if (f2 || g2) count_one(counters, b2_only);
     }
 }
 
@@ -270,13 +268,13 @@ __device__ __forceinline__ int dual_pair(const ScgDualParams& P, const Read& a, 
 }
 
 __global__ __launch_bounds__(BLOCK) void dual_kernel(ScgDualParams P, ScgReads R1, ScgReads R2, int64_t n_pairs,
-                                                      int32_t* __restrict__ counts) {
+                                                      ScgCounters counts) {
     int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n_pairs) return;
     Read a = get_read(R1, i), b = get_read(R2, i);
     int idx = dual_pair(P, a, b);
     if (idx >= 0) {
-        atomicAdd(&counts[idx], 1);
+        count_one(counts, idx);
     } else if (P.diagnostics) {
         diagnose_pair(P,
             [&](int which, int& index, int& mism) { return mate_search(P.tmpl1, P.index1, P.rev1 != 0, P.max_mm1, P.use_first != 0, which ? b : a, index, mism); },
@@ -326,7 +324,7 @@ __device__ __forceinline__ int single_read_staged(const ScgSingleParams& P, cons
 // NC < NW ("compact"): candidate positions fit 32*NC bits and the plan's seeds allow it (ScgScan::compact_ok).
 template<int NW, int NT, int NC>
 __global__ __launch_bounds__(STAGE_BLOCK) __attribute__((amdgpu_num_sgpr(80))) void single_staged_kernel(ScgSingleParams P, ScgReads R, int64_t n_reads,
-                                                                   int32_t* __restrict__ counts, int32_t* __restrict__ error_flag) {
+                                                                   ScgCounters counts, int32_t* __restrict__ error_flag) {
     __shared__ Tile<NW> tile;
     const int64_t r0 = (int64_t)blockIdx.x * STAGE_BLOCK;
     const int nr = (int)((n_reads - r0) < STAGE_BLOCK ? (n_reads - r0) : STAGE_BLOCK);
@@ -350,7 +348,7 @@ __global__ __launch_bounds__(STAGE_BLOCK) __attribute__((amdgpu_num_sgpr(80))) v
     } else {
         idx = single_read_staged<NW, NT, NC>(P, tile, sr, R.ablate);
     }
-    if (idx >= 0) atomicAdd(&counts[idx], 1);
+    if (idx >= 0) count_one(counts, idx);
 }
 
 template<int NW, int NT>
@@ -378,7 +376,7 @@ __device__ __forceinline__ bool combo_candidate_staged(const ScgComboParams& P, 
 
 template<int NW, int NT, int NC>
 __global__ __launch_bounds__(STAGE_BLOCK) __attribute__((amdgpu_num_sgpr(80))) void combo_staged_kernel(ScgComboParams P, ScgReads R, int64_t n_reads,
-                                                                  int32_t* __restrict__ cells, int32_t* __restrict__ error_flag) {
+                                                                  ScgCounters cells, int32_t* __restrict__ error_flag) {
     __shared__ Tile<NW> tile;
     const int64_t r0 = (int64_t)blockIdx.x * STAGE_BLOCK;
     const int nr = (int)((n_reads - r0) < STAGE_BLOCK ? (n_reads - r0) : STAGE_BLOCK);
@@ -423,7 +421,7 @@ __global__ __launch_bounds__(STAGE_BLOCK) __attribute__((amdgpu_num_sgpr(80))) v
             }
         }
     }
-    if (found) atomicAdd(&cells[(int64_t)best_id[0] * P.n_pool[1] + best_id[1]], 1);
+    if (found) count_one(cells, (int64_t)best_id[0] * P.n_pool[1] + best_id[1]);
 }
 
 // Staged counterpart of mate_search.
@@ -509,7 +507,7 @@ __device__ __forceinline__ void dual_orientation_staged(const ScgDualParams& P, 
 // that the ordinary kernel does not pay for it).
 template<int NW, int NT, int NC, bool DIAG>
 __global__ __launch_bounds__(STAGE_BLOCK) void dual_staged_kernel(ScgDualParams P, ScgReads R1, ScgReads R2, int64_t n_pairs,
-                                                                 int32_t* __restrict__ counts, int32_t* __restrict__ error_flag) {
+                                                                 ScgCounters counts, int32_t* __restrict__ error_flag) {
     __shared__ Tile<NW> tile1;
     __shared__ Tile<NW> tile2;
     const int64_t r0 = (int64_t)blockIdx.x * STAGE_BLOCK;
@@ -565,7 +563,7 @@ __global__ __launch_bounds__(STAGE_BLOCK) void dual_staged_kernel(ScgDualParams 
                 counts);
         }
     }
-    if (idx >= 0) atomicAdd(&counts[idx], 1);
+    if (idx >= 0) count_one(counts, idx);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -680,7 +678,7 @@ hipError_t dispatch_shape(int max_len, int tmpl_len, Args&&... args) {
 }
 
 template<int NW, int NT> struct LaunchSingle {
-    static hipError_t go(const ScgSingleParams& P, const ScgReads& R, int64_t n, int32_t* counts, int32_t* flag, hipStream_t stream) {
+    static hipError_t go(const ScgSingleParams& P, const ScgReads& R, int64_t n, const ScgCounters& counts, int32_t* flag, hipStream_t stream) {
         // compact variant: all candidate positions (0 .. max_len - T) fit 3 words of a 5-word read
         if (NW == 5 && P.scan.compact_ok && R.max_len - P.scan.len + 1 <= 96) {
             hipLaunchKernelGGL((single_staged_kernel<NW, NT, (NW == 5 ? 3 : NW)>), dim3(grid_for(n)), dim3(STAGE_BLOCK), 0, stream, P, R, n, counts, flag);
@@ -691,7 +689,7 @@ template<int NW, int NT> struct LaunchSingle {
     }
 };
 template<int NW, int NT> struct LaunchCombo {
-    static hipError_t go(const ScgComboParams& P, const ScgReads& R, int64_t n, int32_t* cells, int32_t* flag, hipStream_t stream) {
+    static hipError_t go(const ScgComboParams& P, const ScgReads& R, int64_t n, const ScgCounters& cells, int32_t* flag, hipStream_t stream) {
         if (NW == 5 && P.scan.compact_ok && R.max_len - P.scan.len + 1 <= 96) {
             hipLaunchKernelGGL((combo_staged_kernel<NW, NT, (NW == 5 ? 3 : NW)>), dim3(grid_for(n)), dim3(STAGE_BLOCK), 0, stream, P, R, n, cells, flag);
         } else {
@@ -701,7 +699,7 @@ template<int NW, int NT> struct LaunchCombo {
     }
 };
 template<int NW, int NT> struct LaunchDual {
-    static hipError_t go(const ScgDualParams& P, const ScgReads& R1, const ScgReads& R2, int64_t n, int32_t* counts, int32_t* flag, hipStream_t stream) {
+    static hipError_t go(const ScgDualParams& P, const ScgReads& R1, const ScgReads& R2, int64_t n, const ScgCounters& counts, int32_t* flag, hipStream_t stream) {
         const int max_len = R1.max_len > R2.max_len ? R1.max_len : R2.max_len;
         const int min_t = P.scan1.len < P.scan2.len ? P.scan1.len : P.scan2.len;
         const bool compact = NW == 5 && P.scan1.compact_ok && P.scan2.compact_ok && max_len - min_t + 1 <= 96;
@@ -722,7 +720,7 @@ template<int NW, int NT> struct LaunchDual {
 // or an unknown maximum length take the byte-wise general kernels.
 static bool use_general(int max_len) { return force_general() || max_len <= 0 || max_len > 320; }
 
-hipError_t launch_single(const ScgSingleParams& P, int tmpl_len, const ScgReads& R, int64_t n, int32_t* counts, int32_t* flag, hipStream_t stream) {
+hipError_t launch_single(const ScgSingleParams& P, int tmpl_len, const ScgReads& R, int64_t n, const ScgCounters& counts, int32_t* flag, hipStream_t stream) {
     if (n <= 0) return hipSuccess;
     if (use_general(R.max_len)) {
         hipLaunchKernelGGL(single_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, stream, P, R, n, counts);
@@ -731,7 +729,7 @@ hipError_t launch_single(const ScgSingleParams& P, int tmpl_len, const ScgReads&
     return dispatch_shape<LaunchSingle>(R.max_len, tmpl_len, P, R, n, counts, flag, stream);
 }
 
-hipError_t launch_combo(const ScgComboParams& P, int tmpl_len, const ScgReads& R, int64_t n, int32_t* cells, int32_t* flag, hipStream_t stream) {
+hipError_t launch_combo(const ScgComboParams& P, int tmpl_len, const ScgReads& R, int64_t n, const ScgCounters& cells, int32_t* flag, hipStream_t stream) {
     if (n <= 0) return hipSuccess;
     if (use_general(R.max_len)) {
         hipLaunchKernelGGL(combo_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, stream, P, R, n, cells);
@@ -740,7 +738,7 @@ hipError_t launch_combo(const ScgComboParams& P, int tmpl_len, const ScgReads& R
     return dispatch_shape<LaunchCombo>(R.max_len, tmpl_len, P, R, n, cells, flag, stream);
 }
 
-hipError_t launch_dual(const ScgDualParams& P, int tmpl_len, const ScgReads& R1, const ScgReads& R2, int64_t n, int32_t* counts, int32_t* flag, hipStream_t stream) {
+hipError_t launch_dual(const ScgDualParams& P, int tmpl_len, const ScgReads& R1, const ScgReads& R2, int64_t n, const ScgCounters& counts, int32_t* flag, hipStream_t stream) {
     if (n <= 0) return hipSuccess;
     const int lo_len = R1.max_len < R2.max_len ? R1.max_len : R2.max_len;
     if (use_general(lo_len) || use_general(R1.max_len > R2.max_len ? R1.max_len : R2.max_len)) {
@@ -749,6 +747,42 @@ hipError_t launch_dual(const ScgDualParams& P, int tmpl_len, const ScgReads& R1,
     }
     const int max_len = R1.max_len > R2.max_len ? R1.max_len : R2.max_len;
     return dispatch_shape<LaunchDual>(max_len, tmpl_len, P, R1, R2, n, counts, flag, stream);
+}
+
+// counters[i] += sum of counter i's replicas, replicas cleared (see ScgCounters).  Few replicas: one
+// lane per counter; many (small, hot counter arrays): one wave per counter with a shuffle reduction.
+// Exchanges, not load + store: kernels of another stream may be adding to the replicas right now.
+__global__ __launch_bounds__(BLOCK) void fold_kernel(int32_t* __restrict__ replicas, int shift, int64_t n,
+                                                     int32_t* __restrict__ counters) {
+    const int R = 1 << shift;
+    if (R < 64) {
+        int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+        if (i >= n) return;
+        int32_t* p = replicas + (i << shift);
+        int32_t sum = 0;
+        for (int r = 0; r < R; ++r) {
+            if (p[r]) sum += atomicExch(p + r, 0);
+        }
+        if (sum) atomicAdd(&counters[i], sum);
+    } else {
+        int64_t i = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;      // one wave per counter
+        if (i >= n) return;
+        const int lane = threadIdx.x & 63;
+        int32_t* p = replicas + (i << shift);
+        int32_t sum = 0;
+        for (int r = lane; r < R; r += 64) {
+            if (p[r]) sum += atomicExch(p + r, 0);
+        }
+        for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
+        if (lane == 0 && sum) atomicAdd(&counters[i], sum);
+    }
+}
+
+hipError_t launch_fold(int32_t* replicas, int shift, int64_t n, int32_t* counters, hipStream_t stream) {
+    if (n <= 0 || shift <= 0) return hipSuccess;
+    const int64_t threads = (1 << shift) < 64 ? n : n * 64;
+    hipLaunchKernelGGL(fold_kernel, dim3(grid_for(threads)), dim3(BLOCK), 0, stream, replicas, shift, n, counters);
+    return hipGetLastError();
 }
 
 hipError_t launch_match(const ScgIndex& tab, const uint8_t* d_seqs, int32_t n, int cap, int reverse,
