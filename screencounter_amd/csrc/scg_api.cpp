@@ -12,6 +12,7 @@
 #include <cstring>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "scg_host.h"
@@ -583,9 +584,70 @@ void diagnostics_from_counters(const scg_plan* P, const std::vector<int32_t>& al
     *idx_out = oi; *freq_out = of; *k_out = static_cast<int64_t>(freq.size());
 }
 
-// Both FASTQ files of a paired-end run, in lock-step by read count (process_data.hpp:246-290).
-void count_paired_files(scg_plan* P, scg::FastqStream& fq1, scg::FastqStream& fq2) {
+// Appends the reads [from, to) of `src` to `dst`.
+void append_reads(scg::ReadBatch& dst, const scg::ReadBatch& src, int64_t from, int64_t to) {
+    if (to <= from) return;
+    const uint64_t b0 = src.offsets[from], b1 = src.offsets[to];
+    const uint64_t base = dst.seqs.size();
+    dst.seqs.insert(dst.seqs.end(), src.seqs.begin() + b0, src.seqs.begin() + b1);
+    for (int64_t i = from + 1; i <= to; ++i) dst.offsets.push_back(base + (src.offsets[i] - b0));
+}
+
+// Both FASTQ files of a paired-end run (process_data.hpp:224-340).  Plain files are parsed by the
+// multi-threaded reader, each file on its own; the two read streams are re-cut into batches of
+// equal read counts (pair i = read i of both files).  gzip input or anything unusual falls back to
+// the sequential readers in lock-step.  Unequal read counts => the reference's error.
+void count_paired_files(scg_plan* P, const char* path1, const char* path2, scg::FastqStream& fq1, scg::FastqStream& fq2, int nthreads) {
     Stager st;
+    auto launch_pair = [&](const scg::ReadBatch& x, const scg::ReadBatch& y) {
+        auto& s = st.acquire();
+        ScgReads R1 = st.stage(s, 0, x);
+        ScgReads R2 = st.stage(s, 1, y);
+        launch_batch_paired(P, R1, R2, x.size(), s.stream);
+        s.busy = true;
+    };
+    const int threads = scg::default_host_threads(nthreads);
+    if (threads > 1 && scg::ParallelFastq::is_plain_file(path1) && scg::ParallelFastq::is_plain_file(path2)) {
+        const int half = threads > 3 ? threads / 2 : 2;
+        scg::ParallelFastq pf1(path1, half), pf2(path2, half);
+        scg::ReadBatch q1, q2;          // reads parsed but not yet paired
+        q1.clear(); q2.clear();
+        std::vector<scg::ReadBatch> w1, w2;
+        bool more1 = true, more2 = true, odd = false;
+        while (more1 || more2) {
+            // advance whichever stream is behind (both at first)
+            const bool need1 = more1 && q1.size() <= q2.size();
+            const bool need2 = more2 && q2.size() <= q1.size();
+            std::thread t;
+            bool got2 = false;
+            if (need2) t = std::thread([&] { got2 = pf2.next_window(w2); });
+            bool got1 = need1 ? pf1.next_window(w1) : false;
+            if (t.joinable()) t.join();
+            if (need1) { if (got1) for (auto& b : w1) append_reads(q1, b, 0, b.size()); else more1 = false; }
+            if (need2) { if (got2) for (auto& b : w2) append_reads(q2, b, 0, b.size()); else more2 = false; }
+            if (pf1.unusual() || pf2.unusual()) { odd = true; break; }
+            const int64_t n = std::min(q1.size(), q2.size());
+            if (n > 0) {
+                scg::ReadBatch a, b2, r1, r2;
+                a.clear(); b2.clear(); r1.clear(); r2.clear();
+                append_reads(a, q1, 0, n); append_reads(r1, q1, n, q1.size());
+                append_reads(b2, q2, 0, n); append_reads(r2, q2, n, q2.size());
+                launch_pair(a, b2);
+                q1.seqs.swap(r1.seqs); q1.offsets.swap(r1.offsets);
+                q2.seqs.swap(r2.seqs); q2.offsets.swap(r2.offsets);
+            }
+            if (!need1 && !need2) break;
+        }
+        st.drain();
+        if (!odd) {
+            if (q1.size() != q2.size()) {
+                throw Error(SCG_ERR_IO, "different number of reads in paired FASTQ files");   // process_data.hpp:284-285
+            }
+            return;
+        }
+        HIP_CHECK(hipMemset(P->counters, 0, static_cast<size_t>(P->n_counters) * sizeof(int32_t)));
+        P->total = 0;
+    }
     scg::ReadBatch b1, b2;
     for (;;) {
         bool more1 = fq1.next_batch(b1, BATCH_READS / 4, INT64_MAX);
@@ -594,11 +656,7 @@ void count_paired_files(scg_plan* P, scg::FastqStream& fq1, scg::FastqStream& fq
             throw Error(SCG_ERR_IO, "different number of reads in paired FASTQ files");   // process_data.hpp:284-285
         }
         if (!more1 && !more2) break;
-        auto& s = st.acquire();
-        ScgReads R1 = st.stage(s, 0, b1);
-        ScgReads R2 = st.stage(s, 1, b2);
-        launch_batch_paired(P, R1, R2, b1.size(), s.stream);
-        s.busy = true;
+        launch_pair(b1, b2);
     }
     st.drain();
 }
@@ -822,7 +880,6 @@ int scg_count_dual_barcodes(const char* path1, const char* constant1, int revers
                             const char* path2, const char* constant2, int reverse2, int mismatches2, const char* const* pool2,
                             int32_t n_pool, int randomized, int use_first, int diagnostics, int nthreads,
                             int32_t* counts_out, int32_t* total_out, char* err, size_t errcap) {
-    (void)nthreads;
     return guarded(err, errcap, [&] {
         if (!path1 || !path2 || !counts_out || !total_out) throw Error(SCG_ERR_INVALID, "null argument");
         scg::FastqStream fq1(path1);                                         // src/count_dual_barcodes.cpp:93-97
@@ -833,7 +890,7 @@ int scg_count_dual_barcodes(const char* path1, const char* constant1, int revers
         auto P = compile_dual(constant1, reverse1, mismatches1, pool1, constant2, reverse2, mismatches2, pool2, n_pool, randomized, use_first);
         P->to_device(-1);
         DeviceGuard g(P->device);
-        count_paired_files(P.get(), fq1, fq2);
+        count_paired_files(P.get(), path1, path2, fq1, fq2, nthreads);
         read_counters(P.get(), counts_out);
         *total_out = static_cast<int32_t>(P->total);
     });
@@ -845,7 +902,6 @@ int scg_count_dual_barcodes_diagnostics(const char* path1, const char* constant1
                                         int32_t* counts_out, int32_t** invalid_indices_out, int32_t** invalid_freq_out, int64_t* k_out,
                                         int32_t* total_out, int32_t* barcode1_only_out, int32_t* barcode2_only_out,
                                         char* err, size_t errcap) {
-    (void)nthreads;
     return guarded(err, errcap, [&] {
         if (!path1 || !path2 || !counts_out || !invalid_indices_out || !invalid_freq_out || !k_out || !total_out ||
             !barcode1_only_out || !barcode2_only_out) {
@@ -856,7 +912,7 @@ int scg_count_dual_barcodes_diagnostics(const char* path1, const char* constant1
         auto P = compile_dual(constant1, reverse1, mismatches1, pool1, constant2, reverse2, mismatches2, pool2, n_pool, randomized, use_first, 1);
         P->to_device(-1);
         DeviceGuard g(P->device);
-        count_paired_files(P.get(), fq1, fq2);
+        count_paired_files(P.get(), path1, path2, fq1, fq2, nthreads);
         std::vector<int32_t> all(static_cast<size_t>(P->n_counters) + 1);
         read_counters(P.get(), all.data());
         diagnostics_from_counters(P.get(), all, counts_out, invalid_indices_out, invalid_freq_out, k_out, barcode1_only_out, barcode2_only_out);

@@ -121,3 +121,30 @@ def test_empty_and_short_inputs(sc, gpu, tmp_path):
     write_fastq(fq, ["", "A", "ACGTAATGC", "ACGTAATGCA"])     # shorter than the template, then exact fit
     counts, total = sc.count_single_barcodes(fq, "ACGT--TGCA", 2, ["AA", "CC"], 0, True, 1)
     assert counts.tolist() == [1, 0] and total == 4
+
+
+def test_paired_files_parallel_stager(sc, oracle, gpu, tmp_path, monkeypatch):
+    """Two plain FASTQ files with ragged reads through the multi-threaded paired stager (tiny pieces
+    => many windows whose read counts differ between the files) == the oracle on the parsed reads."""
+    import random
+    from tests import gen
+    rng = random.Random(404)
+    case = gen.random_dual_case(rng, hazard_free=True, sizes=(3000,), max_mm=1)
+    f1, f2 = str(tmp_path / "p1.fastq"), str(tmp_path / "p2.fastq")
+    write_fastq(f1, case["reads1"])
+    write_fastq(f2, case["reads2"])
+    exp = oracle.count_dual(case["reads1"], case["reads2"], case["template1"], case["reverse1"], case["mismatches1"], case["pool1"],
+                            case["template2"], case["reverse2"], case["mismatches2"], case["pool2"], case["randomized"], case["use_first"])
+    monkeypatch.setenv("SCG_HOST_THREADS", "6")
+    for piece_kb in ("2", "13", "4096"):
+        monkeypatch.setenv("SCG_FASTQ_PIECE_KB", piece_kb)
+        got = sc.count_dual_barcodes(f1, case["template1"], case["reverse1"], case["mismatches1"], case["pool1"],
+                                     f2, case["template2"], case["reverse2"], case["mismatches2"], case["pool2"],
+                                     case["randomized"], case["use_first"], False, 1)
+        assert got[1] == exp[1] == 3000 and np.array_equal(got[0], exp[0]), piece_kb
+    # one read fewer in the second file
+    write_fastq(f2, case["reads2"][:-1])
+    with pytest.raises(sc.ScgError, match="different number of reads in paired FASTQ files"):
+        sc.count_dual_barcodes(f1, case["template1"], case["reverse1"], case["mismatches1"], case["pool1"],
+                               f2, case["template2"], case["reverse2"], case["mismatches2"], case["pool2"],
+                               case["randomized"], case["use_first"], False, 1)
