@@ -492,15 +492,27 @@ void count_single_end_file(scg_plan* P, const char* path, scg::FastqStream& fq, 
     const int threads = scg::default_host_threads(nthreads);
     if (threads > 1 && scg::ParallelFastq::is_plain_file(path)) {
         scg::ParallelFastq pf(path, threads);
-        std::vector<scg::ReadBatch> window;
-        while (pf.next_window(window)) {
-            for (auto& b : window) {
-                if (b.size() == 0) continue;
-                auto& s = st.acquire();
-                ScgReads R = st.stage(s, 0, b);
-                launch_batch(P, R, b.size(), s.stream);
-                s.busy = true;
+        // window k + 1 is parsed by the workers while window k is copied to the device and counted
+        std::vector<scg::ReadBatch> window, ahead;
+        bool have = pf.next_window(window);
+        while (have) {
+            bool have_next = false;
+            std::thread prefetch([&] { have_next = pf.next_window(ahead); });
+            try {
+                for (auto& b : window) {
+                    if (b.size() == 0) continue;
+                    auto& s = st.acquire();
+                    ScgReads R = st.stage(s, 0, b);
+                    launch_batch(P, R, b.size(), s.stream);
+                    s.busy = true;
+                }
+            } catch (...) {
+                prefetch.join();
+                throw;
             }
+            prefetch.join();
+            window.swap(ahead);
+            have = have_next;
         }
         st.drain();
         if (!pf.unusual()) return;
