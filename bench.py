@@ -56,11 +56,17 @@ def main() -> None:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # one rank per GPU; SCG_BENCH_SHARE_GPU=1 lets several ranks share a card (rehearsal on a 1-GPU box, gloo)
+    share = os.environ.get("SCG_BENCH_SHARE_GPU") == "1"
+    dev_index = local_rank % max(torch.cuda.device_count(), 1) if share else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)   # nccl == RCCL on ROCm
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)   # nccl == RCCL on ROCm
 
     import screencounter_amd as sc
     from screencounter_amd import synth
