@@ -100,8 +100,7 @@ __device__ __forceinline__ bool stage_reads(const ScgReads& R, int64_t n_reads, 
         if (!edge) {
 #pragma unroll
             for (int k = 0; k < BATCH; ++k) {
-                x[k] = make_uint4(0, 0, 0, 0);
-                if (c0 + k * STAGE_BLOCK < nchunks) {
+                if (c0 + k * STAGE_BLOCK < nchunks) {      // (x[k] stays unread otherwise)
                     // streamed once: non-temporal, so the read bytes do not evict the library index from L2
                     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
                     u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(base + (size_t)k * STAGE_BLOCK * 16));
