@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libscg.so")
+LIB_PATH = os.environ.get("SCG_LIB") or os.path.join(_HERE, "libscg.so")     # SCG_LIB: A/B builds (tools/ab.sh)
 
 SCG_OK, SCG_ERR_INVALID, SCG_ERR_IO, SCG_ERR_DEVICE, SCG_ERR_UNSUPPORTED = 0, 1, 2, 3, 4
 ERRCAP = 1024

@@ -127,12 +127,11 @@ struct PinnedBuf {
 };
 
 struct DevIndex {
-    DevBuf entries, next, slots, table0;
+    DevBuf nodes, tables;
     ScgIndex view;
     void upload(const scg::HostIndex& h) {
-        entries.upload(h.entries); next.upload(h.next); slots.upload(h.slots); table0.upload(h.table0);
-        view.entries = entries.as<uint4>(); view.next = next.as<int32_t>(); view.slots = slots.as<uint2>();
-        view.table0 = table0.as<uint4>();
+        nodes.upload(h.nodes); tables.upload(h.tables);
+        view.nodes = nodes.as<uint4>(); view.tables = tables.as<uint4>();
         view.slot_mask = h.slot_mask; view.n_entries = h.n_entries; view.len = h.len; view.nseg = h.nseg;
         for (int s = 0; s < SCG_MAX_SEGMENTS; ++s) view.segmask[s] = h.segmask[s];
         for (int c = 0; c < 4; ++c) view.nwalk[c] = h.nwalk[c];

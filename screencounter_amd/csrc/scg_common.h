@@ -93,20 +93,25 @@ struct ScgTemplate {
 //             (c = 0 needs one, c = 1 the first two, c = 2 all six; 10-base keys keep chains ~1 long);
 //   budget 3: four quarters (c + 1 of them);   wider budgets: no tables, dense scans.
 // Walking those short chains and verifying each member by XOR + popcount finds every neighbour.
+//
+// Layout.  Entries that agree on group s form a chain in ascending entry order; `nodes` holds one
+// copy of the entry array per table, each with that table's chain link, and the chain's head node
+// is also stored IN the slot of the (open-addressed, linearly probed) hash table of group s.  One
+// 16-byte access therefore reaches the head entry -- the whole answer for a read whose barcode
+// matches exactly -- and following a chain is one access per further member.  The index is kept
+// small and is touched as rarely as possible on purpose: measured on MI355X, a lane-divergent
+// 16-byte lookup costs about as much as 64 vector instructions of one wavefront, and lookups that
+// miss the 4 MB L2 of an XCD are the kernel's only HBM traffic beyond the reads themselves.
 // Replaces the exact std::unordered_map + mismatch trie + per-thread caches of
 // kaori/BarcodeSearch.hpp:243-251 and kaori/MismatchTrie.hpp:446-501 with the same
 // unique-minimum semantics.
 struct ScgIndex {
-    const uint4* entries;       // n_entries x {key lo, key hi, value, next entry of segment 0's chain}
-    const int32_t* next;        // [nseg][n_entries] chain links (-1 ends a chain)
-    const uint2* slots;         // [nseg][slot_mask + 1] {tag, head entry + 1} ; head 0 = empty
-    const uint4* table0;        // segment 0 only: [slot_mask + 1] copy of the chain's head entry in the slot
-                                // itself ({lo, hi, value, next}; next == SCG_SLOT_EMPTY marks a free slot), so
-                                // that an exact hit costs one memory access
+    const uint4* nodes;         // [max(nseg,1)][n_entries] x {key lo, key hi, value, next entry of table s's chain (-1 ends)}
+    const uint4* tables;        // [nseg][slot_mask + 1] x head node of the chain keyed here; word 3 == SCG_SLOT_EMPTY: free slot
     uint32_t slot_mask;
     int32_t n_entries;
     int32_t len;                // bases per key
-    int32_t nseg;               // number of tables; 0 => budget too wide: dense scan of `entries`
+    int32_t nseg;               // number of tables; 0 => budget too wide: dense scan of `nodes`
     int32_t nwalk[4];           // tables to walk for a query cap of 0..3
     uint64_t segmask[SCG_MAX_SEGMENTS];   // plane-split position mask of table s
 };
@@ -187,11 +192,14 @@ static inline
 __host__ __device__
 #endif
 uint32_t scg_hash64(uint64_t key) {
-    uint32_t lo = (uint32_t)key, hi = (uint32_t)(key >> 32);
-    uint32_t h = lo * 0x9E3779B1u ^ hi * 0x85EBCA77u;
-    h ^= h >> 15;
-    h *= 0x2C1B3C6Du;
+    // Group keys are sparse (a few bit runs of two 32-bit planes, often with the low bits clear), so
+    // each plane gets a multiply and a fold of its own before the final avalanche.
+    uint32_t h = (uint32_t)key * 0x9E3779B1u;
+    h ^= h >> 16;
+    h = (h ^ (uint32_t)(key >> 32)) * 0x85EBCA6Bu;
     h ^= h >> 13;
+    h *= 0xC2B2AE35u;
+    h ^= h >> 16;
     return h;
 }
 

@@ -120,6 +120,15 @@ __device__ __forceinline__ int query_distance(const Query& q, uint32_t elo, uint
     return __popc(mism) + q.n_other;
 }
 
+// One 16-byte access.  The empty asm pins all four words right after the load: left alone, the
+// compiler sinks the words it needs "later" (value, link) into separate dword loads behind the
+// branches that use them, which triples the number of cache requests per lookup.
+__device__ __forceinline__ uint4 load_node(const uint4* p) {
+    uint4 v = *p;
+    asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
+    return v;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Library index search.  Calls f(value, distance) for every entry within Hamming distance
 // <= cap of the query (an entry may be reported more than once); f returns true to stop.
@@ -131,7 +140,7 @@ __device__ __forceinline__ void index_search(const ScgIndex& X, const Query& q, 
     if (X.nseg == 0) {
         // budget wider than the index supports: dense scan (rare, any budget)
         for (int e = 0; e < X.n_entries; ++e) {
-            uint4 ent = X.entries[e];
+            uint4 ent = X.nodes[e];
             int d = query_distance(q, ent.x, ent.y, lm);
             if (d <= cap && f((int)ent.z, d)) return;
         }
@@ -145,53 +154,30 @@ __device__ __forceinline__ void index_search(const ScgIndex& X, const Query& q, 
     const uint64_t qkey = ((uint64_t)q.hi << 32) | q.lo;
     const uint64_t qother = ((uint64_t)q.other << 32) | q.other;
     const uint32_t nslots = X.slot_mask + 1u;
-#pragma unroll
-    for (int s = 0; s < SCG_MAX_SEGMENTS; ++s) {
-        if (s >= nwalk) break;
+#pragma unroll 1
+    for (int s = 0; s < nwalk; ++s) {
         const uint64_t mask = X.segmask[s];
-        if (qother & mask) continue;              // a non-ACGT byte spoils this segment
+        if (qother & mask) continue;              // a non-ACGT byte spoils this group
         const uint64_t sk = qkey & mask;
-        const uint32_t h = scg_hash64(sk);
-        uint32_t pos = h & X.slot_mask;
-        int e = -1;
-        if (s == 0) {
-            // segment 0: the slot holds the chain's head entry itself -> an exact hit is one access
-            for (;;) {
-                const uint4 ent = X.table0[pos];
-                if (ent.w == SCG_SLOT_EMPTY) break;
-                if (((((uint64_t)ent.y << 32) | ent.x) & mask) == sk) {
-                    int d = query_distance(q, ent.x, ent.y, lm);
-                    if (d <= cap && f((int)ent.z, d)) return;
-                    e = (int)ent.w;
-                    break;
-                }
-                pos = (pos + 1) & X.slot_mask;
-            }
-            while (e >= 0) {
-                const uint4 ent = X.entries[e];
-                int d = query_distance(q, ent.x, ent.y, lm);
-                if (d <= cap && f((int)ent.z, d)) return;
-                e = (int)ent.w;
-            }
-        } else {
-            const uint2* slots = X.slots + (size_t)s * nslots;
-            for (;;) {
-                const uint64_t raw = reinterpret_cast<const uint64_t*>(slots)[pos];   // {tag, head + 1} in one load
-                const uint32_t tag = (uint32_t)raw, head1 = (uint32_t)(raw >> 32);
-                if (head1 == 0) break;            // empty slot: no entry shares this segment
-                if (tag == h) {
-                    const uint4 head = X.entries[head1 - 1];
-                    if (((((uint64_t)head.y << 32) | head.x) & mask) == sk) { e = (int)head1 - 1; break; }
-                }
-                pos = (pos + 1) & X.slot_mask;
-            }
-            const int32_t* next = X.next + (size_t)s * (size_t)X.n_entries;
-            while (e >= 0) {
-                const uint4 ent = X.entries[e];
-                int d = query_distance(q, ent.x, ent.y, lm);
-                if (d <= cap && f((int)ent.z, d)) return;
-                e = next[e];
-            }
+        uint32_t pos = scg_hash64(sk) & X.slot_mask;
+        const uint4* table = X.tables + (size_t)s * nslots;
+        // the slot of a group key holds the head node of its chain: an exact hit is one access
+        uint4 ent;
+        bool found = false;
+        for (;;) {
+            ent = load_node(table + pos);
+            if (ent.w == SCG_SLOT_EMPTY) break;   // no entry shares this group with the query
+            if (((((uint64_t)ent.y << 32) | ent.x) & mask) == sk) { found = true; break; }
+            pos = (pos + 1) & X.slot_mask;
+        }
+        if (!found) continue;
+        const uint4* nodes = X.nodes + (size_t)s * (size_t)X.n_entries;
+        for (;;) {
+            int d = query_distance(q, ent.x, ent.y, lm);
+            if (d <= cap && f((int)ent.z, d)) return;
+            const int e = (int)ent.w;
+            if (e < 0) break;
+            ent = load_node(nodes + e);
         }
     }
 }

@@ -41,10 +41,8 @@ struct HostIndex {
     uint32_t slot_mask = 0;
     int32_t nwalk[4] = {0, 0, 0, 0};
     uint64_t segmask[SCG_MAX_SEGMENTS] = {0, 0, 0, 0, 0, 0};
-    std::vector<uint32_t> entries;   // 4 words per entry: key lo, key hi, value, 0
-    std::vector<int32_t> next;       // [nseg][n_entries]
-    std::vector<uint32_t> slots;     // 2 words per slot: tag, head + 1 ; [nseg][slot_mask + 1]
-    std::vector<uint32_t> table0;    // 4 words per slot: the head entry of segment 0's chain, inline
+    std::vector<uint32_t> nodes;     // [max(nseg,1)][n_entries] x 4 words: key lo, key hi, value, next in table s's chain
+    std::vector<uint32_t> tables;    // [nseg][slot_mask + 1] x 4 words: head node of the chain keyed in that slot
 };
 
 // max_mm is the plan's mismatch budget for this pool: the index gets max_mm + 1 segments

@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <unordered_map>
 
 namespace scg {
 
@@ -212,15 +213,9 @@ namespace {
 
 // Lays the concrete entries (key, value) out as a segment index (scg_common.h: ScgIndex).
 void finish_index(HostIndex& X, const std::vector<uint64_t>& keys, const std::vector<int32_t>& vals, int32_t len, int max_mm) {
+    const size_t n = keys.size();
     X.len = len;
-    X.n_entries = static_cast<int32_t>(keys.size());
-    X.entries.resize(keys.size() * 4);
-    for (size_t e = 0; e < keys.size(); ++e) {
-        X.entries[4 * e] = static_cast<uint32_t>(keys[e]);
-        X.entries[4 * e + 1] = static_cast<uint32_t>(keys[e] >> 32);
-        X.entries[4 * e + 2] = static_cast<uint32_t>(vals[e]);
-        X.entries[4 * e + 3] = 0xFFFFFFFFu;   // no chain link (-1) until the segment tables are built
-    }
+    X.n_entries = static_cast<int32_t>(n);
     // position groups (see ScgIndex): masks over `parts` equal slices of the barcode
     auto slice = [&](int part, int parts) -> uint64_t {
         int a = static_cast<int>(static_cast<int64_t>(part) * len / parts);
@@ -243,54 +238,68 @@ void finish_index(HostIndex& X, const std::vector<uint64_t>& keys, const std::ve
     } else if (max_mm == 3) {
         for (int q = 0; q < 4; ++q) groups.push_back(slice(q, 4));
         X.nwalk[0] = 1; X.nwalk[1] = 2; X.nwalk[2] = 3; X.nwalk[3] = 4;
-    } else {
-        X.nseg = 0;            // budget too wide for pigeonhole tables: dense scans
-        return;
-    }
+    }                          // wider budgets: no tables (nseg = 0), dense scans of the node array
     const int nseg = static_cast<int>(groups.size());
     X.nseg = nseg;
-    uint32_t cap = 16;
-    while (cap < keys.size() * 2) cap <<= 1;
-    X.slot_mask = cap - 1;
-    X.slots.assign(static_cast<size_t>(nseg) * cap * 2, 0);
-    X.next.assign(static_cast<size_t>(nseg) * keys.size(), -1);
+    const int ncopies = nseg > 0 ? nseg : 1;
+    X.nodes.resize(static_cast<size_t>(ncopies) * n * 4);
+    for (int c = 0; c < ncopies; ++c) {
+        uint32_t* node = X.nodes.data() + static_cast<size_t>(c) * n * 4;
+        for (size_t e = 0; e < n; ++e) {
+            node[4 * e] = static_cast<uint32_t>(keys[e]);
+            node[4 * e + 1] = static_cast<uint32_t>(keys[e] >> 32);
+            node[4 * e + 2] = static_cast<uint32_t>(vals[e]);
+            node[4 * e + 3] = 0xFFFFFFFFu;          // chain end until linked below
+        }
+    }
+    if (nseg == 0) return;
+
+    // chains: entries agreeing on group s, linked in ascending entry order; heads[s] = first of each chain
+    std::vector<std::vector<int32_t> > heads(nseg);
     for (int sgm = 0; sgm < nseg; ++sgm) {
         const uint64_t mask = groups[sgm];
         X.segmask[sgm] = mask;
-        uint32_t* slots = X.slots.data() + static_cast<size_t>(sgm) * cap * 2;
-        int32_t* next = X.next.data() + static_cast<size_t>(sgm) * keys.size();
-        // Insert back to front so that every chain lists its entries in ascending order.
-        // (segment 0's links are also mirrored into word 3 of each entry, see below)
-        for (size_t i = keys.size(); i-- > 0;) {
-            uint64_t sk = keys[i] & mask;
-            uint32_t h = scg_hash64(sk);
-            uint32_t pos = h & X.slot_mask;
-            for (;;) {
-                uint32_t head = slots[2 * pos + 1];
-                if (head == 0) {
-                    slots[2 * pos] = h;
-                    slots[2 * pos + 1] = static_cast<uint32_t>(i) + 1;
-                    break;
-                }
-                if (slots[2 * pos] == h && (keys[head - 1] & mask) == sk) {
-                    next[i] = static_cast<int32_t>(head - 1);
-                    slots[2 * pos + 1] = static_cast<uint32_t>(i) + 1;
-                    break;
-                }
-                pos = (pos + 1) & X.slot_mask;
+        uint32_t* node = X.nodes.data() + static_cast<size_t>(sgm) * n * 4;
+        std::unordered_map<uint64_t, int32_t> head_of;
+        head_of.reserve(n * 2);
+        for (size_t i = n; i-- > 0;) {              // back to front: every chain ends up ascending
+            auto it = head_of.find(keys[i] & mask);
+            if (it == head_of.end()) {
+                head_of.emplace(keys[i] & mask, static_cast<int32_t>(i));
+            } else {
+                node[4 * i + 3] = static_cast<uint32_t>(it->second);
+                it->second = static_cast<int32_t>(i);
             }
         }
-        if (sgm == 0) {
-            for (size_t e = 0; e < keys.size(); ++e) X.entries[4 * e + 3] = static_cast<uint32_t>(next[e]);
-            // inline table: the slot of a chain holds a copy of its head entry
-            X.table0.assign(static_cast<size_t>(cap) * 4, 0);
-            for (uint32_t pos = 0; pos < cap; ++pos) {
-                uint32_t head = slots[2 * pos + 1];
-                if (head == 0) {
-                    X.table0[4 * pos + 3] = SCG_SLOT_EMPTY;
-                } else {
-                    for (int w = 0; w < 4; ++w) X.table0[4 * pos + w] = X.entries[4 * (head - 1) + w];
-                }
+        heads[sgm].reserve(head_of.size());
+        for (size_t i = 0; i < n; ++i) {            // deterministic insertion order
+            auto it = head_of.find(keys[i] & mask);
+            if (it->second == static_cast<int32_t>(i)) heads[sgm].push_back(static_cast<int32_t>(i));
+        }
+    }
+    // open addressing with linear probing at <= 50 % load, one slot count for all tables
+    uint32_t cap = 16;
+    while (cap < n * 2) cap <<= 1;
+    X.slot_mask = cap - 1;
+    std::vector<std::vector<int32_t> > placed(nseg);
+    for (int sgm = 0; sgm < nseg; ++sgm) {
+        placed[sgm].assign(cap, -1);
+        for (int32_t e : heads[sgm]) {
+            uint32_t pos = scg_hash64(keys[e] & groups[sgm]) & X.slot_mask;
+            while (placed[sgm][pos] >= 0) pos = (pos + 1) & X.slot_mask;
+            placed[sgm][pos] = e;
+        }
+    }
+    X.tables.assign(static_cast<size_t>(nseg) * cap * 4, 0);
+    for (int sgm = 0; sgm < nseg; ++sgm) {
+        const uint32_t* node = X.nodes.data() + static_cast<size_t>(sgm) * n * 4;
+        uint32_t* table = X.tables.data() + static_cast<size_t>(sgm) * cap * 4;
+        for (uint32_t pos = 0; pos < cap; ++pos) {
+            const int32_t e = placed[sgm][pos];
+            if (e < 0) {
+                table[4 * pos + 3] = SCG_SLOT_EMPTY;
+            } else {
+                for (int w = 0; w < 4; ++w) table[4 * pos + w] = node[4 * static_cast<size_t>(e) + w];
             }
         }
     }
@@ -447,6 +456,7 @@ ScgScan build_scan(const ScgTemplate& t, int max_mm) {
                         while (delta > 31) { steps[ns++] = 0x80 | 31; delta -= 31; }   // pure shifts
                         steps[ns++] = static_cast<uint8_t>(delta);                     // shift (maybe 0) then AND
                     }
+                    if (ns & 1) steps[ns++] = 0;      // even step count: the compact scanner folds bases in pairs (a repeated AND is a no-op)
                     if (ns > SCG_SEED_STEPS) { fits = false; break; }
                     for (int k = 0; k < ns; ++k) {
                         sd.walk[c].w[k >> 2] |= static_cast<uint32_t>(steps[k]) << (8 * (k & 3));

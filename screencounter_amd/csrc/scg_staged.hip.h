@@ -215,6 +215,38 @@ __device__ __forceinline__ void seed_candidates(const BasePlanes<NW>& E, const S
 #pragma unroll
         for (int i = 0; i < NC; ++i) g[i] = 0xFFFFFFFFu;
         const uint32_t counts = S.seed[s].nsteps;
+        if constexpr (NC < NW) {
+            // Compact form: every seed offset is < 32, so the plane shifted to a seed base is one
+            // funnel shift per word straight from E (no running copy), and two bases are folded
+            // into g with a single 3-input AND.  The host pads every walk to an even step count.
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                int left = (int)((counts >> (8 * c)) & 0xFFu);
+                int off = 0;
+#pragma unroll
+                for (int wi = 0; wi < SCG_SEED_STEPS / 4; ++wi) {
+                    if (left <= 0) break;
+                    const uint32_t word = S.seed[s].walk[c].w[wi];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        if (left <= 2 * h) break;
+                        const int o1 = off + (int)((word >> (16 * h)) & 31u);
+                        const int o2 = o1 + (int)((word >> (16 * h + 8)) & 31u);
+                        off = o2;
+#pragma unroll
+                        for (int i = 0; i < NC; ++i) {
+                            const uint32_t a = __builtin_amdgcn_alignbit(E.e[c][i + 1], E.e[c][i], o1);
+                            const uint32_t b = __builtin_amdgcn_alignbit(E.e[c][i + 1], E.e[c][i], o2);
+                            g[i] &= a & b;
+                        }
+                    }
+                    left -= 4;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NC; ++i) cand[i] |= g[i];
+            continue;
+        }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             int left = (int)((counts >> (8 * c)) & 0xFFu);
