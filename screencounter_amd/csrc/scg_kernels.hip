@@ -287,7 +287,7 @@ __global__ __launch_bounds__(BLOCK) void dual_kernel(ScgDualParams P, ScgReads R
 // Staged kernels
 // =============================================================================================
 template<int NW, int NT, int NC>
-__device__ __forceinline__ int single_read_staged(const ScgSingleParams& P, const Tile<NW>& tile, const StagedRead& sr, int ablate = 0) {
+__device__ __forceinline__ int single_read_staged(const ScgSingleParams& P, const Tile<NW>& tile, const StrandTable<NT>& st, const StagedRead& sr, int ablate = 0) {
     const ScgScan& T = P.scan;
     const int max_mm = P.max_mm;
     uint32_t candF[NC], candR[NC];
@@ -301,10 +301,9 @@ __device__ __forceinline__ int single_read_staged(const ScgSingleParams& P, cons
         if (p >= (1 << 30)) break;
         clear_bit<NC>(candF, rev ? -1 : p);
         clear_bit<NC>(candR, rev ? p : -1);
-        int c = window_mismatches<NW, NT>(tile, sr.bit + p, T, rev);
+        int c = window_mismatches<NW, NT>(tile, sr.bit + p, st, rev);
         if (c > max_mm) continue;
-        const int fs = uniform(T.fstart[0]), rs = uniform(T.rstart[0]);
-        int start = rev ? rs : fs;
+        const int start = region_start<NT>(st, 0, rev);
         Query q = region_query<NW>(tile, sr.bit + p + start, P.index.len, rev);
         int idx, d;
         index_match(P.index, q, max_mm - c, idx, d);
@@ -326,6 +325,8 @@ template<int NW, int NT, int NC>
 __global__ __launch_bounds__(STAGE_BLOCK) __attribute__((amdgpu_num_sgpr(80))) void single_staged_kernel(ScgSingleParams P, ScgReads R, int64_t n_reads,
                                                                    ScgCounters counts, int32_t* __restrict__ error_flag) {
     __shared__ Tile<NW> tile;
+    __shared__ StrandTable<NT> strands;
+    fill_strand_table<NT>(strands, P.scan);
     const int64_t r0 = (int64_t)blockIdx.x * STAGE_BLOCK;
     const int nr = (int)((n_reads - r0) < STAGE_BLOCK ? (n_reads - r0) : STAGE_BLOCK);
     int64_t span0 = 0;
@@ -342,25 +343,25 @@ __global__ __launch_bounds__(STAGE_BLOCK) __attribute__((amdgpu_num_sgpr(80))) v
     StagedRead sr;
     sr.bit = (int)((int64_t)(rd.p - R.seqs) - span0);
     sr.n = rd.n;
+    if (R.ablate == 5) count_one(counts, (int64_t)(((uint32_t)sr.bit * 2654435761u + (uint32_t)r0) % 100000u));   // experiment: same atomics, issued early
     int idx;
-    if (R.ablate >= 2) {
+    if (R.ablate == 2) {
         idx = (tile.p0[threadIdx.x] == 0xdeadbeefu) ? 0 : -1;
     } else {
-        idx = single_read_staged<NW, NT, NC>(P, tile, sr, R.ablate);
+        idx = single_read_staged<NW, NT, NC>(P, tile, strands, sr, R.ablate);
     }
-    if (idx >= 0) count_one(counts, idx);
+    if (R.ablate == 4) { counts.base[(blockIdx.x * STAGE_BLOCK + threadIdx.x) & 0xFFFFFu] = idx; return; }
+    if (idx >= 0 && !(R.ablate == 3 && idx != 0x7ffffff0) && R.ablate != 5) count_one(counts, idx);
 }
 
 template<int NW, int NT>
-__device__ __forceinline__ bool combo_candidate_staged(const ScgComboParams& P, const Tile<NW>& tile, const StagedRead& sr,
+__device__ __forceinline__ bool combo_candidate_staged(const ScgComboParams& P, const Tile<NW>& tile, const StrandTable<NT>& st, const StagedRead& sr,
                                                        int p, bool reverse, int c, int out[SCG_MAX_REGIONS], int& total) {
-    const ScgScan& T = P.scan;
     int obs = c;
 #pragma unroll
     for (int r = 0; r < SCG_MAX_REGIONS; ++r) {
         int slot = reverse ? (SCG_MAX_REGIONS - 1 - r) : r;
-        const int fs = uniform(T.fstart[r]), rs = uniform(T.rstart[r]);
-        int start = reverse ? rs : fs;
+        const int start = region_start<NT>(st, r, reverse);
         const ScgIndex& tab = P.index[slot];
         Query q = region_query<NW>(tile, sr.bit + p + start, tab.len, reverse);
         int idx, d;
@@ -378,6 +379,8 @@ template<int NW, int NT, int NC>
 __global__ __launch_bounds__(STAGE_BLOCK) __attribute__((amdgpu_num_sgpr(80))) void combo_staged_kernel(ScgComboParams P, ScgReads R, int64_t n_reads,
                                                                   ScgCounters cells, int32_t* __restrict__ error_flag) {
     __shared__ Tile<NW> tile;
+    __shared__ StrandTable<NT> strands;
+    fill_strand_table<NT>(strands, P.scan);
     const int64_t r0 = (int64_t)blockIdx.x * STAGE_BLOCK;
     const int nr = (int)((n_reads - r0) < STAGE_BLOCK ? (n_reads - r0) : STAGE_BLOCK);
     int64_t span0 = 0;
@@ -405,10 +408,10 @@ __global__ __launch_bounds__(STAGE_BLOCK) __attribute__((amdgpu_num_sgpr(80))) v
             if (p >= (1 << 30)) break;
             clear_bit<NC>(candF, rev ? -1 : p);
             clear_bit<NC>(candR, rev ? p : -1);
-            int c = window_mismatches<NW, NT>(tile, sr.bit + p, T, rev);
+            int c = window_mismatches<NW, NT>(tile, sr.bit + p, strands, rev);
             if (c > P.max_mm) continue;
             int cand[SCG_MAX_REGIONS], tot;
-            if (!combo_candidate_staged<NW, NT>(P, tile, sr, p, rev, c, cand, tot)) continue;
+            if (!combo_candidate_staged<NW, NT>(P, tile, strands, sr, p, rev, c, cand, tot)) continue;
             if (P.use_first) {
                 found = 1; best_id[0] = cand[0]; best_id[1] = cand[1];
                 break;
@@ -654,6 +657,7 @@ __global__ __launch_bounds__(BLOCK) void synth_kernel(scg_synth_spec S, char* __
 }
 
 inline unsigned grid_for(int64_t n) { return (unsigned)((n + BLOCK - 1) / BLOCK); }
+inline unsigned staged_grid(int64_t n) { return (unsigned)((n + STAGE_BLOCK - 1) / STAGE_BLOCK); }
 
 } // namespace
 
@@ -681,9 +685,9 @@ template<int NW, int NT> struct LaunchSingle {
     static hipError_t go(const ScgSingleParams& P, const ScgReads& R, int64_t n, const ScgCounters& counts, int32_t* flag, hipStream_t stream) {
         // compact variant: all candidate positions (0 .. max_len - T) fit 3 words of a 5-word read
         if (NW == 5 && P.scan.compact_ok && R.max_len - P.scan.len + 1 <= 96) {
-            hipLaunchKernelGGL((single_staged_kernel<NW, NT, (NW == 5 ? 3 : NW)>), dim3(grid_for(n)), dim3(STAGE_BLOCK), 0, stream, P, R, n, counts, flag);
+            hipLaunchKernelGGL((single_staged_kernel<NW, NT, (NW == 5 ? 3 : NW)>), dim3(staged_grid(n)), dim3(STAGE_BLOCK), 0, stream, P, R, n, counts, flag);
         } else {
-            hipLaunchKernelGGL((single_staged_kernel<NW, NT, NW>), dim3(grid_for(n)), dim3(STAGE_BLOCK), 0, stream, P, R, n, counts, flag);
+            hipLaunchKernelGGL((single_staged_kernel<NW, NT, NW>), dim3(staged_grid(n)), dim3(STAGE_BLOCK), 0, stream, P, R, n, counts, flag);
         }
         return hipGetLastError();
     }
@@ -691,9 +695,9 @@ template<int NW, int NT> struct LaunchSingle {
 template<int NW, int NT> struct LaunchCombo {
     static hipError_t go(const ScgComboParams& P, const ScgReads& R, int64_t n, const ScgCounters& cells, int32_t* flag, hipStream_t stream) {
         if (NW == 5 && P.scan.compact_ok && R.max_len - P.scan.len + 1 <= 96) {
-            hipLaunchKernelGGL((combo_staged_kernel<NW, NT, (NW == 5 ? 3 : NW)>), dim3(grid_for(n)), dim3(STAGE_BLOCK), 0, stream, P, R, n, cells, flag);
+            hipLaunchKernelGGL((combo_staged_kernel<NW, NT, (NW == 5 ? 3 : NW)>), dim3(staged_grid(n)), dim3(STAGE_BLOCK), 0, stream, P, R, n, cells, flag);
         } else {
-            hipLaunchKernelGGL((combo_staged_kernel<NW, NT, NW>), dim3(grid_for(n)), dim3(STAGE_BLOCK), 0, stream, P, R, n, cells, flag);
+            hipLaunchKernelGGL((combo_staged_kernel<NW, NT, NW>), dim3(staged_grid(n)), dim3(STAGE_BLOCK), 0, stream, P, R, n, cells, flag);
         }
         return hipGetLastError();
     }
@@ -704,11 +708,11 @@ template<int NW, int NT> struct LaunchDual {
         const int min_t = P.scan1.len < P.scan2.len ? P.scan1.len : P.scan2.len;
         const bool compact = NW == 5 && P.scan1.compact_ok && P.scan2.compact_ok && max_len - min_t + 1 <= 96;
         if (P.diagnostics) {
-            if (compact) hipLaunchKernelGGL((dual_staged_kernel<NW, NT, (NW == 5 ? 3 : NW), true>), dim3(grid_for(n)), dim3(STAGE_BLOCK), 0, stream, P, R1, R2, n, counts, flag);
-            else hipLaunchKernelGGL((dual_staged_kernel<NW, NT, NW, true>), dim3(grid_for(n)), dim3(STAGE_BLOCK), 0, stream, P, R1, R2, n, counts, flag);
+            if (compact) hipLaunchKernelGGL((dual_staged_kernel<NW, NT, (NW == 5 ? 3 : NW), true>), dim3(staged_grid(n)), dim3(STAGE_BLOCK), 0, stream, P, R1, R2, n, counts, flag);
+            else hipLaunchKernelGGL((dual_staged_kernel<NW, NT, NW, true>), dim3(staged_grid(n)), dim3(STAGE_BLOCK), 0, stream, P, R1, R2, n, counts, flag);
         } else {
-            if (compact) hipLaunchKernelGGL((dual_staged_kernel<NW, NT, (NW == 5 ? 3 : NW), false>), dim3(grid_for(n)), dim3(STAGE_BLOCK), 0, stream, P, R1, R2, n, counts, flag);
-            else hipLaunchKernelGGL((dual_staged_kernel<NW, NT, NW, false>), dim3(grid_for(n)), dim3(STAGE_BLOCK), 0, stream, P, R1, R2, n, counts, flag);
+            if (compact) hipLaunchKernelGGL((dual_staged_kernel<NW, NT, (NW == 5 ? 3 : NW), false>), dim3(staged_grid(n)), dim3(STAGE_BLOCK), 0, stream, P, R1, R2, n, counts, flag);
+            else hipLaunchKernelGGL((dual_staged_kernel<NW, NT, NW, false>), dim3(staged_grid(n)), dim3(STAGE_BLOCK), 0, stream, P, R1, R2, n, counts, flag);
         }
         return hipGetLastError();
     }

@@ -29,7 +29,10 @@
 
 namespace scgdev {
 
-constexpr int STAGE_BLOCK = 256;      // lanes = reads per workgroup
+#ifndef SCG_STAGE_BLOCK
+#define SCG_STAGE_BLOCK 256
+#endif
+constexpr int STAGE_BLOCK = SCG_STAGE_BLOCK;      // lanes = reads per workgroup
 
 // Marks a wave-uniform value as such (keeps it in an SGPR).
 __device__ __forceinline__ uint32_t uniform(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
@@ -46,23 +49,40 @@ struct Tile {
 };
 
 // 16 ASCII bytes -> 16 bits of each plane.
+//
+// Per dword: code k = (byte >> 1) & 3; "ACTG"[k] is fetched with one byte permute and XORed with the
+// byte stripped of its case bit: the result z is zero exactly for ACGTacgt.  Plane bits are
+// gathered with v_dot4_u32_u8 against power-of-two weights, straight from ASCII bits 1 and 2 (so
+// scaled by 2 and 4).  When every lane of the wavefront holds only standard bases -- the rule in
+// real data, where N calls are rare -- the validity plane is all ones and its gather (a carry-free
+// nonzero-byte test per dword plus a third dot product) is skipped.
 __device__ __forceinline__ void transpose_chunk(const uint4& x, uint32_t& p0, uint32_t& p1, uint32_t& v) {
     const uint32_t d[4] = {x.x, x.y, x.z, x.w};
-    uint32_t a0[2] = {0, 0}, a1[2] = {0, 0}, ai[2] = {0, 0};
+    uint32_t a0[2] = {0, 0}, a1[2] = {0, 0};
+    uint32_t z[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const uint32_t w = (i & 1) ? 0x80402010u : 0x08040201u;     // bit weights of the 4 bytes
-        uint32_t k = (d[i] >> 1) & 0x03030303u;                     // codes
-        uint32_t expect = __builtin_amdgcn_perm(0u, 0x47544341u, k);   // "ACTG"[code] per byte
-        uint32_t z = expect ^ (d[i] & 0xDFDFDFDFu);                 // zero byte <=> standard base
-        uint32_t nz = (((z & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | z) & 0x80808080u;
-        a0[i >> 1] = __builtin_amdgcn_udot4(k & 0x01010101u, w, a0[i >> 1], false);
-        a1[i >> 1] = __builtin_amdgcn_udot4(k & 0x02020202u, w, a1[i >> 1], false);
-        ai[i >> 1] = __builtin_amdgcn_udot4(nz, w, ai[i >> 1], false);
+        const uint32_t k = (d[i] >> 1) & 0x03030303u;               // codes
+        const uint32_t expect = __builtin_amdgcn_perm(0u, 0x47544341u, k);   // "ACTG"[code] per byte
+        z[i] = expect ^ (d[i] & 0xDFDFDFDFu);                       // zero byte <=> standard base
+        a0[i >> 1] = __builtin_amdgcn_udot4(d[i] & 0x02020202u, w, a0[i >> 1], false);
+        a1[i >> 1] = __builtin_amdgcn_udot4(d[i] & 0x04040404u, w, a1[i >> 1], false);
     }
-    p0 = a0[0] | (a0[1] << 8);
-    p1 = (a1[0] >> 1) | (a1[1] << 7);
-    v = ~((ai[0] >> 7) | (ai[1] << 1)) & 0xFFFFu;
+    p0 = (a0[0] >> 1) | (a0[1] << 7);
+    p1 = (a1[0] >> 2) | (a1[1] << 6);
+    if (__builtin_amdgcn_ballot_w64((z[0] | z[1] | z[2] | z[3]) != 0) == 0) {     // wave-uniform
+        v = 0xFFFFu;
+    } else {
+        uint32_t ai[2] = {0, 0};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t w = (i & 1) ? 0x80402010u : 0x08040201u;
+            const uint32_t nz = (((z[i] & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | z[i]) & 0x80808080u;
+            ai[i >> 1] = __builtin_amdgcn_udot4(nz, w, ai[i >> 1], false);
+        }
+        v = ~((ai[0] >> 7) | (ai[1] << 1)) & 0xFFFFu;
+    }
 }
 
 // Phase A.  Returns false when the workgroup's span does not fit the tile (caller falls back to
@@ -330,6 +350,56 @@ __device__ __forceinline__ int window_mismatches(const Tile<NW>& tile, int bit, 
         mm += __popc(cm & ~same);
     }
     return mm;
+}
+
+// Both strands' template words side by side in LDS, for kernels where the strand differs from lane
+// to lane (single / combo): choosing between two kernel-argument words per lane costs three vector
+// instructions a word (two SGPR->VGPR moves and a select), reading the chosen strand's row costs none.
+template<int NT>
+struct StrandTable {
+    static constexpr int STRIDE = 3 * NT + SCG_MAX_REGIONS;   // plane0[NT] | plane1[NT] | mask[NT] | region starts
+    uint32_t w[2 * STRIDE];
+};
+
+template<int NT>
+__device__ __forceinline__ void fill_strand_table(StrandTable<NT>& st, const ScgScan& T) {
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            st.w[i] = T.fplane0[i];
+            st.w[NT + i] = T.fplane1[i];
+            st.w[2 * NT + i] = T.fmask[i];
+            st.w[StrandTable<NT>::STRIDE + i] = T.rplane0[i];
+            st.w[StrandTable<NT>::STRIDE + NT + i] = T.rplane1[i];
+            st.w[StrandTable<NT>::STRIDE + 2 * NT + i] = T.rmask[i];
+        }
+#pragma unroll
+        for (int r = 0; r < SCG_MAX_REGIONS; ++r) {
+            st.w[3 * NT + r] = (uint32_t)T.fstart[r];
+            st.w[StrandTable<NT>::STRIDE + 3 * NT + r] = (uint32_t)T.rstart[r];
+        }
+    }
+}
+
+template<int NW, int NT>
+__device__ __forceinline__ int window_mismatches(const Tile<NW>& tile, int bit, const StrandTable<NT>& st, bool reverse) {
+    uint32_t w0[NT], w1[NT], wv[NT];
+    load_bits<NT>(tile.p0, bit, w0);
+    load_bits<NT>(tile.p1, bit, w1);
+    load_bits<NT>(tile.v, bit, wv);
+    const uint32_t* row = st.w + (reverse ? StrandTable<NT>::STRIDE : 0);
+    int mm = 0;
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        uint32_t same = wv[i] & ~((w0[i] ^ row[i]) | (w1[i] ^ row[NT + i]));
+        mm += __popc(row[2 * NT + i] & ~same);
+    }
+    return mm;
+}
+
+template<int NT>
+__device__ __forceinline__ int region_start(const StrandTable<NT>& st, int r, bool reverse) {
+    return (int)st.w[(reverse ? StrandTable<NT>::STRIDE : 0) + 3 * NT + r];
 }
 
 // Variable region of `len` <= 32 bases starting at plane bit `bit`.
