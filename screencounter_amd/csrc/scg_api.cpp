@@ -205,7 +205,9 @@ struct scg_plan {
         HIP_CHECK(hipMemset(counters, 0, static_cast<size_t>(n_counters) * sizeof(int32_t)));
         // enough replicas that ~2^20 distinct addresses take the atomics
         replica_shift = 0;
-        while (replica_shift < 12 && (n_counters << (replica_shift + 1)) <= (int64_t(1) << 20)) ++replica_shift;
+        int addr_log2 = 20;
+        if (const char* e = std::getenv("SCG_REPLICA_ADDR_LOG2")) addr_log2 = std::atoi(e);     // tuning aid
+        while (replica_shift < 12 && (n_counters << (replica_shift + 1)) <= (int64_t(1) << addr_log2)) ++replica_shift;
         if (replica_shift > 0) {
             replicas.alloc((static_cast<size_t>(n_counters) << replica_shift) * sizeof(int32_t));
             HIP_CHECK(hipMemset(replicas.p, 0, replicas.bytes));
