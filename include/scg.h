@@ -90,6 +90,21 @@ int scg_count_dual_barcodes(const char* path1, const char* constant1, int revers
                             int32_t* counts_out, int32_t* total_out,
                             char* err, size_t errcap);
 
+/* countPairedComboBarcodes hot path: one variable region per mate, every
+ * (pool1, pool2) combination counts.  Replaces src/count_combo_barcodes_paired.cpp:57-95
+ * (kaori::CombinatorialBarcodesPairedEnd).  Outputs mirror its 5-list: a malloc'd 2 x K column-major
+ * matrix of 0-based (pool1 index, pool2 index) columns sorted by (first, second) with K
+ * frequencies (release both with scg_free), the number of pairs, and the numbers of pairs where
+ * only barcode 1 / only barcode 2 was found. */
+int scg_count_combo_barcodes_paired(const char* path1, const char* constant1, int reverse1, int mismatches1,
+                                    const char* const* pool1, int32_t n_pool1,
+                                    const char* path2, const char* constant2, int reverse2, int mismatches2,
+                                    const char* const* pool2, int32_t n_pool2,
+                                    int randomized, int use_first, int nthreads,
+                                    int32_t** indices_out, int32_t** freq_out, int64_t* k_out,
+                                    int32_t* total_out, int32_t* barcode1_only_out, int32_t* barcode2_only_out,
+                                    char* err, size_t errcap);
+
 /* countDualBarcodes(include.invalid=TRUE).  Replaces the diagnostics branch of
  * src/count_dual_barcodes.cpp:52-71 (kaori::DualBarcodesPairedEndWithDiagnostics): besides the valid-pair
  * counts, pairs whose two barcodes are both known but do not form a valid combination are
@@ -148,6 +163,14 @@ int scg_plan_dual(scg_plan** plan_out,
                   const char* constant2, int reverse2, int mismatches2, const char* const* pool2,
                   int32_t n_pool, int randomized, int use_first, int diagnostics,
                   int device, char* err, size_t errcap);
+
+/* Plan for countPairedComboBarcodes: counted with scg_count_batch_paired, read with
+ * scg_plan_read_diagnostics (counts_out = NULL; the "invalid" outputs are the combinations). */
+int scg_plan_paired_combo(scg_plan** plan_out,
+                          const char* constant1, int reverse1, int mismatches1, const char* const* pool1, int32_t n_pool1,
+                          const char* constant2, int reverse2, int mismatches2, const char* const* pool2, int32_t n_pool2,
+                          int randomized, int use_first,
+                          int device, char* err, size_t errcap);
 
 void scg_plan_destroy(scg_plan* plan);
 

@@ -162,6 +162,23 @@ def fuzz_dual_diag(rng, ora, ref, tmpdir, it):
     return "ok"
 
 
+def fuzz_combo_paired(rng, ora, ref, tmpdir, it):
+    from tests import gen
+    c = gen.random_paired_combo_case(rng)
+    fq1 = os.path.join(tmpdir, f"p{it}_1.fastq")
+    fq2 = os.path.join(tmpdir, f"p{it}_2.fastq")
+    write_fastq(fq1, c["reads1"])
+    write_fastq(fq2, c["reads2"])
+    exp = ref.count_combo_paired(fq1, c["template1"], c["reverse1"], c["mismatches1"], c["pool1"],
+                                 fq2, c["template2"], c["reverse2"], c["mismatches2"], c["pool2"], c["randomized"], c["use_first"], 1)
+    got = ora.count_combo_paired(c["reads1"], c["reads2"], c["template1"], c["reverse1"], c["mismatches1"], c["pool1"],
+                                 c["template2"], c["reverse2"], c["mismatches2"], c["pool2"], c["randomized"], c["use_first"])
+    for key in exp:
+        if not np.array_equal(np.asarray(exp[key]), np.asarray(got[key])):
+            raise AssertionError(f"combo-paired mismatch in {key}: {c}\nexp={exp}\ngot={got}")
+    return "ok"
+
+
 def fuzz_match(rng, ora, ref):
     vlen = rng.choice([3, 5, 8, 12])
     alphabet = rng.choice(["AC", BASES])
@@ -201,6 +218,7 @@ def main():
                              ("dual", lambda: fuzz_dual(rng, ora, ref, tmp, it, True)),
                              ("dual-hazard", lambda: fuzz_dual(rng, ora, ref, tmp, it, False)),
                              ("dual-diag", lambda: fuzz_dual_diag(rng, ora, ref, tmp, it)),
+                             ("combo-paired", lambda: fuzz_combo_paired(rng, ora, ref, tmp, it)),
                              ("match", lambda: fuzz_match(rng, ora, ref))):
                 res = fn()
                 tally[f"{name}:{res}"] = tally.get(f"{name}:{res}", 0) + 1

@@ -70,6 +70,15 @@ def run_case(ref: KaoriRef, case: dict, tmp: str) -> dict:
                                     case["randomized"], case["use_first"], 1)
             out["expect"] = {"counts": d["counts"].tolist(), "indices": d["indices"].tolist(), "freq": d["freq"].tolist(),
                              "total": d["total"], "barcode1_only": d["barcode1_only"], "barcode2_only": d["barcode2_only"]}
+        elif k == "paired_combo":
+            f1, f2 = os.path.join(tmp, "p1.fastq"), os.path.join(tmp, "p2.fastq")
+            write_fastq(f1, case["reads1"])
+            write_fastq(f2, case["reads2"])
+            d = ref.count_combo_paired(f1, case["template1"], case["reverse1"], case["mismatches1"], case["pool1"],
+                                       f2, case["template2"], case["reverse2"], case["mismatches2"], case["pool2"],
+                                       case["randomized"], case["use_first"], 1)
+            out["expect"] = {"indices": d["indices"].tolist(), "freq": d["freq"].tolist(),
+                             "total": d["total"], "barcode1_only": d["barcode1_only"], "barcode2_only": d["barcode2_only"]}
         elif k == "match":
             idx, mm = ref.match_barcodes(case["sequences"], case["choices"], case["substitutions"], case["reverse"])
             out["expect"] = {"index": idx.tolist(), "mismatches": mm.tolist()}
@@ -235,6 +244,8 @@ def main() -> None:
             c = gen.random_dual_case(rng, hazard_free=True, sizes=small, max_mm=2)
             c["kind"] = "dual_diag"
             rnd.append(run_case(ref, c, tmp))
+        for _ in range(40):     # appended last: the cases above keep their seeds
+            rnd.append(run_case(ref, gen.random_paired_combo_case(rng, sizes=small, max_mm=2), tmp))
         with open(os.path.join(OUT, "kaori_random.json"), "w") as f:
             json.dump({"generator": "oracle/gen_golden.py", "reference": "kaori v1.1.1 (screenCounter 1.5.1)", "seed": 20261003, "cases": rnd}, f)
 

@@ -247,6 +247,64 @@ int kref_count_dual_diag(const char* path1, const char* tmpl1, int reverse1, int
     return 0;
 }
 
+/* src/count_combo_barcodes_paired.cpp:57-95: sorted combinations (2 x K, 0-based) with frequencies,
+ * total, barcode1-only, barcode2-only. */
+int kref_count_combo_paired(const char* path1, const char* tmpl1, int reverse1, int mm1, const char* const* pool1, int n_pool1,
+                            const char* path2, const char* tmpl2, int reverse2, int mm2, const char* const* pool2, int n_pool2,
+                            int randomized, int use_first, int nthreads,
+                            int32_t** idx_out, int32_t** freq_out, int64_t* k_out,
+                            int32_t* total, int32_t* b1_only, int32_t* b2_only, char* err, size_t errcap) {
+    try {
+        byteme::SomeFileReader r1(path1);
+        auto p1 = make_pool(pool1, n_pool1);
+        byteme::SomeFileReader r2(path2);
+        auto p2 = make_pool(pool2, n_pool2);
+        std::string c1(tmpl1), c2(tmpl2);
+        size_t len = std::max(c1.size(), c2.size());
+        std::vector<std::array<int, 2> > sorted;
+        auto run = [&](auto tag) {
+            constexpr size_t N = decltype(tag)::value;
+            typename kaori::CombinatorialBarcodesPairedEnd<N>::Options options;
+            options.strand1 = reverse1 ? kaori::SearchStrand::REVERSE : kaori::SearchStrand::FORWARD;
+            options.max_mismatches1 = mm1;
+            options.strand2 = reverse2 ? kaori::SearchStrand::REVERSE : kaori::SearchStrand::FORWARD;
+            options.max_mismatches2 = mm2;
+            options.random = randomized != 0;
+            options.use_first = use_first != 0;
+            kaori::CombinatorialBarcodesPairedEnd<N> handler(c1.c_str(), c1.size(), p1, c2.c_str(), c2.size(), p2, options);
+            kaori::process_paired_end_data(&r1, &r2, handler, nthreads);
+            handler.sort();
+            sorted = handler.get_combinations();
+            *total = handler.get_total();
+            *b1_only = handler.get_barcode1_only();
+            *b2_only = handler.get_barcode2_only();
+        };
+        if (len <= 32) run(std::integral_constant<size_t, 32>());
+        else if (len <= 64) run(std::integral_constant<size_t, 64>());
+        else if (len <= 128) run(std::integral_constant<size_t, 128>());
+        else if (len <= 256) run(std::integral_constant<size_t, 256>());
+        else throw std::runtime_error("lacking compile-time support for constant regions longer than 256 bp");
+        std::vector<int32_t> idx, freq;
+        for (size_t i = 0; i < sorted.size(); ++i) {
+            if (i && sorted[i] == sorted[i - 1]) {
+                ++freq.back();
+            } else {
+                idx.push_back(sorted[i][0]);
+                idx.push_back(sorted[i][1]);
+                freq.push_back(1);
+            }
+        }
+        *k_out = static_cast<int64_t>(freq.size());
+        *idx_out = static_cast<int32_t*>(std::malloc(sizeof(int32_t) * (idx.size() + 1)));
+        *freq_out = static_cast<int32_t*>(std::malloc(sizeof(int32_t) * (freq.size() + 1)));
+        std::copy(idx.begin(), idx.end(), *idx_out);
+        std::copy(freq.begin(), freq.end(), *freq_out);
+    } catch (std::exception& e) {
+        return set_err(err, errcap, e.what());
+    }
+    return 0;
+}
+
 /* src/match_barcodes.cpp:6-37; index 0-based, -1 where R would report NA. */
 int kref_match_barcodes(const char* const* sequences, int nseq, const char* const* choices, int nchoices,
                         int substitutions, int reverse, int32_t* index_out, int32_t* mm_out,

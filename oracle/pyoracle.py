@@ -192,6 +192,37 @@ class Oracle:
         return dict(counts=counts[:len(pool1)].copy(), indices=tuples[:2 * k].reshape(k, 2).T.copy(), freq=freq[:k].copy(),
                     total=int(total.value), barcode1_only=int(b1.value), barcode2_only=int(b2.value))
 
+    def count_combo_paired(self, reads1, reads2, template1: str, reverse1: bool, mm1: int, pool1: Sequence[str],
+                           template2: str, reverse2: bool, mm2: int, pool2: Sequence[str],
+                           randomized: bool, use_first: bool):
+        """countPairedComboBarcodes -> dict(indices int32[2,K], freq, total, barcode1_only, barcode2_only)"""
+        s1, o1 = _as_batch(reads1)
+        s2, o2 = _as_batch(reads2)
+        n = len(o1) - 1
+        if len(o2) - 1 != n:
+            raise OracleError("different number of reads in paired FASTQ files")
+        tuples = np.zeros(2 * max(n, 1), dtype=np.int32)
+        nt = C.c_int64(0)
+        total, b1, b2 = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        err = C.create_string_buffer(_ERRCAP)
+        p1, _k1 = _cstr_array(pool1)
+        p2, _k2 = _cstr_array(pool2)
+        sp1, _a = _ptr(s1, C.c_char)
+        sp2, _b = _ptr(s2, C.c_char)
+        rc = self.L.scgo_count_combo_paired(
+            sp1, o1.ctypes.data_as(C.POINTER(C.c_uint64)), sp2, o2.ctypes.data_as(C.POINTER(C.c_uint64)), C.c_int64(n),
+            template1.encode(), C.c_int(len(template1)), C.c_int(int(reverse1)), C.c_int(mm1), p1, C.c_int(len(pool1)),
+            template2.encode(), C.c_int(len(template2)), C.c_int(int(reverse2)), C.c_int(mm2), p2, C.c_int(len(pool2)),
+            C.c_int(int(randomized)), C.c_int(int(use_first)),
+            tuples.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(nt),
+            C.byref(total), C.byref(b1), C.byref(b2), err, C.c_size_t(_ERRCAP))
+        if rc:
+            raise OracleError(err.value.decode())
+        freq = np.zeros(max(int(nt.value), 1), dtype=np.int32)
+        k = self.L.scgo_combo_rle(tuples.ctypes.data_as(C.POINTER(C.c_int32)), nt, freq.ctypes.data_as(C.POINTER(C.c_int32)))
+        return dict(indices=tuples[:2 * k].reshape(k, 2).T.copy(), freq=freq[:k].copy(),
+                    total=int(total.value), barcode1_only=int(b1.value), barcode2_only=int(b2.value))
+
     def match_barcodes(self, sequences: Sequence[str], choices: Sequence[str], substitutions: int = 0, reverse: bool = False):
         """-> (index int32[n] 0-based, -1 = NA; mismatches int32[n], -1 = NA)"""
         n = len(sequences)
@@ -322,6 +353,32 @@ class KaoriRef:
             self.L.kref_free(freq_p)
         return dict(counts=counts[:len(pool1)].copy(), indices=idx, freq=freq, total=int(total.value),
                     barcode1_only=int(b1.value), barcode2_only=int(b2.value))
+
+    def count_combo_paired(self, fastq1: str, template1: str, reverse1: bool, mm1: int, pool1: Sequence[str],
+                           fastq2: str, template2: str, reverse2: bool, mm2: int, pool2: Sequence[str],
+                           randomized: bool, use_first: bool, nthreads: int = 1):
+        idx_p = C.POINTER(C.c_int32)()
+        freq_p = C.POINTER(C.c_int32)()
+        k = C.c_int64(0)
+        total, b1, b2 = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        err = C.create_string_buffer(_ERRCAP)
+        p1, _k1 = _cstr_array(pool1)
+        p2, _k2 = _cstr_array(pool2)
+        rc = self.L.kref_count_combo_paired(fastq1.encode(), template1.encode(), C.c_int(int(reverse1)), C.c_int(mm1), p1, C.c_int(len(pool1)),
+                                            fastq2.encode(), template2.encode(), C.c_int(int(reverse2)), C.c_int(mm2), p2, C.c_int(len(pool2)),
+                                            C.c_int(int(randomized)), C.c_int(int(use_first)), C.c_int(nthreads),
+                                            C.byref(idx_p), C.byref(freq_p), C.byref(k),
+                                            C.byref(total), C.byref(b1), C.byref(b2), err, C.c_size_t(_ERRCAP))
+        if rc:
+            raise OracleError(err.value.decode())
+        K = int(k.value)
+        try:
+            idx = np.array([idx_p[i] for i in range(2 * K)], dtype=np.int32).reshape(K, 2).T.copy()
+            freq = np.array([freq_p[i] for i in range(K)], dtype=np.int32)
+        finally:
+            self.L.kref_free(idx_p)
+            self.L.kref_free(freq_p)
+        return dict(indices=idx, freq=freq, total=int(total.value), barcode1_only=int(b1.value), barcode2_only=int(b2.value))
 
     def match_barcodes(self, sequences: Sequence[str], choices: Sequence[str], substitutions: int = 0, reverse: bool = False):
         n = len(sequences)

@@ -766,6 +766,63 @@ static smatch_t single_search(const tmpl_t *T, const lib_t *F, const lib_t *R, c
     return out;
 }
 
+/* CombinatorialBarcodesPairedEnd::process (handlers/CombinatorialBarcodesPairedEnd.hpp:167-242) for one pair.
+ * Returns 1 with (*x, *y) = the combination, 2 = only barcode 1 found, 3 = only barcode 2, 0 = neither. */
+typedef struct {
+    const tmpl_t *T1, *T2;
+    const lib_t *L1, *L2;      /* strand-adjusted libraries of template 1 / 2 */
+    int mm1, mm2, use_first, randomized;
+    int keep_first;            /* DuplicateAction::FIRST (diagnostics) vs ERROR (countPairedComboBarcodes) */
+} pcombo_t;
+
+static int paired_combo_step(const pcombo_t *C, const char *a, int na, const char *b, int nb, int *x, int *y) {
+#define S1(read, n) single_search(C->T1, C->L1, C->L1, read, n, C->mm1, C->use_first, C->keep_first)
+#define S2(read, n) single_search(C->T2, C->L2, C->L2, read, n, C->mm2, C->use_first, C->keep_first)
+#define EMIT(p, q) do { *x = (p); *y = (q); return 1; } while (0)
+    smatch_t m1 = S1(a, na), m2 = S2(b, nb);
+    if (C->use_first) {                                            /* :170-193 */
+        if (m1.found && m2.found) EMIT(m1.index, m2.index);
+        if (C->randomized) {
+            smatch_t n1 = S1(b, nb), n2 = S2(a, na);
+            if (n1.found && n2.found) EMIT(n1.index, n2.index);
+            if (m1.found || n1.found) return 2;
+            if (m2.found || n2.found) return 3;
+            return 0;
+        }
+        if (m1.found) return 2;
+        if (m2.found) return 3;
+        return 0;
+    }
+    if (!C->randomized) {                                          /* :195-205 */
+        if (m1.found && m2.found) EMIT(m1.index, m2.index);
+        if (m1.found) return 2;
+        if (m2.found) return 3;
+        return 0;
+    }
+    if (m1.found && m2.found) {                                    /* :207-226 */
+        int mism = m1.mm + m2.mm;
+        smatch_t n1 = S1(b, nb), n2 = S2(a, na);
+        if (n1.found && n2.found) {
+            int rmism = n1.mm + n2.mm;
+            if (mism > rmism) EMIT(n1.index, n2.index);
+            if (mism < rmism) EMIT(m1.index, m2.index);
+            if (m1.index == n1.index && m2.index == n2.index) EMIT(m1.index, m2.index);
+            return 0;
+        }
+        EMIT(m1.index, m2.index);
+    }
+    {                                                              /* :227-239 */
+        smatch_t n1 = S1(b, nb), n2 = S2(a, na);
+        if (n1.found && n2.found) EMIT(n1.index, n2.index);
+        if (m1.found || n1.found) return 2;
+        if (m2.found || n2.found) return 3;
+    }
+    return 0;
+#undef S1
+#undef S2
+#undef EMIT
+}
+
 int scgo_count_dual_diag(const char *seqs1, const uint64_t *offs1, const char *seqs2, const uint64_t *offs2, int64_t n_pairs,
                          const char *tmpl1, int tmpl_len1, int reverse1, int mm1, const char *const *pool1,
                          const char *tmpl2, int tmpl_len2, int reverse2, int mm2, const char *const *pool2,
@@ -817,9 +874,7 @@ int scgo_count_dual_diag(const char *seqs1, const uint64_t *offs1, const char *s
     memset(counts, 0, sizeof(int32_t) * (size_t)n_pool);
     int32_t tot = 0, b1o = 0, b2o = 0;
     int64_t nt = 0;
-#define S1(read, n) single_search(&D.T1, &L1, &L1, read, n, mm1, use_first, 1)
-#define S2(read, n) single_search(&D.T2, &L2, &L2, read, n, mm2, use_first, 1)
-#define EMIT(x, y) do { tuples[2 * nt] = (x); tuples[2 * nt + 1] = (y); ++nt; } while (0)
+    pcombo_t C = {&D.T1, &D.T2, &L1, &L2, mm1, mm2, use_first, randomized, 1};
     for (int64_t r = 0; r < n_pairs; ++r) {
         const char *a = seqs1 + offs1[r]; int na = (int)(offs1[r + 1] - offs1[r]);
         const char *b = seqs2 + offs2[r]; int nb = (int)(offs2[r + 1] - offs2[r]);
@@ -840,48 +895,67 @@ int scgo_count_dual_diag(const char *seqs1, const uint64_t *offs1, const char *s
         }
         ++tot;
         if (valid >= 0) { ++counts[valid]; continue; }
-        /* CombinatorialBarcodesPairedEnd.hpp:167-242 */
-        smatch_t m1 = S1(a, na), m2 = S2(b, nb);
-        if (use_first) {
-            if (m1.found && m2.found) {
-                EMIT(m1.index, m2.index);
-            } else if (randomized) {
-                smatch_t n1 = S1(b, nb), n2 = S2(a, na);
-                if (n1.found && n2.found) EMIT(n1.index, n2.index);
-                else if (m1.found || n1.found) ++b1o;
-                else if (m2.found || n2.found) ++b2o;
-            } else {
-                if (m1.found) ++b1o;
-                else if (m2.found) ++b2o;
-            }
-        } else if (!randomized) {
-            if (m1.found && m2.found) EMIT(m1.index, m2.index);
-            else if (m1.found) ++b1o;
-            else if (m2.found) ++b2o;
-        } else if (m1.found && m2.found) {
-            int mism = m1.mm + m2.mm;
-            smatch_t n1 = S1(b, nb), n2 = S2(a, na);
-            if (n1.found && n2.found) {
-                int rmism = n1.mm + n2.mm;
-                if (mism > rmism) EMIT(n1.index, n2.index);
-                else if (mism < rmism) EMIT(m1.index, m2.index);
-                else if (m1.index == n1.index && m2.index == n2.index) EMIT(m1.index, m2.index);
-            } else {
-                EMIT(m1.index, m2.index);
-            }
-        } else {
-            smatch_t n1 = S1(b, nb), n2 = S2(a, na);
-            if (n1.found && n2.found) EMIT(n1.index, n2.index);
-            else if (m1.found || n1.found) ++b1o;
-            else if (m2.found || n2.found) ++b2o;
+        int x, y;
+        switch (paired_combo_step(&C, a, na, b, nb, &x, &y)) {
+            case 1: tuples[2 * nt] = x; tuples[2 * nt + 1] = y; ++nt; break;
+            case 2: ++b1o; break;
+            case 3: ++b2o; break;
+            default: break;
         }
     }
-#undef S1
-#undef S2
-#undef EMIT
     *n_tuples = nt; *total = tot; *barcode1_only = b1o; *barcode2_only = b2o;
     free(h1); free(h2); free(comb);
     lib_free(&D.L); lib_free(&L1); lib_free(&L2);
+    return 0;
+}
+
+/* countPairedComboBarcodes: src/count_combo_barcodes_paired.cpp:11-55 over
+ * kaori::CombinatorialBarcodesPairedEnd (two SimpleSingleMatch matchers, DuplicateAction::ERROR).
+ * tuples: capacity 2 * n_pairs, in read order (the caller sorts / run-length encodes, scgo_combo_rle). */
+int scgo_count_combo_paired(const char *seqs1, const uint64_t *offs1, const char *seqs2, const uint64_t *offs2, int64_t n_pairs,
+                            const char *tmpl1, int tmpl_len1, int reverse1, int mm1, const char *const *pool1, int n_pool1,
+                            const char *tmpl2, int tmpl_len2, int reverse2, int mm2, const char *const *pool2, int n_pool2,
+                            int randomized, int use_first,
+                            int32_t *tuples, int64_t *n_tuples, int32_t *total, int32_t *barcode1_only, int32_t *barcode2_only,
+                            char *err, size_t errcap) {
+    errbuf e = {err, errcap};
+    tmpl_t T1, T2;
+    int8_t *s1 = NULL, *s2 = NULL;
+    int len1 = 0, len2 = 0;
+    if (pool_to_sets(pool1, n_pool1, reverse1, &s1, &len1, &e)) return 1;
+    if (pool_to_sets(pool2, n_pool2, reverse2, &s2, &len2, &e)) { free(s1); return 1; }
+    int rc = 0;
+    if (!rc) rc = tmpl_init(&T1, tmpl1, tmpl_len1, reverse1 ? 1 : 0, &e);
+    if (!rc) rc = tmpl_init(&T2, tmpl2, tmpl_len2, reverse2 ? 1 : 0, &e);
+    /* SimpleSingleMatch.hpp:75-83, matcher 1 first */
+    if (!rc && T1.nreg != 1) rc = fail(&e, "expected one variable region in the constant template");
+    if (!rc && T1.fend[0] - T1.fstart[0] != len1)
+        rc = fail(&e, "length of barcode_pool sequences (%d) should be the same as the barcode_pool region (%d)", len1, T1.fend[0] - T1.fstart[0]);
+    lib_t L1 = {0}, L2 = {0};
+    if (!rc) rc = lib_from_sets(&L1, s1, n_pool1, len1, &e);
+    if (!rc && T2.nreg != 1) rc = fail(&e, "expected one variable region in the constant template");
+    if (!rc && T2.fend[0] - T2.fstart[0] != len2)
+        rc = fail(&e, "length of barcode_pool sequences (%d) should be the same as the barcode_pool region (%d)", len2, T2.fend[0] - T2.fstart[0]);
+    if (!rc) rc = lib_from_sets(&L2, s2, n_pool2, len2, &e);
+    free(s1); free(s2);
+    if (rc) { lib_free(&L1); lib_free(&L2); return 1; }
+    pcombo_t C = {&T1, &T2, &L1, &L2, mm1, mm2, use_first, randomized, 0};
+    int32_t tot = 0, b1o = 0, b2o = 0;
+    int64_t nt = 0;
+    for (int64_t r = 0; r < n_pairs; ++r) {
+        const char *a = seqs1 + offs1[r]; int na = (int)(offs1[r + 1] - offs1[r]);
+        const char *b = seqs2 + offs2[r]; int nb = (int)(offs2[r + 1] - offs2[r]);
+        int x, y;
+        ++tot;
+        switch (paired_combo_step(&C, a, na, b, nb, &x, &y)) {
+            case 1: tuples[2 * nt] = x; tuples[2 * nt + 1] = y; ++nt; break;
+            case 2: ++b1o; break;
+            case 3: ++b2o; break;
+            default: break;
+        }
+    }
+    *n_tuples = nt; *total = tot; *barcode1_only = b1o; *barcode2_only = b2o;
+    lib_free(&L1); lib_free(&L2);
     return 0;
 }
 

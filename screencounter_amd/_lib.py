@@ -69,6 +69,13 @@ SIGNATURES = {
                                                       C.c_char_p, C.c_char_p, C.c_int, C.c_int, c_str_p, C.c_int32,
                                                       C.c_int, C.c_int, C.c_int, i32_p, C.POINTER(i32_p), C.POINTER(i32_p), i64_p,
                                                       i32_p, i32_p, i32_p, C.c_char_p, C.c_size_t]),
+    "scg_count_combo_barcodes_paired": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_int, c_str_p, C.c_int32,
+                                                  C.c_char_p, C.c_char_p, C.c_int, C.c_int, c_str_p, C.c_int32,
+                                                  C.c_int, C.c_int, C.c_int, C.POINTER(i32_p), C.POINTER(i32_p), i64_p,
+                                                  i32_p, i32_p, i32_p, C.c_char_p, C.c_size_t]),
+    "scg_plan_paired_combo": (C.c_int, [C.POINTER(C.c_void_p), C.c_char_p, C.c_int, C.c_int, c_str_p, C.c_int32,
+                                        C.c_char_p, C.c_int, C.c_int, c_str_p, C.c_int32,
+                                        C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_size_t]),
     "scg_plan_read_diagnostics": (C.c_int, [C.c_void_p, i32_p, C.POINTER(i32_p), C.POINTER(i32_p), i64_p, i64_p, i32_p, i32_p,
                                             C.c_void_p, C.c_char_p, C.c_size_t]),
     "scg_plan_destroy": (None, [C.c_void_p]),

@@ -118,6 +118,33 @@ def count_dual_barcodes(path1: str, constant1: str, reverse1: bool, mismatches1:
     return counts[:len(pool1)].copy(), int(total.value)
 
 
+def count_combo_barcodes_paired(path1: str, constant1: str, reverse1: bool, mismatches1: int, pool1: Sequence[str],
+                                path2: str, constant2: str, reverse2: bool, mismatches2: int, pool2: Sequence[str],
+                                randomized: bool, use_first: bool, nthreads: int = 1):
+    """src/count_combo_barcodes_paired.cpp:57-95 -> (indices int32[2, K] 0-based sorted by (first, second),
+    freq int32[K], total, barcode1_only, barcode2_only)."""
+    L = _lib.load()
+    idx_p, freq_p = _lib.i32_p(), _lib.i32_p()
+    k = C.c_int64(0)
+    total, b1, b2 = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+    err = errbuf()
+    p1, _k1 = cstr_array(pool1)
+    p2, _k2 = cstr_array(pool2)
+    check(L.scg_count_combo_barcodes_paired(os.fspath(path1).encode(), constant1.encode(), int(bool(reverse1)), int(mismatches1), p1, len(pool1),
+                                            os.fspath(path2).encode(), constant2.encode(), int(bool(reverse2)), int(mismatches2), p2, len(pool2),
+                                            int(bool(randomized)), int(bool(use_first)), int(nthreads),
+                                            C.byref(idx_p), C.byref(freq_p), C.byref(k),
+                                            C.byref(total), C.byref(b1), C.byref(b2), err, _lib.ERRCAP), err)
+    K = int(k.value)
+    try:
+        idx = np.ctypeslib.as_array(idx_p, shape=(max(2 * K, 1),))[:2 * K].reshape(K, 2).T.copy()
+        freq = np.ctypeslib.as_array(freq_p, shape=(max(K, 1),))[:K].copy()
+    finally:
+        L.scg_free(idx_p)
+        L.scg_free(freq_p)
+    return idx.astype(np.int32), freq.astype(np.int32), int(total.value), int(b1.value), int(b2.value)
+
+
 def match_barcodes(sequences: Sequence[str], choices: Sequence[str], substitutions: int = 0, reverse: bool = False):
     """src/match_barcodes.cpp:6-37 -> (index int32[n] 0-based with -1 for NA, mismatches int32[n] with -1 for NA)."""
     L = _lib.load()
@@ -169,6 +196,10 @@ class ComboCounts:
     combinations: Dict[str, list]
     counts: np.ndarray
     nreads: int
+    # countPairedComboBarcodes metadata (R/countPairedComboBarcodes.R:110)
+    npairs: Optional[int] = None
+    barcode1_only: Optional[int] = None
+    barcode2_only: Optional[int] = None
 
 
 @dataclass
@@ -343,6 +374,54 @@ def matrixOfDualBarcodes(files: Sequence[Sequence[str]], choices, withDimnames: 
                      col_data={"paths1": [f[0] for f in files], "paths2": [f[1] for f in files], "npairs": [o.npairs for o in out]})
     if withDimnames:
         se.colnames = [os.path.basename(f[0]) for f in files]
+    return se
+
+
+def countPairedComboBarcodes(fastq: Sequence[str], choices, flank5=None, flank3=None, template=None, substitutions=0,
+                             find_best: bool = False, strand="original", num_threads: int = 1, randomized: bool = False,
+                             indices: bool = False) -> ComboCounts:
+    """R/countPairedComboBarcodes.R:93-112.  `choices` is a pair (or dict) of two pools; the result carries
+    npairs / barcode1_only / barcode2_only like the R function's metadata."""
+    if isinstance(choices, dict):
+        names = list(choices.keys())
+        pools = [list(v) for v in choices.values()]
+    else:
+        names = ["first", "second"]
+        pools = [list(choices[0]), list(choices[1])]
+    if template is not None:
+        t = _rep2(template)
+        template1, template2 = re.sub("[nN]", "-", t[0]), re.sub("[nN]", "-", t[1])
+    else:
+        f5, f3 = _rep2(flank5), _rep2(flank3)
+        template1 = f5[0] + "-" * len(pools[0][0]) + f3[0]
+        template2 = f5[1] + "-" * len(pools[1][0]) + f3[1]
+    subs = _rep2(substitutions)
+    strands = _rep2(strand)
+    for s in strands:
+        if s not in ("original", "reverse"):
+            raise ValueError("'strand' should be one of 'original', 'reverse'")
+    idx, freq, total, b1, b2 = count_combo_barcodes_paired(fastq[0], template1, strands[0] == "reverse", int(subs[0]), pools[0],
+                                                           fastq[1], template2, strands[1] == "reverse", int(subs[1]), pools[1],
+                                                           randomized, not find_best, num_threads)
+    keys = idx + 1
+    combos: Dict[str, list] = {}
+    for i, nm in enumerate(names):
+        col = keys[i].tolist()
+        combos[nm] = col if indices else [pools[i][k - 1] for k in col]
+    return ComboCounts(names=names, combinations=combos, counts=freq, nreads=total, npairs=total, barcode1_only=b1, barcode2_only=b2)
+
+
+def matrixOfPairedComboBarcodes(files: Sequence[Sequence[str]], withDimnames: bool = True, **kwargs) -> CountMatrix:
+    """R/countPairedComboBarcodes.R:119-140."""
+    out = [countPairedComboBarcodes(f, **kwargs) for f in files]
+    combos, mat = combineComboCounts(*out)
+    se = CountMatrix(counts=mat, row_data=combos,
+                     col_data={"paths1": [f[0] for f in files], "paths2": [f[1] for f in files],
+                               "npairs": [o.npairs for o in out], "barcode1.only": [o.barcode1_only for o in out],
+                               "barcode2.only": [o.barcode2_only for o in out]})
+    if withDimnames:
+        se.colnames = [os.path.basename(f[0]) for f in files]
+        se.rownames = [f"BARCODE_{i + 1}" for i in range(mat.shape[0])]
     return se
 
 

@@ -165,7 +165,7 @@ struct scg_plan {
     int32_t n_pool[2] = {0, 0};
     int max_mm1 = 0, max_mm2 = 0;
     bool rev1 = false, rev2 = false, randomized = false, use_first = true;
-    bool diagnostics = false;
+    int diagnostics = 0;         // 0 none, 1 include.invalid=TRUE, 2 paired combinations (ScgDualParams::diagnostics)
     std::vector<int32_t> first1, first2;   // sequence uid -> first pool index (DuplicateAction::FIRST)
 
     // device state
@@ -361,9 +361,50 @@ std::unique_ptr<scg_plan> compile_dual(const char* constant1, int reverse1, int 
         if (cells > (int64_t(1) << 28)) {
             throw Error(SCG_ERR_UNSUPPORTED, "include.invalid=TRUE needs n_unique1 x n_unique2 <= 2^28 cells in this engine");
         }
-        P->diagnostics = true;
+        P->diagnostics = 1;
         P->n_counters = static_cast<int64_t>(n_pool) + 2 + cells;
     }
+    P->max_mm1 = mismatches1; P->max_mm2 = mismatches2;
+    P->rev1 = reverse1 != 0; P->rev2 = reverse2 != 0;
+    P->randomized = randomized != 0;
+    P->use_first = use_first != 0;
+    return P;
+}
+
+// countPairedComboBarcodes: two independent SimpleSingleMatch matchers (CombinatorialBarcodesPairedEnd.hpp:85-118).
+std::unique_ptr<scg_plan> compile_paired_combo(const char* constant1, int reverse1, int mismatches1, const char* const* pool1, int32_t n1,
+                                               const char* constant2, int reverse2, int mismatches2, const char* const* pool2, int32_t n2,
+                                               int randomized, int use_first) {
+    if (!constant1 || !constant2 || (n1 > 0 && !pool1) || (n2 > 0 && !pool2) || n1 < 0 || n2 < 0) throw Error(SCG_ERR_INVALID, "null argument");
+    std::unique_ptr<scg_plan> P(new scg_plan);
+    P->kind = scg_plan::DUAL;
+    int len1 = scg::pool_length(pool1, n1);                    // src/utils.cpp:15-17
+    int len2 = scg::pool_length(pool2, n2);
+    P->ht1 = scg::parse_template(constant1, reverse1 ? 1 : 0);
+    P->ht2 = scg::parse_template(constant2, reverse2 ? 1 : 0);
+    auto check = [](const scg::HostTemplate& ht, int plen) {   // SimpleSingleMatch.hpp:75-83
+        if (ht.t.nreg != 1) throw Error(SCG_ERR_INVALID, "expected one variable region in the constant template");
+        if (ht.t.flen[0] != plen) {
+            throw Error(SCG_ERR_INVALID, "length of barcode_pool sequences (" + std::to_string(plen) +
+                        ") should be the same as the barcode_pool region (" + std::to_string(ht.t.flen[0]) + ")");
+        }
+    };
+    check(P->ht1, len1);
+    check(P->ht2, len2);
+    if (mismatches1 < 0 || mismatches2 < 0) throw Error(SCG_ERR_INVALID, "negative number of mismatches");
+    P->htab[0] = scg::build_index(pool1, n1, len1, mismatches1);     // values = pool indices; duplicates => error
+    P->htab[1] = scg::build_index(pool2, n2, len2, mismatches2);
+    P->scan1 = scg::build_scan(P->ht1.t, mismatches1);
+    P->scan2 = scg::build_scan(P->ht2.t, mismatches2);
+    int64_t cells = static_cast<int64_t>(n1) * static_cast<int64_t>(n2);
+    if (cells > (int64_t(1) << 28)) throw Error(SCG_ERR_UNSUPPORTED, "paired combinations need n_pool1 x n_pool2 <= 2^28 cells in this engine");
+    P->first1.resize(n1);
+    P->first2.resize(n2);
+    for (int32_t i = 0; i < n1; ++i) P->first1[i] = i;
+    for (int32_t i = 0; i < n2; ++i) P->first2[i] = i;
+    P->n_pool[0] = P->n_pool[1] = 0;                           // no list of valid pairs
+    P->diagnostics = 2;
+    P->n_counters = 2 + cells;                                 // [barcode1-only][barcode2-only][n1 x n2]
     P->max_mm1 = mismatches1; P->max_mm2 = mismatches2;
     P->rev1 = reverse1 != 0; P->rev2 = reverse2 != 0;
     P->randomized = randomized != 0;
@@ -422,7 +463,7 @@ void launch_batch_paired(scg_plan* P, const ScgReads& R1, const ScgReads& R2, in
     dp.index1 = P->tab[0].view; dp.index2 = P->tab[1].view; dp.pairs = P->pairs.view;
     dp.rev1 = P->rev1; dp.rev2 = P->rev2; dp.max_mm1 = P->max_mm1; dp.max_mm2 = P->max_mm2;
     dp.randomized = P->randomized; dp.use_first = P->use_first;
-    dp.diagnostics = P->diagnostics; dp.n_pool = P->n_pool[0]; dp.n_uid2 = static_cast<int32_t>(P->first2.size());
+    dp.diagnostics = P->diagnostics; dp.n_pool = P->diagnostics == 2 ? 0 : P->n_pool[0]; dp.n_uid2 = static_cast<int32_t>(P->first2.size());
     HIP_CHECK(scg::launch_dual(dp, std::max(P->ht1.t.len, P->ht2.t.len), R1, R2, n, plan_counters(P), P->error_flag.as<int32_t>(), stream));
     timer.stop();
     fold_replicas(P, stream);
@@ -758,6 +799,20 @@ int scg_plan_dual(scg_plan** plan_out, const char* constant1, int reverse1, int 
     });
 }
 
+int scg_plan_paired_combo(scg_plan** plan_out,
+                          const char* constant1, int reverse1, int mismatches1, const char* const* pool1, int32_t n_pool1,
+                          const char* constant2, int reverse2, int mismatches2, const char* const* pool2, int32_t n_pool2,
+                          int randomized, int use_first, int device, char* err, size_t errcap) {
+    return guarded(err, errcap, [&] {
+        if (!plan_out) throw Error(SCG_ERR_INVALID, "null argument");
+        *plan_out = nullptr;
+        auto P = compile_paired_combo(constant1, reverse1, mismatches1, pool1, n_pool1, constant2, reverse2, mismatches2, pool2, n_pool2,
+                                      randomized, use_first);
+        P->to_device(device);
+        *plan_out = P.release();
+    });
+}
+
 void scg_plan_destroy(scg_plan* plan) {
     if (!plan) return;
     int prev = -1;
@@ -929,6 +984,32 @@ int scg_count_dual_barcodes_diagnostics(const char* path1, const char* constant1
         std::vector<int32_t> all(static_cast<size_t>(P->n_counters) + 1);
         read_counters(P.get(), all.data());
         diagnostics_from_counters(P.get(), all, counts_out, invalid_indices_out, invalid_freq_out, k_out, barcode1_only_out, barcode2_only_out);
+        *total_out = static_cast<int32_t>(P->total);
+    });
+}
+
+int scg_count_combo_barcodes_paired(const char* path1, const char* constant1, int reverse1, int mismatches1,
+                                    const char* const* pool1, int32_t n_pool1,
+                                    const char* path2, const char* constant2, int reverse2, int mismatches2,
+                                    const char* const* pool2, int32_t n_pool2,
+                                    int randomized, int use_first, int nthreads,
+                                    int32_t** indices_out, int32_t** freq_out, int64_t* k_out,
+                                    int32_t* total_out, int32_t* barcode1_only_out, int32_t* barcode2_only_out,
+                                    char* err, size_t errcap) {
+    return guarded(err, errcap, [&] {
+        if (!path1 || !path2 || !indices_out || !freq_out || !k_out || !total_out || !barcode1_only_out || !barcode2_only_out) {
+            throw Error(SCG_ERR_INVALID, "null argument");
+        }
+        scg::FastqStream fq1(path1);                           // src/count_combo_barcodes_paired.cpp:75-79: readers first
+        scg::FastqStream fq2(path2);
+        auto P = compile_paired_combo(constant1, reverse1, mismatches1, pool1, n_pool1, constant2, reverse2, mismatches2, pool2, n_pool2,
+                                      randomized, use_first);
+        P->to_device(-1);
+        DeviceGuard g(P->device);
+        count_paired_files(P.get(), path1, path2, fq1, fq2, nthreads);
+        std::vector<int32_t> all(static_cast<size_t>(P->n_counters) + 1);
+        read_counters(P.get(), all.data());
+        diagnostics_from_counters(P.get(), all, nullptr, indices_out, freq_out, k_out, barcode1_only_out, barcode2_only_out);
         *total_out = static_cast<int32_t>(P->total);
     });
 }

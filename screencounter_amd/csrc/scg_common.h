@@ -182,6 +182,9 @@ struct ScgDualParams {
     // include.invalid=TRUE (handlers/DualBarcodesPairedEndWithDiagnostics.hpp): pairs without a valid
     // combination are searched mate by mate; counters = [n_pool valid][barcode1-only][barcode2-only]
     // [n_uid1 x n_uid2 invalid combinations by sequence uid]
+    // diagnostics == 2: countPairedComboBarcodes (handlers/CombinatorialBarcodesPairedEnd.hpp) -- there is no
+    // list of valid pairs at all (n_pool = 0), every pair is searched mate by mate, and a tie between
+    // different barcodes is ambiguous (DuplicateAction::ERROR) instead of going to the first.
     int32_t diagnostics;
     int32_t n_pool;
     int32_t n_uid2;

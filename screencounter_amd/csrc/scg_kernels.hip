@@ -181,7 +181,7 @@ __device__ __forceinline__ void dual_best(const ScgDualParams& P, const Read& a,
 // SimpleSingleMatch::search_first / search_best of one mate on one strand (byte-wise), with the
 // FIRST duplicate policy of the diagnostics path.  Returns found; index = sequence uid.
 __device__ __forceinline__ bool mate_search(const ScgTemplate* T, const ScgIndex& X, bool reverse, int max_mm, bool use_first,
-                                            const Read& rd, int& index, int& mism) {
+                                            bool keep_first, const Read& rd, int& index, int& mism) {
     bool found = false;
     index = -1; mism = 0;
     int best = max_mm + 1;
@@ -191,7 +191,7 @@ __device__ __forceinline__ bool mate_search(const ScgTemplate* T, const ScgIndex
         if (c > max_mm) continue;
         Query q = pack_region(rd.p + p + start, X.len, reverse);
         int idx, d;
-        index_match(X, q, max_mm - c, idx, d, true);
+        index_match(X, q, max_mm - c, idx, d, keep_first);
         if (idx < 0) continue;
         int tot = c + d;
         if (use_first) { index = idx; mism = tot; return true; }
@@ -272,13 +272,14 @@ __global__ __launch_bounds__(BLOCK) void dual_kernel(ScgDualParams P, ScgReads R
     int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n_pairs) return;
     Read a = get_read(R1, i), b = get_read(R2, i);
-    int idx = dual_pair(P, a, b);
+    int idx = P.diagnostics == 2 ? -1 : dual_pair(P, a, b);
     if (idx >= 0) {
         count_one(counts, idx);
     } else if (P.diagnostics) {
+        const bool keep_first = P.diagnostics == 1;
         diagnose_pair(P,
-            [&](int which, int& index, int& mism) { return mate_search(P.tmpl1, P.index1, P.rev1 != 0, P.max_mm1, P.use_first != 0, which ? b : a, index, mism); },
-            [&](int which, int& index, int& mism) { return mate_search(P.tmpl2, P.index2, P.rev2 != 0, P.max_mm2, P.use_first != 0, which ? b : a, index, mism); },
+            [&](int which, int& index, int& mism) { return mate_search(P.tmpl1, P.index1, P.rev1 != 0, P.max_mm1, P.use_first != 0, keep_first, which ? b : a, index, mism); },
+            [&](int which, int& index, int& mism) { return mate_search(P.tmpl2, P.index2, P.rev2 != 0, P.max_mm2, P.use_first != 0, keep_first, which ? b : a, index, mism); },
             counts);
     }
 }
@@ -430,7 +431,7 @@ __global__ __launch_bounds__(STAGE_BLOCK) __attribute__((amdgpu_num_sgpr(80))) v
 // Staged counterpart of mate_search.
 template<int NW, int NT, int NC>
 __device__ __forceinline__ bool mate_search_staged(const Tile<NW>& tile, const StagedRead& sr, const ScgScan& T, const ScgIndex& X,
-                                                   bool reverse, int max_mm, bool use_first, int& index, int& mism) {
+                                                   bool reverse, int max_mm, bool use_first, bool keep_first, int& index, int& mism) {
     bool found = false;
     index = -1; mism = 0;
     int best = max_mm + 1;
@@ -445,7 +446,7 @@ __device__ __forceinline__ bool mate_search_staged(const Tile<NW>& tile, const S
         if (c > max_mm) continue;
         Query q = region_query<NW>(tile, sr.bit + p + start, X.len, reverse);
         int idx, d;
-        index_match(X, q, max_mm - c, idx, d, true);
+        index_match(X, q, max_mm - c, idx, d, keep_first);
         if (idx < 0) continue;
         int tot = c + d;
         if (use_first) { index = idx; mism = tot; return true; }
@@ -534,7 +535,7 @@ __global__ __launch_bounds__(STAGE_BLOCK) void dual_staged_kernel(ScgDualParams 
         // One body for both orientations (template 1 on mate 1 / on mate 2 when randomized) and
         // both policies: DualBarcodesPairedEnd.hpp:353-381.
         const bool best_mode = !P.use_first;
-        const int norient = P.randomized ? 2 : 1;
+        const int norient = (DIAG && P.diagnostics == 2) ? 0 : (P.randomized ? 2 : 1);     // 2: no valid-pair list to search
         int best = 0;
         idx = -1;
         for (int o = 0; o < norient; ++o) {
@@ -554,14 +555,15 @@ __global__ __launch_bounds__(STAGE_BLOCK) void dual_staged_kernel(ScgDualParams 
             }
         }
         if (DIAG && idx < 0) {
+            const bool keep_first = P.diagnostics == 1;
             diagnose_pair(P,
                 [&](int which, int& index, int& mism) {
                     return mate_search_staged<NW, NT, NC>(which ? tile2 : tile1, which ? sb : sa, P.scan1, P.index1, P.rev1 != 0,
-                                                          P.max_mm1, P.use_first != 0, index, mism);
+                                                          P.max_mm1, P.use_first != 0, keep_first, index, mism);
                 },
                 [&](int which, int& index, int& mism) {
                     return mate_search_staged<NW, NT, NC>(which ? tile2 : tile1, which ? sb : sa, P.scan2, P.index2, P.rev2 != 0,
-                                                          P.max_mm2, P.use_first != 0, index, mism);
+                                                          P.max_mm2, P.use_first != 0, keep_first, index, mism);
                 },
                 counts);
         }

@@ -109,6 +109,22 @@ class Plan:
                               int(bool(randomized)), int(bool(use_first)), int(bool(diagnostics)), int(device), err, _lib.ERRCAP), err)
         return cls(h.value, "dual", (len(pool1),), device)
 
+    @classmethod
+    def paired_combo(cls, template1: str, reverse1: bool, mismatches1: int, pool1: Sequence[str],
+                     template2: str, reverse2: bool, mismatches2: int, pool2: Sequence[str],
+                     randomized: bool = False, use_first: bool = True, device: int = -1) -> "Plan":
+        """countPairedComboBarcodes: counted with count_paired(), read with read_diagnostics()
+        (indices/freq = the combinations; `counts` is empty)."""
+        L = _lib.load()
+        h = C.c_void_p()
+        err = errbuf()
+        p1, _k1 = cstr_array(pool1)
+        p2, _k2 = cstr_array(pool2)
+        check(L.scg_plan_paired_combo(C.byref(h), template1.encode(), int(bool(reverse1)), int(mismatches1), p1, len(pool1),
+                                      template2.encode(), int(bool(reverse2)), int(mismatches2), p2, len(pool2),
+                                      int(bool(randomized)), int(bool(use_first)), int(device), err, _lib.ERRCAP), err)
+        return cls(h.value, "dual", (0,), device)
+
     def close(self) -> None:
         if self._h:
             self._lib.scg_plan_destroy(self._h)

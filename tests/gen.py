@@ -184,6 +184,17 @@ def random_dual_case(rng: random.Random, hazard_free: bool = True, sizes=(1, 30,
                 randomized=randomized, use_first=first, reads1=r1s, reads2=r2s)
 
 
+def random_paired_combo_case(rng: random.Random, sizes=(1, 30, 150), max_mm: int = 2) -> dict:
+    """countPairedComboBarcodes: the reads of a dual case against the two pools taken independently
+    (distinct barcodes, no list of valid pairs; close barcodes allowed so that ties occur)."""
+    c = random_dual_case(rng, hazard_free=rng.random() < 0.5, sizes=sizes, max_mm=max_mm)
+    pool1 = list(dict.fromkeys(c["pool1"]))
+    pool2 = list(dict.fromkeys(c["pool2"]))
+    return dict(kind="paired_combo", template1=c["template1"], reverse1=c["reverse1"], mismatches1=c["mismatches1"], pool1=pool1,
+                template2=c["template2"], reverse2=c["reverse2"], mismatches2=c["mismatches2"], pool2=pool2,
+                randomized=c["randomized"], use_first=c["use_first"], reads1=c["reads1"], reads2=c["reads2"])
+
+
 def random_match_case(rng: random.Random) -> dict:
     vlen = rng.choice([3, 5, 8, 12])
     alphabet = rng.choice(["AC", BASES])

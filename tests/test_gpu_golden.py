@@ -44,6 +44,14 @@ def run_file_level(sc, c, tmp_path, gz=False):
                                                                     c["randomized"], c["use_first"], True, 1)
         return {"counts": counts.tolist(), "indices": idx.tolist(), "freq": freq.tolist(), "total": total,
                 "barcode1_only": b1, "barcode2_only": b2}
+    if k == "paired_combo":
+        f1, f2 = str(tmp_path / ("p1" + ext)), str(tmp_path / ("p2" + ext))
+        write_fastq(f1, c["reads1"], gz=gz)
+        write_fastq(f2, c["reads2"], gz=gz)
+        idx, freq, total, b1, b2 = sc.count_combo_barcodes_paired(f1, c["template1"], c["reverse1"], c["mismatches1"], c["pool1"],
+                                                                  f2, c["template2"], c["reverse2"], c["mismatches2"], c["pool2"],
+                                                                  c["randomized"], c["use_first"], 1)
+        return {"indices": idx.tolist(), "freq": freq.tolist(), "total": total, "barcode1_only": b1, "barcode2_only": b2}
     idx, mm = sc.match_barcodes(c["sequences"], c["choices"], c["substitutions"], c["reverse"])
     return {"index": idx.tolist(), "mismatches": mm.tolist()}
 

@@ -174,6 +174,25 @@ def test_template_longer_than_64(sc, oracle, gpu):
 
 
 @pytest.mark.parametrize("seed", range(5))
+def test_paired_combo_random(sc, oracle, gpu, seed):
+    """countPairedComboBarcodes: combinations of independently matched mates, barcode1/2-only tallies."""
+    rng = random.Random(6500 + seed)
+    for _ in range(20):
+        case = gen.random_paired_combo_case(rng)
+        exp = oracle.count_combo_paired(case["reads1"], case["reads2"], case["template1"], case["reverse1"], case["mismatches1"], case["pool1"],
+                                        case["template2"], case["reverse2"], case["mismatches2"], case["pool2"], case["randomized"], case["use_first"])
+        s1, o1 = sc.upload_reads(case["reads1"], gpu)
+        s2, o2 = sc.upload_reads(case["reads2"], gpu)
+        with sc.Plan.paired_combo(case["template1"], case["reverse1"], case["mismatches1"], case["pool1"],
+                                  case["template2"], case["reverse2"], case["mismatches2"], case["pool2"],
+                                  case["randomized"], case["use_first"]) as plan:
+            plan.count_paired(s1, s2, o1, o2)
+            got = plan.read_diagnostics()
+        for key in exp:
+            assert np.array_equal(np.asarray(exp[key]), np.asarray(got[key])), (key, case, exp, got)
+
+
+@pytest.mark.parametrize("seed", range(5))
 def test_dual_diagnostics_random(sc, oracle, gpu, seed):
     """include.invalid=TRUE: valid-pair counts, invalid combinations, barcode1/2-only tallies."""
     rng = random.Random(6000 + seed)

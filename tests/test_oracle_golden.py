@@ -28,6 +28,11 @@ def run_oracle(oracle, c):
                                    c["template2"], c["reverse2"], c["mismatches2"], c["pool2"], c["randomized"], c["use_first"])
         return {"counts": d["counts"].tolist(), "indices": d["indices"].tolist(), "freq": d["freq"].tolist(), "total": d["total"],
                 "barcode1_only": d["barcode1_only"], "barcode2_only": d["barcode2_only"]}
+    if k == "paired_combo":
+        d = oracle.count_combo_paired(c["reads1"], c["reads2"], c["template1"], c["reverse1"], c["mismatches1"], c["pool1"],
+                                      c["template2"], c["reverse2"], c["mismatches2"], c["pool2"], c["randomized"], c["use_first"])
+        return {"indices": d["indices"].tolist(), "freq": d["freq"].tolist(), "total": d["total"],
+                "barcode1_only": d["barcode1_only"], "barcode2_only": d["barcode2_only"]}
     idx, mm = oracle.match_barcodes(c["sequences"], c["choices"], c["substitutions"], c["reverse"])
     return {"index": idx.tolist(), "mismatches": mm.tolist()}
 
