@@ -55,6 +55,12 @@ const char* scg_version(void);
 /* Number of visible HIP devices (0 when there is none; never fails). */
 int scg_device_count(void);
 
+/* Makes `device` the calling thread's current HIP device.  The file-level entry points below run on
+ * $SCG_DEVICE if set, else on the calling thread's current device, so a host that counts several
+ * files at once (the matrixOf* functions: R/countSingleBarcodes.R:112-126 and siblings, BiocParallel
+ * workers in the reference) gives each worker thread its own GPU with this call. */
+int scg_set_device(int device, char* err, size_t errcap);
+
 /* ---------------------------------------------------------------------------------------------
  * File-level entry points: what the Rcpp shim binds.
  * ------------------------------------------------------------------------------------------- */

@@ -245,9 +245,43 @@ def countSingleBarcodes(fastq: str, choices: Sequence[str], flank5: str = "", fl
     return BarcodeCounts(choices=choices, counts=counts, nreads=total)
 
 
-def matrixOfSingleBarcodes(files: Sequence[str], choices: Sequence[str], withDimnames: bool = True, **kwargs) -> CountMatrix:
-    """R/countSingleBarcodes.R:112-126 (files are processed one after another on the GPU)."""
-    out = [countSingleBarcodes(f, choices, **kwargs) for f in files]
+def _map_files(fn, files, devices=None):
+    """The matrixOf* schedulers (R/countSingleBarcodes.R:117 `bplapply(files, ...)` and siblings): file i is
+    counted on GPU devices[i % len(devices)] by a worker thread of this process (one thread per GPU; the C ABI
+    releases the GIL and every call owns its plan, so the calls are independent).  devices=None uses every
+    visible GPU.  Results come back in file order."""
+    files = list(files)
+    L = _lib.load()
+    if devices is None:
+        devices = list(range(max(int(L.scg_device_count()), 1)))
+    devices = list(devices)
+    if len(files) <= 1 or len(devices) <= 1:
+        if files and devices and int(L.scg_device_count()) > 0:
+            err = errbuf()
+            check(L.scg_set_device(int(devices[0]), err, _lib.ERRCAP), err)
+        return [fn(f) for f in files]
+    import queue
+    from concurrent.futures import ThreadPoolExecutor
+    free = queue.Queue()
+    for d in devices:
+        free.put(d)
+
+    def job(f):
+        d = free.get()                      # one file at a time per GPU
+        try:
+            err = errbuf()
+            check(L.scg_set_device(int(d), err, _lib.ERRCAP), err)
+            return fn(f)
+        finally:
+            free.put(d)
+
+    with ThreadPoolExecutor(max_workers=len(devices)) as pool:
+        return list(pool.map(job, files))
+
+
+def matrixOfSingleBarcodes(files: Sequence[str], choices: Sequence[str], withDimnames: bool = True, devices=None, **kwargs) -> CountMatrix:
+    """R/countSingleBarcodes.R:112-126; files are spread over the visible GPUs (`devices`)."""
+    out = _map_files(lambda f: countSingleBarcodes(f, choices, **kwargs), files, devices)
     mat = np.stack([o.counts for o in out], axis=1) if out else np.zeros((len(choices), 0), dtype=np.int32)
     se = CountMatrix(counts=mat, row_data={"choices": list(choices)},
                      col_data={"paths": list(files), "nreads": [o.nreads for o in out], "nmapped": mat.sum(axis=0).astype(np.int64).tolist()})
@@ -309,9 +343,9 @@ def combineComboCounts(*results: ComboCounts):
     return combos, mat
 
 
-def matrixOfComboBarcodes(files: Sequence[str], withDimnames: bool = True, **kwargs) -> CountMatrix:
+def matrixOfComboBarcodes(files: Sequence[str], withDimnames: bool = True, devices=None, **kwargs) -> CountMatrix:
     """R/countComboBarcodes.R:149-164."""
-    out = [countComboBarcodes(f, **kwargs) for f in files]
+    out = _map_files(lambda f: countComboBarcodes(f, **kwargs), files, devices)
     combos, mat = combineComboCounts(*out)
     se = CountMatrix(counts=mat, row_data=combos,
                      col_data={"paths": list(files), "nreads": [o.nreads for o in out], "nmapped": mat.sum(axis=0).astype(np.int64).tolist()})
@@ -365,9 +399,9 @@ def countDualBarcodes(fastq: Sequence[str], choices, flank5=None, flank3=None, t
                       barcode1_only=b1, barcode2_only=b2, invalid_pair=int(freq.sum()))
 
 
-def matrixOfDualBarcodes(files: Sequence[Sequence[str]], choices, withDimnames: bool = True, **kwargs) -> CountMatrix:
+def matrixOfDualBarcodes(files: Sequence[Sequence[str]], choices, withDimnames: bool = True, devices=None, **kwargs) -> CountMatrix:
     """R/countDualBarcodes.R:205-224 (include.invalid=FALSE)."""
-    out = [countDualBarcodes(f, choices, **kwargs) for f in files]
+    out = _map_files(lambda f: countDualBarcodes(f, choices, **kwargs), files, devices)
     nrow = len(out[0].counts) if out else 0
     mat = np.stack([o.counts for o in out], axis=1) if out else np.zeros((nrow, 0), dtype=np.int32)
     se = CountMatrix(counts=mat, row_data=out[0].choices if out else {},
@@ -411,9 +445,9 @@ def countPairedComboBarcodes(fastq: Sequence[str], choices, flank5=None, flank3=
     return ComboCounts(names=names, combinations=combos, counts=freq, nreads=total, npairs=total, barcode1_only=b1, barcode2_only=b2)
 
 
-def matrixOfPairedComboBarcodes(files: Sequence[Sequence[str]], withDimnames: bool = True, **kwargs) -> CountMatrix:
+def matrixOfPairedComboBarcodes(files: Sequence[Sequence[str]], withDimnames: bool = True, devices=None, **kwargs) -> CountMatrix:
     """R/countPairedComboBarcodes.R:119-140."""
-    out = [countPairedComboBarcodes(f, **kwargs) for f in files]
+    out = _map_files(lambda f: countPairedComboBarcodes(f, **kwargs), files, devices)
     combos, mat = combineComboCounts(*out)
     se = CountMatrix(counts=mat, row_data=combos,
                      col_data={"paths1": [f[0] for f in files], "paths2": [f[1] for f in files],

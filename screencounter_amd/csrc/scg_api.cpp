@@ -767,6 +767,17 @@ int scg_parse_fastq(const char* path, char** seqs_out, uint64_t** offsets_out, i
     });
 }
 
+int scg_set_device(int device, char* err, size_t errcap) {
+    return guarded(err, errcap, [&] {
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) throw Error(SCG_ERR_DEVICE, "no HIP device available: libscg has no CPU fallback");
+        if (device < 0 || device >= n) {
+            throw Error(SCG_ERR_DEVICE, "HIP device " + std::to_string(device) + " out of range (" + std::to_string(n) + " visible)");
+        }
+        HIP_CHECK(hipSetDevice(device));
+    });
+}
+
 int scg_plan_single(scg_plan** plan_out, const char* constant, int strand, const char* const* pool, int32_t n_pool,
                     int mismatches, int use_first, int device, char* err, size_t errcap) {
     return guarded(err, errcap, [&] {

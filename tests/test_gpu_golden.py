@@ -113,6 +113,36 @@ def test_r_level_wrappers(sc, gpu, tmp_path):
     assert int(d.counts.sum()) == 4 and d.npairs == 5
 
 
+def test_matrix_of_files_scheduled_over_devices(sc, oracle, gpu, tmp_path):
+    """matrixOf* (SURVEY 8f rank 3): files are handed to one worker thread per listed device; listing GPU 0
+    twice exercises the concurrent path on a one-GPU box.  Columns must equal the per-file results."""
+    import random
+    from tests import gen
+    rng = random.Random(77)
+    template = "ACGTAC" + "N" * 8 + "TGCATG"
+    pool = gen.make_pool(rng, 12, 8, "ACGT")
+    files, expect, nreads = [], [], []
+    for i in range(5):
+        reads = gen.make_reads(rng, template.replace("N", "-"), [pool], 300 + 40 * i, 2, 0.02, 0.005, 0.0, 0.1, 12)
+        fq = str(tmp_path / f"m{i}.fastq")
+        write_fastq(fq, reads)
+        files.append(fq)
+        counts, total = oracle.count_single(reads, template.replace("N", "-"), 2, pool, 1, True)
+        expect.append(counts)
+        nreads.append(total)
+    for devices in ([0], [0, 0], None):
+        se = sc.matrixOfSingleBarcodes(files, pool, template=template, substitutions=1, devices=devices)
+        assert np.array_equal(se.counts, np.stack(expect, axis=1))
+        assert se.col_data["nreads"] == nreads and se.col_data["paths"] == files
+    pairs = [(f, f) for f in files]        # mates must have equal read counts
+    seq = sc.matrixOfDualBarcodes(pairs[:3], {"a": pool, "b": pool}, template=template, substitutions=1, devices=[0])
+    par = sc.matrixOfDualBarcodes(pairs[:3], {"a": pool, "b": pool}, template=template, substitutions=1, devices=[0, 0, 0])
+    assert np.array_equal(seq.counts, par.counts) and seq.col_data == par.col_data
+    seq = sc.matrixOfPairedComboBarcodes(pairs[:3], choices=[pool, pool], template=template, substitutions=1, devices=[0])
+    par = sc.matrixOfPairedComboBarcodes(pairs[:3], choices=[pool, pool], template=template, substitutions=1, devices=[0, 0])
+    assert np.array_equal(seq.counts, par.counts) and seq.row_data == par.row_data and seq.col_data == par.col_data
+
+
 def test_paired_files_with_different_read_counts(sc, gpu, tmp_path):
     f1, f2 = str(tmp_path / "a.fastq"), str(tmp_path / "b.fastq")
     write_fastq(f1, ["ACGTAATGCA"] * 3)
