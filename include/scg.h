@@ -96,6 +96,16 @@ int scg_count_dual_barcodes(const char* path1, const char* constant1, int revers
                             int32_t* counts_out, int32_t* total_out,
                             char* err, size_t errcap);
 
+/* countDualBarcodesSingleEnd hot path: every variable region of the construct lies in
+ * one read; pools[r][c] over the regions r spells valid combination c.  Replaces
+ * src/count_dual_barcodes_single_end.cpp:53-87, non-diagnostic branch (:27-34, kaori::DualBarcodesSingleEnd).
+ * pools: n_regions arrays of n_pools[r] strings; counts_out: n_pools[0] entries.  This engine handles 1 or 2
+ * regions with at most 64 bases in total and diagnostics = 0 (SCG_ERR_UNSUPPORTED otherwise). */
+int scg_count_dual_barcodes_single_end(const char* path, const char* constant,
+                                       const char* const* const* pools, const int32_t* n_pools, int32_t n_regions,
+                                       int strand, int mismatches, int use_first, int diagnostics, int nthreads,
+                                       int32_t* counts_out, int32_t* total_out, char* err, size_t errcap);
+
 /* countPairedComboBarcodes hot path: one variable region per mate, every
  * (pool1, pool2) combination counts.  Replaces src/count_combo_barcodes_paired.cpp:57-95
  * (kaori::CombinatorialBarcodesPairedEnd).  Outputs mirror its 5-list: a malloc'd 2 x K column-major
@@ -169,6 +179,11 @@ int scg_plan_dual(scg_plan** plan_out,
                   const char* constant2, int reverse2, int mismatches2, const char* const* pool2,
                   int32_t n_pool, int randomized, int use_first, int diagnostics,
                   int device, char* err, size_t errcap);
+
+/* Plan for countDualBarcodesSingleEnd: counted with scg_count_batch, read with scg_plan_read. */
+int scg_plan_dual_single_end(scg_plan** plan_out, const char* constant, int strand,
+                             const char* const* const* pools, const int32_t* n_pools, int32_t n_regions,
+                             int mismatches, int use_first, int device, char* err, size_t errcap);
 
 /* Plan for countPairedComboBarcodes: counted with scg_count_batch_paired, read with
  * scg_plan_read_diagnostics (counts_out = NULL; the "invalid" outputs are the combinations). */

@@ -179,6 +179,25 @@ def fuzz_combo_paired(rng, ora, ref, tmpdir, it):
     return "ok"
 
 
+def fuzz_dual_single_end(rng, ora, ref, tmpdir, it):
+    from tests import gen
+    c = gen.random_dual_single_end_case(rng)
+    fq = os.path.join(tmpdir, f"e{it}.fastq")
+    write_fastq(fq, c["reads"])
+    try:
+        exp = ref.count_dual_single_end(fq, c["template"], c["strand"], c["pools"], c["mismatches"], c["use_first"], 1)
+    except OracleError:
+        try:
+            ora.count_dual_single_end(c["reads"], c["template"], c["strand"], c["pools"], c["mismatches"], c["use_first"])
+        except OracleError:
+            return "both-error"
+        raise
+    got = ora.count_dual_single_end(c["reads"], c["template"], c["strand"], c["pools"], c["mismatches"], c["use_first"])
+    if not (got[1] == exp[1] and np.array_equal(got[0], exp[0])):
+        raise AssertionError(f"dual-single-end mismatch: {c}\nexp={exp}\ngot={got}")
+    return "ok"
+
+
 def fuzz_match(rng, ora, ref):
     vlen = rng.choice([3, 5, 8, 12])
     alphabet = rng.choice(["AC", BASES])
@@ -219,6 +238,7 @@ def main():
                              ("dual-hazard", lambda: fuzz_dual(rng, ora, ref, tmp, it, False)),
                              ("dual-diag", lambda: fuzz_dual_diag(rng, ora, ref, tmp, it)),
                              ("combo-paired", lambda: fuzz_combo_paired(rng, ora, ref, tmp, it)),
+                             ("dual-single-end", lambda: fuzz_dual_single_end(rng, ora, ref, tmp, it)),
                              ("match", lambda: fuzz_match(rng, ora, ref))):
                 res = fn()
                 tally[f"{name}:{res}"] = tally.get(f"{name}:{res}", 0) + 1

@@ -70,6 +70,11 @@ def run_case(ref: KaoriRef, case: dict, tmp: str) -> dict:
                                     case["randomized"], case["use_first"], 1)
             out["expect"] = {"counts": d["counts"].tolist(), "indices": d["indices"].tolist(), "freq": d["freq"].tolist(),
                              "total": d["total"], "barcode1_only": d["barcode1_only"], "barcode2_only": d["barcode2_only"]}
+        elif k == "dual_single_end":
+            fq = os.path.join(tmp, "e.fastq")
+            write_fastq(fq, case["reads"])
+            counts, total = ref.count_dual_single_end(fq, case["template"], case["strand"], case["pools"], case["mismatches"], case["use_first"], 1)
+            out["expect"] = {"counts": counts.tolist(), "total": total}
         elif k == "paired_combo":
             f1, f2 = os.path.join(tmp, "p1.fastq"), os.path.join(tmp, "p2.fastq")
             write_fastq(f1, case["reads1"])
@@ -246,6 +251,10 @@ def main() -> None:
             rnd.append(run_case(ref, c, tmp))
         for _ in range(40):     # appended last: the cases above keep their seeds
             rnd.append(run_case(ref, gen.random_paired_combo_case(rng, sizes=small, max_mm=2), tmp))
+        for i in range(40):
+            rnd.append(run_case(ref, gen.random_dual_single_end_case(rng, sizes=small, wide=(i % 2 == 0)), tmp))
+        for _ in range(20):     # single barcodes of 33..64 bases (wide keys)
+            rnd.append(run_case(ref, gen.random_single_case(rng, max_vlen=64, sizes=small, min_vlen=33), tmp))
         with open(os.path.join(OUT, "kaori_random.json"), "w") as f:
             json.dump({"generator": "oracle/gen_golden.py", "reference": "kaori v1.1.1 (screenCounter 1.5.1)", "seed": 20261003, "cases": rnd}, f)
 

@@ -247,6 +247,40 @@ int kref_count_dual_diag(const char* path1, const char* tmpl1, int reverse1, int
     return 0;
 }
 
+/* src/count_dual_barcodes_single_end.cpp:53-87, non-diagnostic branch. */
+int kref_count_dual_single_end(const char* path, const char* tmpl, int strand,
+                               const char* const* const* pools, const int* n_pools, int n_regions,
+                               int mm, int use_first, int nthreads, int32_t* counts, int32_t* total,
+                               char* err, size_t errcap) {
+    try {
+        byteme::SomeFileReader reader(path);
+        std::vector<kaori::BarcodePool> ptr_pools;
+        for (int r = 0; r < n_regions; ++r) ptr_pools.push_back(make_pool(pools[r], n_pools[r]));
+        std::string constant(tmpl);
+        auto run = [&](auto tag) {
+            constexpr size_t N = decltype(tag)::value;
+            typename kaori::DualBarcodesSingleEnd<N>::Options options;
+            options.strand = to_strand(strand);
+            options.max_mismatches = mm;
+            options.use_first = use_first != 0;
+            kaori::DualBarcodesSingleEnd<N> handler(constant.c_str(), constant.size(), ptr_pools, options);
+            kaori::process_single_end_data(&reader, handler, nthreads);
+            const auto& c = handler.get_counts();
+            std::copy(c.begin(), c.end(), counts);
+            *total = handler.get_total();
+        };
+        size_t len = constant.size();
+        if (len <= 32) run(std::integral_constant<size_t, 32>());
+        else if (len <= 64) run(std::integral_constant<size_t, 64>());
+        else if (len <= 128) run(std::integral_constant<size_t, 128>());
+        else if (len <= 256) run(std::integral_constant<size_t, 256>());
+        else throw std::runtime_error("lacking compile-time support for constant regions longer than 256 bp");
+    } catch (std::exception& e) {
+        return set_err(err, errcap, e.what());
+    }
+    return 0;
+}
+
 /* src/count_combo_barcodes_paired.cpp:57-95: sorted combinations (2 x K, 0-based) with frequencies,
  * total, barcode1-only, barcode2-only. */
 int kref_count_combo_paired(const char* path1, const char* tmpl1, int reverse1, int mm1, const char* const* pool1, int n_pool1,

@@ -26,6 +26,18 @@ KAORI_SO = os.path.join(_HERE, "_ref", "libkaori_ref.so")
 _ERRCAP = 1024
 
 
+def _cstr_matrix(pools):
+    """list of pools -> (const char* const* const*, int[] sizes, keepalive)"""
+    keep = []
+    rows = (C.POINTER(C.c_char_p) * max(len(pools), 1))()
+    for r, p in enumerate(pools):
+        arr, k = _cstr_array(p)
+        keep.append((arr, k))
+        rows[r] = C.cast(arr, C.POINTER(C.c_char_p))
+    sizes = (C.c_int * max(len(pools), 1))(*[len(p) for p in pools])
+    return rows, sizes, keep
+
+
 class OracleError(RuntimeError):
     """The checker reported an error (the reference would have thrown std::runtime_error)."""
 
@@ -192,6 +204,24 @@ class Oracle:
         return dict(counts=counts[:len(pool1)].copy(), indices=tuples[:2 * k].reshape(k, 2).T.copy(), freq=freq[:k].copy(),
                     total=int(total.value), barcode1_only=int(b1.value), barcode2_only=int(b2.value))
 
+    def count_dual_single_end(self, reads, template: str, strand: int, pools: Sequence[Sequence[str]], mismatches: int, use_first: bool):
+        """countDualBarcodesSingleEnd -> (counts int32[n], total)"""
+        s, o = _as_batch(reads)
+        n = len(o) - 1
+        nch = len(pools[0]) if pools else 0
+        counts = np.zeros(max(nch, 1), dtype=np.int32)
+        total = C.c_int32(0)
+        err = C.create_string_buffer(_ERRCAP)
+        rows, sizes, _keep = _cstr_matrix(pools)
+        sp, _a = _ptr(s, C.c_char)
+        rc = self.L.scgo_count_dual_single_end(sp, o.ctypes.data_as(C.POINTER(C.c_uint64)), C.c_int64(n),
+                                               template.encode(), C.c_int(len(template)), C.c_int(strand),
+                                               rows, sizes, C.c_int(len(pools)), C.c_int(mismatches), C.c_int(int(use_first)),
+                                               counts.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(total), err, C.c_size_t(_ERRCAP))
+        if rc:
+            raise OracleError(err.value.decode())
+        return counts[:nch].copy(), int(total.value)
+
     def count_combo_paired(self, reads1, reads2, template1: str, reverse1: bool, mm1: int, pool1: Sequence[str],
                            template2: str, reverse2: bool, mm2: int, pool2: Sequence[str],
                            randomized: bool, use_first: bool):
@@ -353,6 +383,20 @@ class KaoriRef:
             self.L.kref_free(freq_p)
         return dict(counts=counts[:len(pool1)].copy(), indices=idx, freq=freq, total=int(total.value),
                     barcode1_only=int(b1.value), barcode2_only=int(b2.value))
+
+    def count_dual_single_end(self, fastq: str, template: str, strand: int, pools: Sequence[Sequence[str]], mismatches: int,
+                              use_first: bool, nthreads: int = 1):
+        nch = len(pools[0]) if pools else 0
+        counts = np.zeros(max(nch, 1), dtype=np.int32)
+        total = C.c_int32(0)
+        err = C.create_string_buffer(_ERRCAP)
+        rows, sizes, _keep = _cstr_matrix(pools)
+        rc = self.L.kref_count_dual_single_end(fastq.encode(), template.encode(), C.c_int(strand), rows, sizes, C.c_int(len(pools)),
+                                               C.c_int(mismatches), C.c_int(int(use_first)), C.c_int(nthreads),
+                                               counts.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(total), err, C.c_size_t(_ERRCAP))
+        if rc:
+            raise OracleError(err.value.decode())
+        return counts[:nch].copy(), int(total.value)
 
     def count_combo_paired(self, fastq1: str, template1: str, reverse1: bool, mm1: int, pool1: Sequence[str],
                            fastq2: str, template2: str, reverse2: bool, mm2: int, pool2: Sequence[str],

@@ -909,6 +909,99 @@ int scgo_count_dual_diag(const char *seqs1, const uint64_t *offs1, const char *s
     return 0;
 }
 
+/* countDualBarcodesSingleEnd: src/count_dual_barcodes_single_end.cpp:11-35 (non-diagnostic branch) over
+ * kaori::DualBarcodesSingleEnd (handlers/DualBarcodesSingleEnd.hpp:66-123, :140-232): any number of
+ * variable regions in one template; pools[r][c] over r spells combination c; the window's regions are
+ * concatenated in read order and searched in the concatenated library (reverse strand: the library of
+ * reverse complements) with the budget left after the constant mismatches. */
+int scgo_count_dual_single_end(const char *seqs, const uint64_t *offsets, int64_t n_reads,
+                               const char *tmpl, int tmpl_len, int strand,
+                               const char *const *const *pools, const int *n_pools, int n_regions,
+                               int max_mm, int use_first,
+                               int32_t *counts /* n_pools[0], zeroed here */, int32_t *total,
+                               char *err, size_t errcap) {
+    errbuf e = {err, errcap};
+    /* format_pointers per pool first (src/count_dual_barcodes_single_end.cpp:66-71, src/utils.cpp:15-17) */
+    int plen[SCGO_MAX_TEMPLATE];
+    if (n_regions > SCGO_MAX_TEMPLATE) return fail(&e, "too many pools");
+    for (int r = 0; r < n_regions; ++r) {
+        plen[r] = n_pools[r] ? (int)strlen(pools[r][0]) : 0;
+        for (int i = 1; i < n_pools[r]; ++i) {
+            if ((int)strlen(pools[r][i]) != plen[r])
+                return fail(&e, "variable regions should all have the same length (%d)", plen[r]);
+        }
+    }
+    tmpl_t T;
+    if (tmpl_init(&T, tmpl, tmpl_len, strand, &e)) return 1;
+    if (T.nreg != n_regions) return fail(&e, "length of 'barcode_pools' should equal the number of variable regions");
+    int clen = 0;
+    for (int r = 0; r < n_regions; ++r) {
+        int rlen = T.fend[r] - T.fstart[r];
+        if (rlen != plen[r])
+            return fail(&e, "length of variable region %d (%d) should be the same as its sequences (%d)", r + 1, rlen, plen[r]);
+        clen += rlen;
+    }
+    int n_choices = n_regions ? n_pools[0] : 0;
+    for (int r = 1; r < n_regions; ++r) {
+        if (n_pools[r] != n_choices) return fail(&e, "all entries of 'barcode_pools' should have the same length");
+    }
+    char **combined = (char **)malloc(sizeof(char *) * (size_t)(n_choices + 1));
+    for (int c = 0; c < n_choices; ++c) {
+        combined[c] = (char *)malloc((size_t)clen + 1);
+        int off = 0;
+        for (int r = 0; r < n_regions; ++r) { memcpy(combined[c] + off, pools[r][c], plen[r]); off += plen[r]; }
+        combined[c][clen] = 0;
+    }
+    lib_t F = {0}, R = {0};
+    int rc = 0;
+    if (T.fwd) rc = lib_init(&F, (const char *const *)combined, n_choices, 0, &e);
+    if (!rc && T.rev) rc = lib_init(&R, (const char *const *)combined, n_choices, 1, &e);
+    for (int c = 0; c < n_choices; ++c) free(combined[c]);
+    free(combined);
+    if (rc) { lib_free(&F); lib_free(&R); return 1; }
+
+    char *buffer = (char *)malloc((size_t)clen + 1);
+    memset(counts, 0, sizeof(int32_t) * (size_t)n_choices);
+    int32_t tot = 0;
+    for (int64_t r = 0; r < n_reads; ++r) {
+        const char *read = seqs + offsets[r];
+        int n = (int)(offsets[r + 1] - offsets[r]);
+        int found = 0, index = -1, best = max_mm + 1;
+        for (int p = 0; p + T.len <= n; ++p) {
+            int stop = 0;
+            for (int s = 0; s < 2 && !stop; ++s) {       /* forward before reverse: :178-193 */
+                if (s == 0 ? !T.fwd : !T.rev) continue;
+                int c = const_mm(&T, read, p, s);
+                if (c > max_mm) continue;
+                int off = 0;
+                for (int v = 0; v < T.nreg; ++v) {       /* find_match: :149-160 */
+                    int a = s ? T.rstart[v] : T.fstart[v], b = s ? T.rend[v] : T.fend[v];
+                    memcpy(buffer + off, read + p + a, (size_t)(b - a));
+                    off += b - a;
+                }
+                int idx, d;
+                lib_match(s ? &R : &F, buffer, max_mm - c, &idx, &d);
+                if (idx < 0) continue;
+                int tmm = c + d;
+                if (use_first) {
+                    found = 1; index = idx; stop = 1;
+                } else if (tmm == best) {                /* :206-221 */
+                    if (index != idx) found = 0;
+                } else if (tmm < best) {
+                    found = 1; best = tmm; index = idx;
+                }
+            }
+            if (stop) break;
+        }
+        if (found) ++counts[index];
+        ++tot;
+    }
+    *total = tot;
+    free(buffer);
+    lib_free(&F); lib_free(&R);
+    return 0;
+}
+
 /* countPairedComboBarcodes: src/count_combo_barcodes_paired.cpp:11-55 over
  * kaori::CombinatorialBarcodesPairedEnd (two SimpleSingleMatch matchers, DuplicateAction::ERROR).
  * tuples: capacity 2 * n_pairs, in read order (the caller sorts / run-length encodes, scgo_combo_rle). */

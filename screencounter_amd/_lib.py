@@ -70,6 +70,10 @@ SIGNATURES = {
                                                       C.c_char_p, C.c_char_p, C.c_int, C.c_int, c_str_p, C.c_int32,
                                                       C.c_int, C.c_int, C.c_int, i32_p, C.POINTER(i32_p), C.POINTER(i32_p), i64_p,
                                                       i32_p, i32_p, i32_p, C.c_char_p, C.c_size_t]),
+    "scg_count_dual_barcodes_single_end": (C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(c_str_p), i32_p, C.c_int32,
+                                                     C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, i32_p, i32_p, C.c_char_p, C.c_size_t]),
+    "scg_plan_dual_single_end": (C.c_int, [C.POINTER(C.c_void_p), C.c_char_p, C.c_int, C.POINTER(c_str_p), i32_p, C.c_int32,
+                                           C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_size_t]),
     "scg_count_combo_barcodes_paired": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_int, c_str_p, C.c_int32,
                                                   C.c_char_p, C.c_char_p, C.c_int, C.c_int, c_str_p, C.c_int32,
                                                   C.c_int, C.c_int, C.c_int, C.POINTER(i32_p), C.POINTER(i32_p), i64_p,
@@ -136,6 +140,18 @@ def check(rc: int, err) -> None:
 
 def errbuf():
     return C.create_string_buffer(ERRCAP)
+
+
+def cstr_matrix(pools):
+    """list of pools -> (const char* const* const*, int32[] sizes, keepalive) for scg_*_dual_single_end"""
+    keep = []
+    rows = (c_str_p * max(len(pools), 1))()
+    for r, p in enumerate(pools):
+        arr, k = cstr_array(p)
+        keep.append((arr, k))
+        rows[r] = C.cast(arr, c_str_p)
+    sizes = (C.c_int32 * max(len(pools), 1))(*[len(p) for p in pools])
+    return rows, sizes, keep
 
 
 def cstr_array(strings):

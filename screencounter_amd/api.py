@@ -118,6 +118,21 @@ def count_dual_barcodes(path1: str, constant1: str, reverse1: bool, mismatches1:
     return counts[:len(pool1)].copy(), int(total.value)
 
 
+def count_dual_barcodes_single_end(path: str, constant: str, pools: Sequence[Sequence[str]], strand: int, mismatches: int,
+                                   use_first: bool, diagnostics: bool = False, nthreads: int = 1):
+    """src/count_dual_barcodes_single_end.cpp:53-87 (non-diagnostic branch) -> (counts int32[n combinations], total)."""
+    L = _lib.load()
+    nch = len(pools[0]) if pools else 0
+    counts = np.zeros(max(nch, 1), dtype=np.int32)
+    total = C.c_int32(0)
+    err = errbuf()
+    rows, sizes, _keep = _lib.cstr_matrix(pools)
+    check(L.scg_count_dual_barcodes_single_end(os.fspath(path).encode(), constant.encode(), rows, sizes, len(pools),
+                                               int(strand), int(mismatches), int(bool(use_first)), int(bool(diagnostics)), int(nthreads),
+                                               counts.ctypes.data_as(_lib.i32_p), C.byref(total), err, _lib.ERRCAP), err)
+    return counts[:nch].copy(), int(total.value)
+
+
 def count_combo_barcodes_paired(path1: str, constant1: str, reverse1: bool, mismatches1: int, pool1: Sequence[str],
                                 path2: str, constant2: str, reverse2: bool, mismatches2: int, pool2: Sequence[str],
                                 randomized: bool, use_first: bool, nthreads: int = 1):
@@ -408,6 +423,33 @@ def matrixOfDualBarcodes(files: Sequence[Sequence[str]], choices, withDimnames: 
                      col_data={"paths1": [f[0] for f in files], "paths2": [f[1] for f in files], "npairs": [o.npairs for o in out]})
     if withDimnames:
         se.colnames = [os.path.basename(f[0]) for f in files]
+    return se
+
+
+def countDualBarcodesSingleEnd(fastq: str, choices, template: str, substitutions: int = 0, find_best: bool = False,
+                               strand: str = "both", include_invalid: bool = False, num_threads: int = 1) -> DualCounts:
+    """R/countDualBarcodesSingleEnd.R:85-122 (include.invalid=FALSE).  `choices`: dict / list of equally long columns,
+    one per variable region of `template`."""
+    if isinstance(choices, dict):
+        names = list(choices.keys())
+        cols = [list(v) for v in choices.values()]
+    else:
+        cols = [list(v) for v in choices]
+        names = ["first", "second", "third", "fourth"][:len(cols)]
+    counts, total = count_dual_barcodes_single_end(fastq, re.sub("[nN]", "-", template), cols, _strand_code(strand),
+                                                   substitutions, not find_best, include_invalid, num_threads)
+    return DualCounts(choices=dict(zip(names, cols)), counts=counts, npairs=total)
+
+
+def matrixOfDualBarcodesSingleEnd(files: Sequence[str], choices, withDimnames: bool = True, devices=None, **kwargs) -> CountMatrix:
+    """R/countDualBarcodesSingleEnd.R:129-150 (include.invalid=FALSE)."""
+    out = _map_files(lambda f: countDualBarcodesSingleEnd(f, choices, **kwargs), files, devices)
+    nrow = len(out[0].counts) if out else 0
+    mat = np.stack([o.counts for o in out], axis=1) if out else np.zeros((nrow, 0), dtype=np.int32)
+    se = CountMatrix(counts=mat, row_data=out[0].choices if out else {},
+                     col_data={"paths": list(files), "nreads": [o.npairs for o in out]})
+    if withDimnames:
+        se.colnames = [os.path.basename(f) for f in files]
     return se
 
 

@@ -132,7 +132,7 @@ struct DevIndex {
     void upload(const scg::HostIndex& h) {
         nodes.upload(h.nodes); tables.upload(h.tables);
         view.nodes = nodes.as<uint4>(); view.tables = tables.as<uint4>();
-        view.slot_mask = h.slot_mask; view.n_entries = h.n_entries; view.len = h.len; view.nseg = h.nseg;
+        view.wide = h.wide ? 1 : 0; view.slot_mask = h.slot_mask; view.n_entries = h.n_entries; view.len = h.len; view.nseg = h.nseg;
         for (int s = 0; s < SCG_MAX_SEGMENTS; ++s) view.segmask[s] = h.segmask[s];
         for (int c = 0; c < 4; ++c) view.nwalk[c] = h.nwalk[c];
     }
@@ -273,10 +273,60 @@ std::unique_ptr<scg_plan> compile_single(const char* constant, int strand, const
                     ") should be the same as the barcode_pool region (" + std::to_string(vlen) + ")");
     }
     if (mismatches < 0) throw Error(SCG_ERR_INVALID, "negative number of mismatches");
-    P->htab[0] = scg::build_index(pool, n_pool, plen, mismatches);   // BarcodeSearch.hpp:23-60
+    // BarcodeSearch.hpp:23-60; barcodes of 33..64 bases take the wide (2 x 64-bit plane) index and kernels
+    P->htab[0] = plen > SCG_MAX_BARCODE ? scg::build_index_wide(pool, n_pool, plen, mismatches) : scg::build_index(pool, n_pool, plen, mismatches);
     P->scan1 = scg::build_scan(P->ht1.t, mismatches);
     P->n_pool[0] = n_pool;
     P->n_counters = n_pool;
+    P->max_mm1 = mismatches;
+    P->use_first = use_first != 0;
+    return P;
+}
+
+// countDualBarcodesSingleEnd (kaori::DualBarcodesSingleEnd, handlers/DualBarcodesSingleEnd.hpp:66-123): one read
+// holds every variable region; pools[r][c] over r spells valid combination c, and the concatenation of a window's
+// regions is matched against the concatenated library with one shared mismatch budget.  Same kernels as the single
+// barcode with a wide key assembled from several regions.
+std::unique_ptr<scg_plan> compile_dual_single_end(const char* constant, int strand, const char* const* const* pools, const int32_t* n_pools,
+                                                  int32_t n_regions, int mismatches, int use_first) {
+    if (!constant || n_regions < 0 || (n_regions > 0 && (!pools || !n_pools))) throw Error(SCG_ERR_INVALID, "null argument");
+    std::unique_ptr<scg_plan> P(new scg_plan);
+    P->kind = scg_plan::SINGLE;
+    std::vector<int> plen(n_regions);
+    for (int r = 0; r < n_regions; ++r) {
+        if (n_pools[r] < 0 || (n_pools[r] > 0 && !pools[r])) throw Error(SCG_ERR_INVALID, "null argument");
+        plen[r] = scg::pool_length(pools[r], n_pools[r]);         // src/utils.cpp:15-17 (format_pointers per pool)
+    }
+    P->ht1 = scg::parse_template(constant, strand);
+    const ScgTemplate& t = P->ht1.t;
+    if (t.nreg != n_regions) throw Error(SCG_ERR_INVALID, "length of 'barcode_pools' should equal the number of variable regions");   // :76-78
+    if (n_regions < 1 || n_regions > SCG_MAX_REGIONS) {
+        throw Error(SCG_ERR_UNSUPPORTED, "this engine counts dual barcodes in single-end reads with 1 or 2 variable regions (got " +
+                    std::to_string(n_regions) + ")");
+    }
+    int total = 0;
+    for (int r = 0; r < n_regions; ++r) {                         // :80-87
+        if (plen[r] != t.flen[r]) {
+            throw Error(SCG_ERR_INVALID, "length of variable region " + std::to_string(r + 1) + " (" + std::to_string(t.flen[r]) +
+                        ") should be the same as its sequences (" + std::to_string(plen[r]) + ")");
+        }
+        total += plen[r];
+    }
+    const int32_t n_choices = n_pools[0];
+    for (int r = 1; r < n_regions; ++r) {                         // :89-97
+        if (n_pools[r] != n_choices) throw Error(SCG_ERR_INVALID, "all entries of 'barcode_pools' should have the same length");
+    }
+    if (mismatches < 0) throw Error(SCG_ERR_INVALID, "negative number of mismatches");
+    std::vector<std::string> combined(n_choices);                // :100-109
+    std::vector<const char*> ptrs(n_choices);
+    for (int32_t c = 0; c < n_choices; ++c) {
+        for (int r = 0; r < n_regions; ++r) combined[c].append(pools[r][c], plen[r]);
+        ptrs[c] = combined[c].c_str();
+    }
+    P->htab[0] = scg::build_index_wide(ptrs.data(), n_choices, total, mismatches);     // duplicates => error (:111-113)
+    P->scan1 = scg::build_scan(t, mismatches);
+    P->n_pool[0] = n_choices;
+    P->n_counters = n_choices;
     P->max_mm1 = mismatches;
     P->use_first = use_first != 0;
     return P;
@@ -810,6 +860,17 @@ int scg_plan_dual(scg_plan** plan_out, const char* constant1, int reverse1, int 
     });
 }
 
+int scg_plan_dual_single_end(scg_plan** plan_out, const char* constant, int strand, const char* const* const* pools, const int32_t* n_pools,
+                             int32_t n_regions, int mismatches, int use_first, int device, char* err, size_t errcap) {
+    return guarded(err, errcap, [&] {
+        if (!plan_out) throw Error(SCG_ERR_INVALID, "null argument");
+        *plan_out = nullptr;
+        auto P = compile_dual_single_end(constant, strand, pools, n_pools, n_regions, mismatches, use_first);
+        P->to_device(device);
+        *plan_out = P.release();
+    });
+}
+
 int scg_plan_paired_combo(scg_plan** plan_out,
                           const char* constant1, int reverse1, int mismatches1, const char* const* pool1, int32_t n_pool1,
                           const char* constant2, int reverse2, int mismatches2, const char* const* pool2, int32_t n_pool2,
@@ -999,6 +1060,24 @@ int scg_count_dual_barcodes_diagnostics(const char* path1, const char* constant1
     });
 }
 
+int scg_count_dual_barcodes_single_end(const char* path, const char* constant, const char* const* const* pools, const int32_t* n_pools,
+                                       int32_t n_regions, int strand, int mismatches, int use_first, int diagnostics, int nthreads,
+                                       int32_t* counts_out, int32_t* total_out, char* err, size_t errcap) {
+    return guarded(err, errcap, [&] {
+        if (!path || !total_out || (n_regions > 0 && n_pools && n_pools[0] > 0 && !counts_out)) throw Error(SCG_ERR_INVALID, "null argument");
+        scg::FastqStream fq(path);                             // src/count_dual_barcodes_single_end.cpp:64: reader first
+        auto P = compile_dual_single_end(constant, strand, pools, n_pools, n_regions, mismatches, use_first);
+        if (diagnostics) {
+            throw Error(SCG_ERR_UNSUPPORTED, "include.invalid=TRUE is not implemented for single-end dual barcodes in this engine");
+        }
+        P->to_device(-1);
+        DeviceGuard g(P->device);
+        count_single_end_file(P.get(), path, fq, nthreads);
+        read_counters(P.get(), counts_out);
+        *total_out = static_cast<int32_t>(P->total);
+    });
+}
+
 int scg_count_combo_barcodes_paired(const char* path1, const char* constant1, int reverse1, int mismatches1,
                                     const char* const* pool1, int32_t n_pool1,
                                     const char* path2, const char* constant2, int reverse2, int mismatches2,
@@ -1049,7 +1128,8 @@ int scg_match_barcodes(const char* const* sequences, int32_t n_sequences, const 
             throw Error(SCG_ERR_INVALID, "null argument");
         }
         int clen = scg::pool_length(choices, n_choices);                     // src/match_barcodes.cpp:12
-        scg::HostIndex ht = scg::build_index(choices, n_choices, clen, substitutions < 0 ? 0 : substitutions);   // :13
+        scg::HostIndex ht = clen > SCG_MAX_BARCODE ? scg::build_index_wide(choices, n_choices, clen, substitutions < 0 ? 0 : substitutions)
+                                                   : scg::build_index(choices, n_choices, clen, substitutions < 0 ? 0 : substitutions);   // :13
         int slen = scg::pool_length(sequences, n_sequences);                 // :20
         if (n_sequences > 0 && slen != clen) {
             throw Error(SCG_ERR_INVALID, "sequences should have the same length as the choices (" + std::to_string(clen) + ")");

@@ -17,7 +17,8 @@
 
 #define SCG_MAX_TEMPLATE 256   // reference: src/count_single_barcodes.cpp:37-47
 #define SCG_MAX_REGIONS 2      // reference: src/count_combo_barcodes_single.cpp:44-46
-#define SCG_MAX_BARCODE 32     // bases per variable region handled by the packed-key engine
+#define SCG_MAX_BARCODE 32     // bases per key of the narrow (2 x 32-bit plane) engine
+#define SCG_MAX_WIDE_BARCODE 64   // bases per key of the wide (2 x 64-bit plane) single-end engine
 #define SCG_MAX_SEGMENTS 6     // hash tables ("segment groups") of the library index (mismatch budgets <= 3)
 #define SCG_MAX_SEEDS 4        // pigeonhole seeds of the constant-region scan (budgets <= 3)
 #define SCG_SEED_LEN 10        // constant bases per seed (at most)
@@ -60,6 +61,8 @@ struct ScgScan {
     int32_t nreg;
     int32_t fstart[SCG_MAX_REGIONS];          // variable-region starts, forward template
     int32_t rstart[SCG_MAX_REGIONS];          // ... on the reverse-complemented template
+    int32_t flen[SCG_MAX_REGIONS];            // region lengths, forward order
+    int32_t rlen[SCG_MAX_REGIONS];            // ... in the order they appear on the reverse-complemented template
     ScgSeeds fseeds, rseeds;
     int32_t compact_ok;                       // every seed starts below bit 32 and spans < 32 positions
     int32_t pad[3];
@@ -112,6 +115,8 @@ struct ScgIndex {
     int32_t n_entries;
     int32_t len;                // bases per key
     int32_t nseg;               // number of tables; 0 => budget too wide: dense scan of `nodes`
+    int32_t wide;               // keys of 33..64 bases: nodes / slots are two uint4 {lo64, hi64}, {value, next, 0, 0},
+                                // segmask[s] is a 64-bit position mask applied to both planes
     int32_t nwalk[4];           // tables to walk for a query cap of 0..3
     uint64_t segmask[SCG_MAX_SEGMENTS];   // plane-split position mask of table s
 };
@@ -204,6 +209,17 @@ uint32_t scg_hash64(uint64_t key) {
     h *= 0xC2B2AE35u;
     h ^= h >> 16;
     return h;
+}
+
+// Hash of a wide (2 x 64-bit plane) group key.
+static inline
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+uint32_t scg_hash128(uint64_t lo, uint64_t hi) {
+    uint32_t a = scg_hash64(lo), b = scg_hash64(hi);
+    uint32_t h = (a ^ ((b << 15) | (b >> 17))) * 0x9E3779B1u;
+    return h ^ (h >> 15);
 }
 
 #endif

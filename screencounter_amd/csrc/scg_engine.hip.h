@@ -74,50 +74,65 @@ __device__ __forceinline__ int const_mismatches(const ScgTemplate* __restrict__ 
 // ---------------------------------------------------------------------------------------------
 // A variable region as a plane-split key.  `other` has bit j set where the read holds a
 // non-ACGT byte; such a position mismatches every library base (MismatchTrie.hpp:452-453).
+// W = uint32_t for keys of up to 32 bases (every paired-end and combinatorial path), uint64_t for
+// the wide single-end variants (barcodes of 33-64 bases, concatenated dual barcodes).
 // ---------------------------------------------------------------------------------------------
-struct Query {
-    uint32_t lo, hi;     // code bit planes
-    uint32_t other;      // non-ACGT positions
+template<class W>
+struct QueryT {
+    W lo, hi;            // code bit planes
+    W other;             // non-ACGT positions
     int n_other;
 };
+using Query = QueryT<uint32_t>;
 
 __device__ __forceinline__ uint32_t low_mask(int len) { return len >= 32 ? 0xFFFFFFFFu : ((1u << len) - 1u); }
+template<class W> __device__ __forceinline__ W low_mask_w(int len);
+template<> __device__ __forceinline__ uint32_t low_mask_w<uint32_t>(int len) { return low_mask(len); }
+template<> __device__ __forceinline__ uint64_t low_mask_w<uint64_t>(int len) { return len >= 64 ? ~0ull : ((1ull << len) - 1ull); }
+
+__device__ __forceinline__ int popcount_w(uint32_t x) { return __popc(x); }
+__device__ __forceinline__ int popcount_w(uint64_t x) { return __popcll(x); }
+__device__ __forceinline__ uint32_t bitrev_w(uint32_t x) { return __brev(x); }
+__device__ __forceinline__ uint64_t bitrev_w(uint64_t x) { return __brevll(x); }
 
 // Reverse complement of a plane-split region: reverse the bit order, complement = code ^ 2
 // (flips plane 1 only).  Equivalent to kaori indexing reverse-complemented barcodes
 // (BarcodeSearch.hpp:36-43): Hamming distance is invariant under joint reverse complement.
-__device__ __forceinline__ Query reverse_complement(const Query& q, int len) {
-    Query r;
-    int sh = 32 - len;
-    uint32_t m = low_mask(len);
-    r.lo = __brev(q.lo) >> sh;
-    r.hi = (~(__brev(q.hi) >> sh)) & m;
-    r.other = __brev(q.other) >> sh;
+template<class W>
+__device__ __forceinline__ QueryT<W> reverse_complement(const QueryT<W>& q, int len) {
+    QueryT<W> r;
+    const int sh = (int)(8 * sizeof(W)) - len;
+    const W m = low_mask_w<W>(len);
+    r.lo = bitrev_w(q.lo) >> sh;
+    r.hi = (~(bitrev_w(q.hi) >> sh)) & m;
+    r.other = bitrev_w(q.other) >> sh;
     r.hi &= ~r.other;
     r.n_other = q.n_other;
     return r;
 }
 
 // Byte-wise packing straight from global memory (general engine).
-__device__ __forceinline__ Query pack_region(const uint8_t* __restrict__ s, int len, bool reverse) {
-    Query q;
+template<class W = uint32_t>
+__device__ __forceinline__ QueryT<W> pack_region(const uint8_t* __restrict__ s, int len, bool reverse) {
+    QueryT<W> q;
     q.lo = 0; q.hi = 0; q.other = 0;
     for (int j = 0; j < len; ++j) {
         int c = base_code(s[j]);
         if (c < 0) {
-            q.other |= 1u << j;
+            q.other |= (W)1 << j;
         } else {
-            q.lo |= (uint32_t)(c & 1) << j;
-            q.hi |= (uint32_t)(c >> 1) << j;
+            q.lo |= (W)(c & 1) << j;
+            q.hi |= (W)(c >> 1) << j;
         }
     }
-    q.n_other = __popc(q.other);
+    q.n_other = popcount_w(q.other);
     return reverse ? reverse_complement(q, len) : q;
 }
 
-__device__ __forceinline__ int query_distance(const Query& q, uint32_t elo, uint32_t ehi, uint32_t lenmask) {
-    uint32_t mism = ((q.lo ^ elo) | (q.hi ^ ehi)) & ~q.other & lenmask;
-    return __popc(mism) + q.n_other;
+template<class W>
+__device__ __forceinline__ int query_distance(const QueryT<W>& q, W elo, W ehi, W lenmask) {
+    W mism = ((q.lo ^ elo) | (q.hi ^ ehi)) & ~q.other & lenmask;
+    return popcount_w(mism) + q.n_other;
 }
 
 // One 16-byte access.  The empty asm pins all four words right after the load: left alone, the
@@ -130,19 +145,45 @@ __device__ __forceinline__ uint4 load_node(const uint4* p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Node access per key width.  Narrow: one uint4 {lo, hi, value, next}.  Wide: two uint4,
+// {lo.lo32, lo.hi32, hi.lo32, hi.hi32} and {value, next, 0, 0}.  segmask: plane-split 2 x 32 bits
+// (narrow) or one 64-bit position mask for both planes (wide).
+// ---------------------------------------------------------------------------------------------
+template<class W> struct KeyOps;
+template<> struct KeyOps<uint32_t> {
+    struct Node { uint32_t lo, hi; int val, next; };
+    static __device__ __forceinline__ Node load(const uint4* base, size_t i) {
+        const uint4 v = load_node(base + i);
+        return Node{v.x, v.y, (int)v.z, (int)v.w};
+    }
+    static __device__ __forceinline__ uint32_t plane_mask(uint64_t m, int plane) { return plane ? (uint32_t)(m >> 32) : (uint32_t)m; }
+    static __device__ __forceinline__ uint32_t hash(uint32_t lo, uint32_t hi) { return scg_hash64(((uint64_t)hi << 32) | lo); }
+};
+template<> struct KeyOps<uint64_t> {
+    struct Node { uint64_t lo, hi; int val, next; };
+    static __device__ __forceinline__ Node load(const uint4* base, size_t i) {
+        const uint4 a = load_node(base + 2 * i), b = load_node(base + 2 * i + 1);
+        return Node{((uint64_t)a.y << 32) | a.x, ((uint64_t)a.w << 32) | a.z, (int)b.x, (int)b.y};
+    }
+    static __device__ __forceinline__ uint64_t plane_mask(uint64_t m, int) { return m; }
+    static __device__ __forceinline__ uint32_t hash(uint64_t lo, uint64_t hi) { return scg_hash128(lo, hi); }
+};
+
+// ---------------------------------------------------------------------------------------------
 // Library index search.  Calls f(value, distance) for every entry within Hamming distance
 // <= cap of the query (an entry may be reported more than once); f returns true to stop.
 // ---------------------------------------------------------------------------------------------
-template<class F>
-__device__ __forceinline__ void index_search(const ScgIndex& X, const Query& q, int cap, F f) {
+template<class W, class F>
+__device__ __forceinline__ void index_search(const ScgIndex& X, const QueryT<W>& q, int cap, F f) {
+    typedef KeyOps<W> K;
     if (q.n_other > cap) return;
-    const uint32_t lm = low_mask(X.len);
+    const W lm = low_mask_w<W>(X.len);
     if (X.nseg == 0) {
         // budget wider than the index supports: dense scan (rare, any budget)
         for (int e = 0; e < X.n_entries; ++e) {
-            uint4 ent = X.nodes[e];
-            int d = query_distance(q, ent.x, ent.y, lm);
-            if (d <= cap && f((int)ent.z, d)) return;
+            const typename K::Node ent = K::load(X.nodes, (size_t)e);
+            int d = query_distance<W>(q, ent.lo, ent.hi, lm);
+            if (d <= cap && f(ent.val, d)) return;
         }
         return;
     }
@@ -151,33 +192,32 @@ __device__ __forceinline__ void index_search(const ScgIndex& X, const Query& q, 
     const int w0 = __builtin_amdgcn_readfirstlane(X.nwalk[0]), w1 = __builtin_amdgcn_readfirstlane(X.nwalk[1]);
     const int w2 = __builtin_amdgcn_readfirstlane(X.nwalk[2]), w3 = __builtin_amdgcn_readfirstlane(X.nwalk[3]);
     const int nwalk = cap <= 0 ? w0 : (cap == 1 ? w1 : (cap == 2 ? w2 : w3));
-    const uint64_t qkey = ((uint64_t)q.hi << 32) | q.lo;
-    const uint64_t qother = ((uint64_t)q.other << 32) | q.other;
     const uint32_t nslots = X.slot_mask + 1u;
 #pragma unroll 1
     for (int s = 0; s < nwalk; ++s) {
         const uint64_t mask = X.segmask[s];
-        if (qother & mask) continue;              // a non-ACGT byte spoils this group
-        const uint64_t sk = qkey & mask;
-        uint32_t pos = scg_hash64(sk) & X.slot_mask;
-        const uint4* table = X.tables + (size_t)s * nslots;
+        const W mlo = K::plane_mask(mask, 0), mhi = K::plane_mask(mask, 1);
+        if (q.other & mlo) continue;              // a non-ACGT byte spoils this group
+        const W sklo = q.lo & mlo, skhi = q.hi & mhi;
+        uint32_t pos = K::hash(sklo, skhi) & X.slot_mask;
+        const uint4* table = X.tables + (size_t)s * nslots * (sizeof(W) / 4);
         // the slot of a group key holds the head node of its chain: an exact hit is one access
-        uint4 ent;
+        typename K::Node ent;
         bool found = false;
         for (;;) {
-            ent = load_node(table + pos);
-            if (ent.w == SCG_SLOT_EMPTY) break;   // no entry shares this group with the query
-            if (((((uint64_t)ent.y << 32) | ent.x) & mask) == sk) { found = true; break; }
+            ent = K::load(table, (size_t)pos);
+            if ((uint32_t)ent.next == SCG_SLOT_EMPTY) break;   // no entry shares this group with the query
+            if ((ent.lo & mlo) == sklo && (ent.hi & mhi) == skhi) { found = true; break; }
             pos = (pos + 1) & X.slot_mask;
         }
         if (!found) continue;
-        const uint4* nodes = X.nodes + (size_t)s * (size_t)X.n_entries;
+        const uint4* nodes = X.nodes + (size_t)s * (size_t)X.n_entries * (sizeof(W) / 4);
         for (;;) {
-            int d = query_distance(q, ent.x, ent.y, lm);
-            if (d <= cap && f((int)ent.z, d)) return;
-            const int e = (int)ent.w;
+            int d = query_distance<W>(q, ent.lo, ent.hi, lm);
+            if (d <= cap && f(ent.val, d)) return;
+            const int e = ent.next;
             if (e < 0) break;
-            ent = load_node(nodes + e);
+            ent = K::load(nodes, (size_t)e);
         }
     }
 }
@@ -189,10 +229,11 @@ __device__ __forceinline__ void index_search(const ScgIndex& X, const Query& q, 
 // keep_first = DuplicateAction::FIRST (MismatchTrie.hpp:109-110, :273-276, :311-314): a tie goes to
 // the smallest value instead of being ambiguous.  Used by the include.invalid=TRUE path, where
 // the values are sequence uids numbered in order of first appearance in the pool.
-__device__ __forceinline__ void index_match(const ScgIndex& X, const Query& q, int cap, int& index, int& mm,
+template<class W>
+__device__ __forceinline__ void index_match(const ScgIndex& X, const QueryT<W>& q, int cap, int& index, int& mm,
                                             bool keep_first = false) {
     int best = cap + 1, cur = SCG_MISSING;
-    index_search(X, q, cap, [&](int v, int d) -> bool {
+    index_search<W>(X, q, cap, [&](int v, int d) -> bool {
         if (d < best) { best = d; cur = v; }
         else if (d == best && cur != v) { cur = keep_first ? (v < cur ? v : cur) : SCG_AMBIGUOUS; }
         return d == 0;      // an exact entry is unique (one entry per concrete sequence)
@@ -219,7 +260,7 @@ template<int K>
 __device__ __forceinline__ bool index_neighbours(const ScgIndex& X, const Query& q, int cap, int val[K], int dist[K], int& n) {
     n = 0;
     bool overflow = false;
-    index_search(X, q, cap, [&](int v, int d) -> bool {
+    index_search<uint32_t>(X, q, cap, [&](int v, int d) -> bool {
         bool seen = false;
 #pragma unroll
         for (int i = 0; i < K; ++i) seen |= (i < n && val[i] == v);
@@ -272,8 +313,8 @@ __device__ __forceinline__ void pair_match(const ScgIndex& X1, const ScgIndex& X
                 }
             }
         } else {
-            index_search(X1, q1, cap1, [&](int u1, int e1) -> bool {
-                index_search(X2, q2, cap2, [&](int u2, int e2) -> bool {
+            index_search<uint32_t>(X1, q1, cap1, [&](int u1, int e1) -> bool {
+                index_search<uint32_t>(X2, q2, cap2, [&](int u2, int e2) -> bool {
                     consider(u1, e1, u2, e2);
                     return false;
                 });
@@ -284,10 +325,10 @@ __device__ __forceinline__ void pair_match(const ScgIndex& X1, const ScgIndex& X
         uint32_t lm1 = low_mask(X1.len), lm2 = low_mask(X2.len);
         for (int i = 0; i < P.n_entries; ++i) {
             uint64_t k1 = P.list_key1[i];
-            int e1 = query_distance(q1, (uint32_t)k1, (uint32_t)(k1 >> 32), lm1);
+            int e1 = query_distance<uint32_t>(q1, (uint32_t)k1, (uint32_t)(k1 >> 32), lm1);
             if (e1 > cap1) continue;
             uint64_t k2 = P.list_key2[i];
-            int e2 = query_distance(q2, (uint32_t)k2, (uint32_t)(k2 >> 32), lm2);
+            int e2 = query_distance<uint32_t>(q2, (uint32_t)k2, (uint32_t)(k2 >> 32), lm2);
             if (e2 > cap2) continue;
             int tot = e1 + e2, v = P.list_vals[i];
             if (tot < best) { best = tot; cur = v; }

@@ -38,6 +38,7 @@ struct HostIndex {
     int32_t len = 0;
     int32_t n_entries = 0;
     int32_t nseg = 0;
+    bool wide = false;               // 2 x 64-bit planes: 8 words per node / slot (ScgIndex::wide)
     uint32_t slot_mask = 0;
     int32_t nwalk[4] = {0, 0, 0, 0};
     uint64_t segmask[SCG_MAX_SEGMENTS] = {0, 0, 0, 0, 0, 0};
@@ -50,6 +51,9 @@ struct HostIndex {
 // value = barcode index; two barcodes sharing one concrete sequence => Error("duplicate sequences
 // detected (a, b) when constructing the trie").
 HostIndex build_index(const char* const* pool, int32_t n, int32_t len, int max_mm);
+
+// Same for keys of up to 64 bases (wide index; always used for concatenated multi-region keys).
+HostIndex build_index_wide(const char* const* pool, int32_t n, int32_t len, int max_mm);
 
 // value = uid of the concrete sequence (duplicates within the pool merge).  expansions[i] receives
 // the uids of barcode i's concrete expansions, in lexicographic (A,C,G,T) order.

@@ -28,6 +28,31 @@ constexpr int BLOCK = 256;
 // ---------------------------------------------------------------------------------------------
 // single
 // ---------------------------------------------------------------------------------------------
+// Key of the template's variable regions at window position p, concatenated in read order (one
+// region: the ordinary single barcode; several: DualBarcodesSingleEnd.hpp:149-166).
+template<class W>
+__device__ __forceinline__ QueryT<W> pack_regions(const ScgTemplate* T, const uint8_t* __restrict__ window, bool reverse, int total_len) {
+    QueryT<W> q;
+    q.lo = 0; q.hi = 0; q.other = 0;
+    int off = 0;
+    for (int r = 0; r < T->nreg; ++r) {
+        const int start = reverse ? T->rstart[r] : T->fstart[r], len = reverse ? T->rlen[r] : T->flen[r];
+        for (int j = 0; j < len; ++j) {
+            int c = base_code(window[start + j]);
+            if (c < 0) {
+                q.other |= (W)1 << (off + j);
+            } else {
+                q.lo |= (W)(c & 1) << (off + j);
+                q.hi |= (W)(c >> 1) << (off + j);
+            }
+        }
+        off += len;
+    }
+    q.n_other = popcount_w(q.other);
+    return reverse ? reverse_complement(q, total_len) : q;
+}
+
+template<class W = uint32_t>
 __device__ __forceinline__ int single_read(const ScgSingleParams& P, const Read& rd) {
     const ScgTemplate* T = P.tmpl;
     const int len = T->len;
@@ -38,10 +63,9 @@ __device__ __forceinline__ int single_read(const ScgSingleParams& P, const Read&
             if (s == 0 ? !P.fwd : !P.rev) continue;
             int c = const_mismatches(T, s != 0, rd.p, p, max_mm);
             if (c > max_mm) continue;
-            int start = s ? T->rstart[0] : T->fstart[0];
-            Query q = pack_region(rd.p + p + start, P.index.len, s != 0);
+            QueryT<W> q = pack_regions<W>(T, rd.p + p, s != 0, P.index.len);
             int idx, d;
-            index_match(P.index, q, max_mm - c, idx, d);
+            index_match<W>(P.index, q, max_mm - c, idx, d);
             if (idx < 0) continue;
             int tot = c + d;
             if (P.use_first) {
@@ -56,12 +80,13 @@ __device__ __forceinline__ int single_read(const ScgSingleParams& P, const Read&
     return found ? index : -1;
 }
 
+template<class W>
 __global__ __launch_bounds__(BLOCK) void single_kernel(ScgSingleParams P, ScgReads R, int64_t n_reads,
                                                         ScgCounters counts) {
     int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n_reads) return;
     Read rd = get_read(R, i);
-    int idx = single_read(P, rd);
+    int idx = single_read<W>(P, rd);
     if (idx >= 0) count_one(counts, idx);
 }
 
@@ -287,7 +312,9 @@ __global__ __launch_bounds__(BLOCK) void dual_kernel(ScgDualParams P, ScgReads R
 // =============================================================================================
 // Staged kernels
 // =============================================================================================
-template<int NW, int NT, int NC>
+// W = uint32_t: one variable region of <= 32 bases (the hot configuration).  W = uint64_t: keys of up to
+// 64 bases, one region or several concatenated (wide barcodes, countDualBarcodesSingleEnd).
+template<int NW, int NT, int NC, class W>
 __device__ __forceinline__ int single_read_staged(const ScgSingleParams& P, const Tile<NW>& tile, const StrandTable<NT>& st, const StagedRead& sr, int ablate = 0) {
     const ScgScan& T = P.scan;
     const int max_mm = P.max_mm;
@@ -304,10 +331,15 @@ __device__ __forceinline__ int single_read_staged(const ScgSingleParams& P, cons
         clear_bit<NC>(candR, rev ? p : -1);
         int c = window_mismatches<NW, NT>(tile, sr.bit + p, st, rev);
         if (c > max_mm) continue;
-        const int start = region_start<NT>(st, 0, rev);
-        Query q = region_query<NW>(tile, sr.bit + p + start, P.index.len, rev);
+        QueryT<W> q;
+        if constexpr (sizeof(W) == 4) {
+            const int start = region_start<NT>(st, 0, rev);
+            q = region_query<NW>(tile, sr.bit + p + start, P.index.len, rev);
+        } else {
+            q = regions_query<NW, NT, W>(tile, sr.bit + p, st, uniform(T.nreg), P.index.len, rev);
+        }
         int idx, d;
-        index_match(P.index, q, max_mm - c, idx, d);
+        index_match<W>(P.index, q, max_mm - c, idx, d);
         if (idx < 0) continue;
         int tot = c + d;
         if (P.use_first) {
@@ -322,7 +354,7 @@ __device__ __forceinline__ int single_read_staged(const ScgSingleParams& P, cons
 }
 
 // NC < NW ("compact"): candidate positions fit 32*NC bits and the plan's seeds allow it (ScgScan::compact_ok).
-template<int NW, int NT, int NC>
+template<int NW, int NT, int NC, class W>
 __global__ __launch_bounds__(STAGE_BLOCK) __attribute__((amdgpu_num_sgpr(80))) void single_staged_kernel(ScgSingleParams P, ScgReads R, int64_t n_reads,
                                                                    ScgCounters counts, int32_t* __restrict__ error_flag) {
     __shared__ Tile<NW> tile;
@@ -344,15 +376,13 @@ __global__ __launch_bounds__(STAGE_BLOCK) __attribute__((amdgpu_num_sgpr(80))) v
     StagedRead sr;
     sr.bit = (int)((int64_t)(rd.p - R.seqs) - span0);
     sr.n = rd.n;
-    if (R.ablate == 5) count_one(counts, (int64_t)(((uint32_t)sr.bit * 2654435761u + (uint32_t)r0) % 100000u));   // experiment: same atomics, issued early
     int idx;
     if (R.ablate == 2) {
         idx = (tile.p0[threadIdx.x] == 0xdeadbeefu) ? 0 : -1;
     } else {
-        idx = single_read_staged<NW, NT, NC>(P, tile, strands, sr, R.ablate);
+        idx = single_read_staged<NW, NT, NC, W>(P, tile, strands, sr, R.ablate);
     }
-    if (R.ablate == 4) { counts.base[(blockIdx.x * STAGE_BLOCK + threadIdx.x) & 0xFFFFFu] = idx; return; }
-    if (idx >= 0 && !(R.ablate == 3 && idx != 0x7ffffff0) && R.ablate != 5) count_one(counts, idx);
+    if (idx >= 0 && !(R.ablate == 3 && idx != 0x7ffffff0)) count_one(counts, idx);
 }
 
 template<int NW, int NT>
@@ -574,13 +604,14 @@ __global__ __launch_bounds__(STAGE_BLOCK) void dual_staged_kernel(ScgDualParams 
 // ---------------------------------------------------------------------------------------------
 // matchBarcodes: one packed query per lane.
 // ---------------------------------------------------------------------------------------------
+template<class W>
 __global__ __launch_bounds__(BLOCK) void match_kernel(ScgIndex tab, const uint8_t* __restrict__ seqs, int32_t n, int cap, int reverse,
                                                        int32_t* __restrict__ index_out, int32_t* __restrict__ mm_out) {
     int i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
-    Query q = pack_region(seqs + (size_t)i * tab.len, tab.len, reverse != 0);
+    QueryT<W> q = pack_region<W>(seqs + (size_t)i * tab.len, tab.len, reverse != 0);
     int idx, d;
-    index_match(tab, q, cap, idx, d);
+    index_match<W>(tab, q, cap, idx, d);
     index_out[i] = idx >= 0 ? idx : -1;
     mm_out[i] = idx >= 0 ? d : -1;
 }
@@ -686,10 +717,14 @@ hipError_t dispatch_shape(int max_len, int tmpl_len, Args&&... args) {
 template<int NW, int NT> struct LaunchSingle {
     static hipError_t go(const ScgSingleParams& P, const ScgReads& R, int64_t n, const ScgCounters& counts, int32_t* flag, hipStream_t stream) {
         // compact variant: all candidate positions (0 .. max_len - T) fit 3 words of a 5-word read
-        if (NW == 5 && P.scan.compact_ok && R.max_len - P.scan.len + 1 <= 96) {
-            hipLaunchKernelGGL((single_staged_kernel<NW, NT, (NW == 5 ? 3 : NW)>), dim3(staged_grid(n)), dim3(STAGE_BLOCK), 0, stream, P, R, n, counts, flag);
+        const bool compact = NW == 5 && P.scan.compact_ok && R.max_len - P.scan.len + 1 <= 96;
+        if (P.index.wide || P.scan.nreg != 1) {          // wide / concatenated keys
+            if (compact) hipLaunchKernelGGL((single_staged_kernel<NW, NT, (NW == 5 ? 3 : NW), uint64_t>), dim3(staged_grid(n)), dim3(STAGE_BLOCK), 0, stream, P, R, n, counts, flag);
+            else hipLaunchKernelGGL((single_staged_kernel<NW, NT, NW, uint64_t>), dim3(staged_grid(n)), dim3(STAGE_BLOCK), 0, stream, P, R, n, counts, flag);
+        } else if (compact) {
+            hipLaunchKernelGGL((single_staged_kernel<NW, NT, (NW == 5 ? 3 : NW), uint32_t>), dim3(staged_grid(n)), dim3(STAGE_BLOCK), 0, stream, P, R, n, counts, flag);
         } else {
-            hipLaunchKernelGGL((single_staged_kernel<NW, NT, NW>), dim3(staged_grid(n)), dim3(STAGE_BLOCK), 0, stream, P, R, n, counts, flag);
+            hipLaunchKernelGGL((single_staged_kernel<NW, NT, NW, uint32_t>), dim3(staged_grid(n)), dim3(STAGE_BLOCK), 0, stream, P, R, n, counts, flag);
         }
         return hipGetLastError();
     }
@@ -729,7 +764,8 @@ static bool use_general(int max_len) { return force_general() || max_len <= 0 ||
 hipError_t launch_single(const ScgSingleParams& P, int tmpl_len, const ScgReads& R, int64_t n, const ScgCounters& counts, int32_t* flag, hipStream_t stream) {
     if (n <= 0) return hipSuccess;
     if (use_general(R.max_len)) {
-        hipLaunchKernelGGL(single_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, stream, P, R, n, counts);
+        if (P.index.wide || P.scan.nreg != 1) hipLaunchKernelGGL(single_kernel<uint64_t>, dim3(grid_for(n)), dim3(BLOCK), 0, stream, P, R, n, counts);
+        else hipLaunchKernelGGL(single_kernel<uint32_t>, dim3(grid_for(n)), dim3(BLOCK), 0, stream, P, R, n, counts);
         return hipGetLastError();
     }
     return dispatch_shape<LaunchSingle>(R.max_len, tmpl_len, P, R, n, counts, flag, stream);
@@ -794,7 +830,8 @@ hipError_t launch_fold(int32_t* replicas, int shift, int64_t n, int32_t* counter
 hipError_t launch_match(const ScgIndex& tab, const uint8_t* d_seqs, int32_t n, int cap, int reverse,
                         int32_t* d_index, int32_t* d_mm, hipStream_t stream) {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(match_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, stream, tab, d_seqs, n, cap, reverse, d_index, d_mm);
+    if (tab.wide) hipLaunchKernelGGL(match_kernel<uint64_t>, dim3(grid_for(n)), dim3(BLOCK), 0, stream, tab, d_seqs, n, cap, reverse, d_index, d_mm);
+    else hipLaunchKernelGGL(match_kernel<uint32_t>, dim3(grid_for(n)), dim3(BLOCK), 0, stream, tab, d_seqs, n, cap, reverse, d_index, d_mm);
     return hipGetLastError();
 }
 

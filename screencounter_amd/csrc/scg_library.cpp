@@ -337,6 +337,135 @@ HostIndex build_index(const char* const* pool, int32_t n, int32_t len, int max_m
     return X;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Wide keys (33..64 bases, or several regions concatenated): same index, 2 x 64-bit planes.
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+struct WideKey {
+    uint64_t lo, hi;
+    bool operator==(const WideKey& o) const { return lo == o.lo && hi == o.hi; }
+};
+struct WideKeyHash {
+    size_t operator()(const WideKey& k) const { return (static_cast<size_t>(scg_hash64(k.lo)) << 32) ^ scg_hash64(k.hi) ^ (k.lo * 0x9E3779B97F4A7C15ull); }
+};
+
+template<class F>
+void for_each_expansion_wide(const char* s, int len, F f) {
+    int cnt[SCG_MAX_WIDE_BARCODE], codes[SCG_MAX_WIDE_BARCODE][4], choice[SCG_MAX_WIDE_BARCODE];
+    for (int p = 0; p < len; ++p) {
+        cnt[p] = iupac_codes(s[p], codes[p]);
+        choice[p] = 0;
+    }
+    for (;;) {
+        WideKey key{0, 0};
+        for (int p = 0; p < len; ++p) {
+            uint64_t c = static_cast<uint64_t>(codes[p][choice[p]]);
+            key.lo |= (c & 1) << p;
+            key.hi |= (c >> 1) << p;
+        }
+        f(key);
+        int p = len - 1;
+        for (; p >= 0; --p) {
+            if (++choice[p] < cnt[p]) break;
+            choice[p] = 0;
+        }
+        if (p < 0) break;
+    }
+}
+
+void put_node(uint32_t* node, const WideKey& k, uint32_t val, uint32_t next) {
+    node[0] = static_cast<uint32_t>(k.lo); node[1] = static_cast<uint32_t>(k.lo >> 32);
+    node[2] = static_cast<uint32_t>(k.hi); node[3] = static_cast<uint32_t>(k.hi >> 32);
+    node[4] = val; node[5] = next; node[6] = 0; node[7] = 0;
+}
+
+} // namespace
+
+HostIndex build_index_wide(const char* const* pool, int32_t n, int32_t len, int max_mm) {
+    if (len > SCG_MAX_WIDE_BARCODE) {
+        throw Error(SCG_ERR_UNSUPPORTED, "variable regions longer than 64 bp in total are not supported by this engine (got " + std::to_string(len) + ")");
+    }
+    count_expansions(pool, n, len);
+    std::unordered_map<WideKey, int32_t, WideKeyHash> owner;
+    std::vector<WideKey> keys;
+    std::vector<int32_t> vals;
+    for (int32_t i = 0; i < n; ++i) {
+        for_each_expansion_wide(pool[i], len, [&](const WideKey& key) {
+            auto ins = owner.emplace(key, i);
+            if (!ins.second) throw_duplicate(ins.first->second, i);
+            keys.push_back(key);
+            vals.push_back(i);
+        });
+    }
+    HostIndex X;
+    X.wide = true;
+    X.len = len;
+    const size_t cnt = keys.size();
+    X.n_entries = static_cast<int32_t>(cnt);
+    auto slice = [&](int part, int parts) -> uint64_t {
+        int a = static_cast<int>(static_cast<int64_t>(part) * len / parts);
+        int b = static_cast<int>(static_cast<int64_t>(part + 1) * len / parts);
+        return (b - a >= 64) ? ~0ull : (((1ull << (b - a)) - 1ull) << a);
+    };
+    std::vector<uint64_t> groups;           // same position groups as finish_index, as 64-bit position masks
+    if (max_mm == 0) {
+        groups.push_back(slice(0, 1));
+        X.nwalk[0] = X.nwalk[1] = X.nwalk[2] = X.nwalk[3] = 1;
+    } else if (max_mm == 1) {
+        groups.push_back(slice(0, 2));
+        groups.push_back(slice(1, 2));
+        X.nwalk[0] = 1; X.nwalk[1] = X.nwalk[2] = X.nwalk[3] = 2;
+    } else if (max_mm == 2) {
+        static const int pairs[6][2] = {{0, 1}, {2, 3}, {0, 2}, {1, 3}, {0, 3}, {1, 2}};
+        for (auto& pr : pairs) groups.push_back(slice(pr[0], 4) | slice(pr[1], 4));
+        X.nwalk[0] = 1; X.nwalk[1] = 2; X.nwalk[2] = X.nwalk[3] = 6;
+    } else if (max_mm == 3) {
+        for (int q = 0; q < 4; ++q) groups.push_back(slice(q, 4));
+        X.nwalk[0] = 1; X.nwalk[1] = 2; X.nwalk[2] = 3; X.nwalk[3] = 4;
+    }
+    const int nseg = static_cast<int>(groups.size());
+    X.nseg = nseg;
+    const int ncopies = nseg > 0 ? nseg : 1;
+    X.nodes.resize(static_cast<size_t>(ncopies) * cnt * 8);
+    for (int c = 0; c < ncopies; ++c) {
+        uint32_t* node = X.nodes.data() + static_cast<size_t>(c) * cnt * 8;
+        for (size_t e = 0; e < cnt; ++e) put_node(node + 8 * e, keys[e], static_cast<uint32_t>(vals[e]), 0xFFFFFFFFu);
+    }
+    if (nseg == 0) return X;
+    uint32_t cap = 16;
+    while (cap < cnt * 2) cap <<= 1;
+    X.slot_mask = cap - 1;
+    X.tables.assign(static_cast<size_t>(nseg) * cap * 8, 0);
+    for (int sgm = 0; sgm < nseg; ++sgm) {
+        const uint64_t mask = groups[sgm];
+        X.segmask[sgm] = mask;
+        uint32_t* node = X.nodes.data() + static_cast<size_t>(sgm) * cnt * 8;
+        uint32_t* table = X.tables.data() + static_cast<size_t>(sgm) * cap * 8;
+        for (uint32_t pos = 0; pos < cap; ++pos) table[8 * pos + 5] = SCG_SLOT_EMPTY;
+        std::unordered_map<WideKey, int32_t, WideKeyHash> head_of;
+        head_of.reserve(cnt * 2);
+        for (size_t i = cnt; i-- > 0;) {            // back to front: every chain ends up ascending
+            WideKey sk{keys[i].lo & mask, keys[i].hi & mask};
+            auto it = head_of.find(sk);
+            if (it == head_of.end()) {
+                head_of.emplace(sk, static_cast<int32_t>(i));
+            } else {
+                node[8 * i + 5] = static_cast<uint32_t>(it->second);
+                it->second = static_cast<int32_t>(i);
+            }
+        }
+        for (size_t i = 0; i < cnt; ++i) {
+            WideKey sk{keys[i].lo & mask, keys[i].hi & mask};
+            if (head_of[sk] != static_cast<int32_t>(i)) continue;
+            uint32_t pos = scg_hash128(sk.lo, sk.hi) & X.slot_mask;
+            while (table[8 * pos + 5] != SCG_SLOT_EMPTY) pos = (pos + 1) & X.slot_mask;
+            for (int w = 0; w < 8; ++w) table[8 * pos + w] = node[8 * i + w];
+        }
+    }
+    return X;
+}
+
 HostIndex build_uid_index(const char* const* pool, int32_t n, int32_t len, int max_mm,
                           std::vector<std::vector<int32_t> >& expansions,
                           std::vector<uint64_t>& uid_keys) {
@@ -411,6 +540,8 @@ ScgScan build_scan(const ScgTemplate& t, int max_mm) {
     for (int r = 0; r < SCG_MAX_REGIONS; ++r) {
         sc.fstart[r] = t.fstart[r];
         sc.rstart[r] = t.rstart[r];
+        sc.flen[r] = t.flen[r];
+        sc.rlen[r] = t.rlen[r];
     }
     for (int k = 0; k < t.nconst; ++k) {
         int fp = t.fpos[k], rp = t.rpos[k];

@@ -357,7 +357,7 @@ __device__ __forceinline__ int window_mismatches(const Tile<NW>& tile, int bit, 
 // instructions a word (two SGPR->VGPR moves and a select), reading the chosen strand's row costs none.
 template<int NT>
 struct StrandTable {
-    static constexpr int STRIDE = 3 * NT + SCG_MAX_REGIONS;   // plane0[NT] | plane1[NT] | mask[NT] | region starts
+    static constexpr int STRIDE = 3 * NT + 2 * SCG_MAX_REGIONS;   // plane0[NT] | plane1[NT] | mask[NT] | region starts | region lengths
     uint32_t w[2 * STRIDE];
 };
 
@@ -377,6 +377,8 @@ __device__ __forceinline__ void fill_strand_table(StrandTable<NT>& st, const Scg
         for (int r = 0; r < SCG_MAX_REGIONS; ++r) {
             st.w[3 * NT + r] = (uint32_t)T.fstart[r];
             st.w[StrandTable<NT>::STRIDE + 3 * NT + r] = (uint32_t)T.rstart[r];
+            st.w[3 * NT + SCG_MAX_REGIONS + r] = (uint32_t)T.flen[r];
+            st.w[StrandTable<NT>::STRIDE + 3 * NT + SCG_MAX_REGIONS + r] = (uint32_t)T.rlen[r];
         }
     }
 }
@@ -402,20 +404,58 @@ __device__ __forceinline__ int region_start(const StrandTable<NT>& st, int r, bo
     return (int)st.w[(reverse ? StrandTable<NT>::STRIDE : 0) + 3 * NT + r];
 }
 
-// Variable region of `len` <= 32 bases starting at plane bit `bit`.
-template<int NW>
-__device__ __forceinline__ Query region_query(const Tile<NW>& tile, int bit, int len, bool reverse) {
-    uint32_t a[1], b[1], c[1];
-    load_bits<1>(tile.p0, bit, a);
-    load_bits<1>(tile.p1, bit, b);
-    load_bits<1>(tile.v, bit, c);
-    const uint32_t m = low_mask(len);
-    Query q;
-    q.other = ~c[0] & m;
-    q.lo = a[0] & m & ~q.other;
-    q.hi = b[0] & m & ~q.other;
-    q.n_other = __popc(q.other);
+template<int NT>
+__device__ __forceinline__ int region_length(const StrandTable<NT>& st, int r, bool reverse) {
+    return (int)st.w[(reverse ? StrandTable<NT>::STRIDE : 0) + 3 * NT + SCG_MAX_REGIONS + r];
+}
+
+// `len` plane bits starting at bit `bit`, as a W-wide word (len <= bits of W).
+template<class W> __device__ __forceinline__ W plane_bits(const uint32_t* __restrict__ plane, int bit);
+template<> __device__ __forceinline__ uint32_t plane_bits<uint32_t>(const uint32_t* __restrict__ plane, int bit) {
+    uint32_t a[1];
+    load_bits<1>(plane, bit, a);
+    return a[0];
+}
+template<> __device__ __forceinline__ uint64_t plane_bits<uint64_t>(const uint32_t* __restrict__ plane, int bit) {
+    uint32_t a[2];
+    load_bits<2>(plane, bit, a);
+    return ((uint64_t)a[1] << 32) | a[0];
+}
+
+// Variable region of `len` bases (<= bits of W) starting at plane bit `bit`.
+template<int NW, class W = uint32_t>
+__device__ __forceinline__ QueryT<W> region_query(const Tile<NW>& tile, int bit, int len, bool reverse) {
+    const W a = plane_bits<W>(tile.p0, bit), b = plane_bits<W>(tile.p1, bit), c = plane_bits<W>(tile.v, bit);
+    const W m = low_mask_w<W>(len);
+    QueryT<W> q;
+    q.other = ~c & m;
+    q.lo = a & m & ~q.other;
+    q.hi = b & m & ~q.other;
+    q.n_other = popcount_w(q.other);
     return reverse ? reverse_complement(q, len) : q;
+}
+
+// The template's variable regions at window position `bit`, concatenated in read order into one
+// key (DualBarcodesSingleEnd.hpp:149-166 builds the same string; one region is the ordinary single
+// barcode).  On the reverse strand the regions come in the reverse template's order and the whole
+// key is reverse-complemented, which equals kaori searching its reverse-complemented library.
+template<int NW, int NT, class W>
+__device__ __forceinline__ QueryT<W> regions_query(const Tile<NW>& tile, int bit, const StrandTable<NT>& st, int nreg, int total_len, bool reverse) {
+    QueryT<W> q;
+    q.lo = 0; q.hi = 0; q.other = 0;
+    int off = 0;
+    for (int r = 0; r < nreg; ++r) {
+        const int start = region_start<NT>(st, r, reverse), len = region_length<NT>(st, r, reverse);
+        const W a = plane_bits<W>(tile.p0, bit + start), b = plane_bits<W>(tile.p1, bit + start), c = plane_bits<W>(tile.v, bit + start);
+        const W m = low_mask_w<W>(len);
+        const W other = ~c & m;
+        q.other |= other << off;
+        q.lo |= (a & m & ~other) << off;
+        q.hi |= (b & m & ~other) << off;
+        off += len;
+    }
+    q.n_other = popcount_w(q.other);
+    return reverse ? reverse_complement(q, total_len) : q;
 }
 
 // Per-lane view of one staged read.

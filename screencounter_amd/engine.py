@@ -110,6 +110,18 @@ class Plan:
         return cls(h.value, "dual", (len(pool1),), device)
 
     @classmethod
+    def dual_single_end(cls, template: str, strand: int, pools: Sequence[Sequence[str]], mismatches: int = 0,
+                        use_first: bool = True, device: int = -1) -> "Plan":
+        """countDualBarcodesSingleEnd: counted with count(), read with read()."""
+        L = _lib.load()
+        h = C.c_void_p()
+        err = errbuf()
+        rows, sizes, _keep = _lib.cstr_matrix(pools)
+        check(L.scg_plan_dual_single_end(C.byref(h), template.encode(), int(strand), rows, sizes, len(pools),
+                                         int(mismatches), int(bool(use_first)), int(device), err, _lib.ERRCAP), err)
+        return cls(h.value, "single", (len(pools[0]) if pools else 0,), device)
+
+    @classmethod
     def paired_combo(cls, template1: str, reverse1: bool, mismatches1: int, pool1: Sequence[str],
                      template2: str, reverse2: bool, mismatches2: int, pool2: Sequence[str],
                      randomized: bool = False, use_first: bool = True, device: int = -1) -> "Plan":

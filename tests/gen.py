@@ -104,8 +104,8 @@ def make_reads(rng, template, pools, n, strand, p_sub, p_n, p_lower, p_junk, pad
 # ---------------------------------------------------------------------------------------------
 # Whole random cases (inputs only) for the three entry points and the matcher.
 # ---------------------------------------------------------------------------------------------
-def random_single_case(rng: random.Random, max_vlen: int = 33, sizes=(1, 30, 200)) -> dict:
-    vlen = rng.choice([v for v in (3, 4, 6, 8, 10, 20, 33) if v <= max_vlen])
+def random_single_case(rng: random.Random, max_vlen: int = 33, sizes=(1, 30, 200), min_vlen: int = 0) -> dict:
+    vlen = rng.choice([v for v in (3, 4, 6, 8, 10, 20, 33, 40, 57, 64) if min_vlen <= v <= max_vlen])
     alphabet = rng.choice(["AC", "ACG", BASES, BASES])
     npool = rng.choice([1, 2, 5, 20, 100])
     pool = make_pool(rng, npool, vlen, alphabet, min_dist=1, iupac_rate=rng.choice([0, 0, 0.05]))
@@ -193,6 +193,45 @@ def random_paired_combo_case(rng: random.Random, sizes=(1, 30, 150), max_mm: int
     return dict(kind="paired_combo", template1=c["template1"], reverse1=c["reverse1"], mismatches1=c["mismatches1"], pool1=pool1,
                 template2=c["template2"], reverse2=c["reverse2"], mismatches2=c["mismatches2"], pool2=pool2,
                 randomized=c["randomized"], use_first=c["use_first"], reads1=c["reads1"], reads2=c["reads2"])
+
+
+def random_dual_single_end_case(rng: random.Random, sizes=(1, 30, 150), wide: bool = None) -> dict:
+    """countDualBarcodesSingleEnd: one or two variable regions in one read, pools aligned by row
+    (row c = valid combination c); `wide` forces a combined key longer than 32 bases."""
+    nreg = rng.choice([1, 2, 2])
+    if wide is None:
+        wide = rng.random() < 0.4
+    if nreg == 1:
+        lens = [rng.choice([33, 40, 64] if wide else [4, 9, 20])]
+    else:
+        lens = rng.choice([[20, 20], [17, 30], [32, 32], [5, 40]] if wide else [[4, 6], [8, 8], [12, 20]])
+    alphabet = rng.choice(["AC", BASES])
+    n = min(rng.choice([1, 4, 25]), len(alphabet) ** min(sum(lens), 8) // 2)      # distinct rows must exist
+    seen, rows = set(), []
+    while len(rows) < n:
+        row = tuple(rand_seq(rng, l, alphabet) for l in lens)
+        if "".join(row) not in seen:
+            seen.add("".join(row))
+            rows.append(row)
+    pools = [[row[r] for row in rows] for r in range(nreg)]
+    template = make_template(rng, nreg, lens, rng.choice([0, 2, 5]), rng.choice([5, 9]))
+    strand = rng.choice([0, 1, 2])
+    mm = rng.randint(0, 3)
+    first = rng.random() < 0.5
+    reads = []
+    p_sub, p_n = rng.choice([0, 0.01, 0.04]), rng.choice([0, 0.01])
+    for _ in range(rng.choice(sizes)):
+        u = rng.random()
+        if u < 0.1:
+            reads.append(rand_seq(rng, rng.randint(0, len(template) + 20)))
+            continue
+        row = rng.choice(rows) if u < 0.85 else tuple(rng.choice(rows)[r] for r in range(nreg))   # some mixed (invalid) rows
+        core = mutate(rng, fill_template(template, list(row)), p_sub, p_n, 0.05)
+        read = rand_seq(rng, rng.randint(0, 12)) + core + rand_seq(rng, rng.randint(0, 12))
+        if strand == 1 or (strand == 2 and rng.random() < 0.5):
+            read = rc(read)
+        reads.append(read)
+    return dict(kind="dual_single_end", template=template, strand=strand, pools=pools, mismatches=mm, use_first=first, reads=reads)
 
 
 def random_match_case(rng: random.Random) -> dict:

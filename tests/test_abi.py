@@ -80,7 +80,13 @@ def test_plan_argument_checks_precede_device_errors(sc):
     expect_error(sc, INV, "cannot complement unknown base 'X'", P.single, "ACXT----TGCA", 1, ["AAAA"])
     expect_error(sc, INV, "unknown base 'Z' detected when constructing the trie", P.single, "ACGT----TGCA", 2, ["AAZA"])
     expect_error(sc, INV, "longer than 256 bp", P.single, "A" * 250 + "----" + "C" * 10, 2, ["AAAA"])
-    expect_error(sc, UNS, "longer than 32 bp", P.single, "ACGT" + "-" * 33 + "TGCA", 2, ["A" * 33])
+    expect_error(sc, UNS, "longer than 64 bp", P.single, "ACGT" + "-" * 65 + "TGCA", 2, ["A" * 65])
+    expect_error(sc, UNS, "longer than 32 bp", P.combo, "ACGT" + "-" * 33 + "TG--CA", 2, ["A" * 33], ["CC"])
+    expect_error(sc, INV, "length of 'barcode_pools' should equal the number of variable regions", P.dual_single_end, "ACGT----TG--CA", 2, [["AAAA"]])
+    expect_error(sc, INV, "length of variable region 2 \\(2\\) should be the same as its sequences \\(3\\)", P.dual_single_end, "ACGT----TG--CA", 2, [["AAAA"], ["CCC"]])
+    expect_error(sc, INV, "all entries of 'barcode_pools' should have the same length", P.dual_single_end, "ACGT----TG--CA", 2, [["AAAA", "CCCC"], ["CC"]])
+    expect_error(sc, INV, "duplicate sequences detected \\(1, 2\\)", P.dual_single_end, "ACGT----TG--CA", 2, [["AAAA", "AAAA"], ["CC", "CC"]])
+    expect_error(sc, UNS, "1 or 2 variable regions", P.dual_single_end, "AC--GT--AC--GT", 2, [["AA"], ["CC"], ["GG"]])
     expect_error(sc, INV, "expected 2 variable regions", P.combo, "ACGT----TGCA", 2, ["AAAA"], ["CC"])
     expect_error(sc, INV, "length of variable region 2 \\(3\\) should be the same as its sequences \\(2\\)", P.combo, "ACGT----TG---CA", 2, ["AAAA"], ["CC"])
     expect_error(sc, INV, "both barcode pools should be of the same length", P.dual, "AC--GT", False, 0, ["AA", "CC"], "AC--GT", False, 0, ["AA"])

@@ -44,6 +44,11 @@ def run_file_level(sc, c, tmp_path, gz=False):
                                                                     c["randomized"], c["use_first"], True, 1)
         return {"counts": counts.tolist(), "indices": idx.tolist(), "freq": freq.tolist(), "total": total,
                 "barcode1_only": b1, "barcode2_only": b2}
+    if k == "dual_single_end":
+        fq = str(tmp_path / ("e" + ext))
+        write_fastq(fq, c["reads"], gz=gz)
+        counts, total = sc.count_dual_barcodes_single_end(fq, c["template"], c["pools"], c["strand"], c["mismatches"], c["use_first"], False, 1)
+        return {"counts": counts.tolist(), "total": total}
     if k == "paired_combo":
         f1, f2 = str(tmp_path / ("p1" + ext)), str(tmp_path / ("p2" + ext))
         write_fastq(f1, c["reads1"], gz=gz)

@@ -174,6 +174,46 @@ def test_template_longer_than_64(sc, oracle, gpu):
 
 
 @pytest.mark.parametrize("seed", range(5))
+def test_dual_single_end_random(sc, oracle, gpu, seed):
+    """countDualBarcodesSingleEnd: one or two regions concatenated into one (possibly > 32 bp) key."""
+    rng = random.Random(6800 + seed)
+    for _ in range(20):
+        case = gen.random_dual_single_end_case(rng)
+        exp = oracle.count_dual_single_end(case["reads"], case["template"], case["strand"], case["pools"], case["mismatches"], case["use_first"])
+        seqs, offs = sc.upload_reads(case["reads"], gpu)
+        with sc.Plan.dual_single_end(case["template"], case["strand"], case["pools"], case["mismatches"], case["use_first"]) as plan:
+            plan.count(seqs, offs)
+            got = plan.read()
+        assert got[1] == exp[1] and np.array_equal(got[0], exp[0]), (case, exp, got)
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_wide_single_and_match_random(sc, oracle, gpu, seed):
+    """Barcodes of 33..64 bases through the wide-key kernels (countSingleBarcodes, matchBarcodes)."""
+    rng = random.Random(6900 + seed)
+    for _ in range(15):
+        case = gen.random_single_case(rng, max_vlen=64, min_vlen=33)
+        try:
+            exp = oracle.count_single(case["reads"], case["template"], case["strand"], case["pool"], case["mismatches"], case["use_first"])
+        except Exception:
+            with pytest.raises(sc.ScgError):
+                run_single(sc, case, gpu)
+            continue
+        got = run_single(sc, case, gpu)
+        assert got[1] == exp[1] and np.array_equal(got[0], exp[0]), (case, exp, got)
+    for _ in range(10):
+        vlen = rng.choice([33, 48, 64])
+        pool = gen.make_pool(rng, rng.choice([1, 5, 30]), vlen, "ACGT")
+        seqs = [gen.mutate(rng, rng.choice(pool), 0.04, 0.01, 0.1) for _ in range(40)]
+        subs, rev = rng.choice([0, 1, 2, 3]), rng.random() < 0.5
+        if rev:
+            seqs = [gen.rc(s) if set(s.upper()) <= set("ACGT") else s for s in seqs]
+        exp = oracle.match_barcodes(seqs, pool, subs, rev)
+        got = sc.match_barcodes(seqs, pool, subs, rev)
+        assert np.array_equal(got[0], exp[0]) and np.array_equal(got[1], exp[1]), (pool, seqs, subs, rev)
+
+
+@pytest.mark.parametrize("seed", range(5))
 def test_paired_combo_random(sc, oracle, gpu, seed):
     """countPairedComboBarcodes: combinations of independently matched mates, barcode1/2-only tallies."""
     rng = random.Random(6500 + seed)

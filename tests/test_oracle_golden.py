@@ -28,6 +28,9 @@ def run_oracle(oracle, c):
                                    c["template2"], c["reverse2"], c["mismatches2"], c["pool2"], c["randomized"], c["use_first"])
         return {"counts": d["counts"].tolist(), "indices": d["indices"].tolist(), "freq": d["freq"].tolist(), "total": d["total"],
                 "barcode1_only": d["barcode1_only"], "barcode2_only": d["barcode2_only"]}
+    if k == "dual_single_end":
+        counts, total = oracle.count_dual_single_end(c["reads"], c["template"], c["strand"], c["pools"], c["mismatches"], c["use_first"])
+        return {"counts": counts.tolist(), "total": total}
     if k == "paired_combo":
         d = oracle.count_combo_paired(c["reads1"], c["reads2"], c["template1"], c["reverse1"], c["mismatches1"], c["pool1"],
                                       c["template2"], c["reverse2"], c["mismatches2"], c["pool2"], c["randomized"], c["use_first"])
