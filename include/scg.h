@@ -106,6 +106,14 @@ int scg_count_dual_barcodes_single_end(const char* path, const char* constant,
                                        int strand, int mismatches, int use_first, int diagnostics, int nthreads,
                                        int32_t* counts_out, int32_t* total_out, char* err, size_t errcap);
 
+/* countRandomBarcodes: tally of the sequences found in the variable region of
+ * `constant`.  Replaces src/count_random_barcodes.cpp:41-62 (kaori::RandomBarcodeSingleEnd).  On success
+ * *sequences_out is a malloc'd block of K NUL-terminated strings of *length_out characters each (stride
+ * *length_out + 1), sorted byte-wise, *freq_out their K counts (release both with scg_free). */
+int scg_count_random_barcodes(const char* path, const char* constant, int strand, int mismatches, int use_first,
+                              int nthreads, char** sequences_out, int32_t** freq_out, int64_t* k_out,
+                              int32_t* length_out, int32_t* total_out, char* err, size_t errcap);
+
 /* countPairedComboBarcodes hot path: one variable region per mate, every
  * (pool1, pool2) combination counts.  Replaces src/count_combo_barcodes_paired.cpp:57-95
  * (kaori::CombinatorialBarcodesPairedEnd).  Outputs mirror its 5-list: a malloc'd 2 x K column-major

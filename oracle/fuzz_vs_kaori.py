@@ -198,6 +198,25 @@ def fuzz_dual_single_end(rng, ora, ref, tmpdir, it):
     return "ok"
 
 
+def fuzz_random(rng, ora, ref, tmpdir, it):
+    from tests import gen
+    c = gen.random_random_barcode_case(rng)
+    fq = os.path.join(tmpdir, f"r{it}.fastq")
+    write_fastq(fq, c["reads"])
+    try:
+        exp = ref.count_random(fq, c["template"], c["strand"], c["mismatches"], c["use_first"], 1)
+    except OracleError:
+        try:
+            ora.count_random(c["reads"], c["template"], c["strand"], c["mismatches"], c["use_first"])
+        except OracleError:
+            return "both-error"
+        raise
+    got = ora.count_random(c["reads"], c["template"], c["strand"], c["mismatches"], c["use_first"])
+    if got != exp:
+        raise AssertionError(f"random mismatch: {c}\nexp={exp}\ngot={got}")
+    return "ok"
+
+
 def fuzz_match(rng, ora, ref):
     vlen = rng.choice([3, 5, 8, 12])
     alphabet = rng.choice(["AC", BASES])
@@ -239,6 +258,7 @@ def main():
                              ("dual-diag", lambda: fuzz_dual_diag(rng, ora, ref, tmp, it)),
                              ("combo-paired", lambda: fuzz_combo_paired(rng, ora, ref, tmp, it)),
                              ("dual-single-end", lambda: fuzz_dual_single_end(rng, ora, ref, tmp, it)),
+                             ("random", lambda: fuzz_random(rng, ora, ref, tmp, it)),
                              ("match", lambda: fuzz_match(rng, ora, ref))):
                 res = fn()
                 tally[f"{name}:{res}"] = tally.get(f"{name}:{res}", 0) + 1

@@ -247,6 +247,49 @@ int kref_count_dual_diag(const char* path1, const char* tmpl1, int reverse1, int
     return 0;
 }
 
+/* src/count_random_barcodes.cpp:41-62: *seq_out = K strings of *len_out chars, NUL-terminated, sorted
+ * byte-wise (the reference's unordered_map order is unspecified; its R caller sorts); free with kref_free. */
+int kref_count_random(const char* path, const char* tmpl, int strand, int mm, int use_first, int nthreads,
+                      char** seq_out, int32_t** freq_out, int64_t* k_out, int32_t* len_out, int32_t* total,
+                      char* err, size_t errcap) {
+    try {
+        byteme::SomeFileReader reader(path);
+        std::string constant(tmpl);
+        std::vector<std::pair<std::string, int> > rows;
+        auto run = [&](auto tag) {
+            constexpr size_t N = decltype(tag)::value;
+            typename kaori::RandomBarcodeSingleEnd<N>::Options options;
+            options.strand = to_strand(strand);
+            options.max_mismatches = mm;
+            options.use_first = use_first != 0;
+            kaori::RandomBarcodeSingleEnd<N> handler(constant.c_str(), constant.size(), options);
+            kaori::process_single_end_data(&reader, handler, nthreads);
+            rows.assign(handler.get_counts().begin(), handler.get_counts().end());
+            *total = handler.get_total();
+        };
+        size_t len = constant.size();
+        if (len <= 32) run(std::integral_constant<size_t, 32>());
+        else if (len <= 64) run(std::integral_constant<size_t, 64>());
+        else if (len <= 128) run(std::integral_constant<size_t, 128>());
+        else if (len <= 256) run(std::integral_constant<size_t, 256>());
+        else throw std::runtime_error("lacking compile-time support for constant regions longer than 256 bp");
+        std::sort(rows.begin(), rows.end());
+        size_t vlen = rows.empty() ? 0 : rows[0].first.size();
+        *len_out = static_cast<int32_t>(vlen);
+        *k_out = static_cast<int64_t>(rows.size());
+        *seq_out = static_cast<char*>(std::malloc(rows.size() * (vlen + 1) + 1));
+        *freq_out = static_cast<int32_t*>(std::malloc(sizeof(int32_t) * (rows.size() + 1)));
+        for (size_t i = 0; i < rows.size(); ++i) {
+            std::memcpy(*seq_out + i * (vlen + 1), rows[i].first.data(), vlen);
+            (*seq_out)[i * (vlen + 1) + vlen] = 0;
+            (*freq_out)[i] = rows[i].second;
+        }
+    } catch (std::exception& e) {
+        return set_err(err, errcap, e.what());
+    }
+    return 0;
+}
+
 /* src/count_dual_barcodes_single_end.cpp:53-87, non-diagnostic branch. */
 int kref_count_dual_single_end(const char* path, const char* tmpl, int strand,
                                const char* const* const* pools, const int* n_pools, int n_regions,

@@ -204,6 +204,37 @@ class Oracle:
         return dict(counts=counts[:len(pool1)].copy(), indices=tuples[:2 * k].reshape(k, 2).T.copy(), freq=freq[:k].copy(),
                     total=int(total.value), barcode1_only=int(b1.value), barcode2_only=int(b2.value))
 
+    def count_random(self, reads, template: str, strand: int, mismatches: int, use_first: bool):
+        """countRandomBarcodes -> (dict sequence -> count, total).  The C restatement decides the window of
+        every read (scgo_random_hits); the strings are cut here exactly as RandomBarcodeSingleEnd.hpp:86-115 does."""
+        s, o = _as_batch(reads)
+        n = len(o) - 1
+        hits = np.zeros(max(n, 1), dtype=np.int32)
+        vstart, vlen = C.c_int32(0), C.c_int32(0)
+        err = C.create_string_buffer(_ERRCAP)
+        sp, _a = _ptr(s, C.c_char)
+        rc = self.L.scgo_random_hits(sp, o.ctypes.data_as(C.POINTER(C.c_uint64)), C.c_int64(n), template.encode(), C.c_int(len(template)),
+                                     C.c_int(strand), C.c_int(mismatches), C.c_int(int(use_first)),
+                                     hits.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(vstart), C.byref(vlen), err, C.c_size_t(_ERRCAP))
+        if rc:
+            raise OracleError(err.value.decode())
+        comp = {"A": "T", "C": "G", "G": "C", "T": "A", "N": "N"}
+        raw = bytes(s)
+        out = {}
+        for i in range(n):
+            h = int(hits[i])
+            if h < 0:
+                continue
+            a = int(o[i]) + (h >> 1) + vstart.value
+            piece = raw[a:a + vlen.value].decode("latin-1")
+            if h & 1:
+                try:
+                    piece = "".join(comp[c.upper()] for c in reversed(piece))
+                except KeyError as ex:
+                    raise OracleError(f"cannot complement unknown base '{ex.args[0]}'")
+            out[piece] = out.get(piece, 0) + 1
+        return out, n
+
     def count_dual_single_end(self, reads, template: str, strand: int, pools: Sequence[Sequence[str]], mismatches: int, use_first: bool):
         """countDualBarcodesSingleEnd -> (counts int32[n], total)"""
         s, o = _as_batch(reads)
@@ -383,6 +414,25 @@ class KaoriRef:
             self.L.kref_free(freq_p)
         return dict(counts=counts[:len(pool1)].copy(), indices=idx, freq=freq, total=int(total.value),
                     barcode1_only=int(b1.value), barcode2_only=int(b2.value))
+
+    def count_random(self, fastq: str, template: str, strand: int, mismatches: int, use_first: bool, nthreads: int = 1):
+        seq_p = C.c_void_p()
+        freq_p = C.POINTER(C.c_int32)()
+        k, vlen, total = C.c_int64(0), C.c_int32(0), C.c_int32(0)
+        err = C.create_string_buffer(_ERRCAP)
+        rc = self.L.kref_count_random(fastq.encode(), template.encode(), C.c_int(strand), C.c_int(mismatches), C.c_int(int(use_first)),
+                                      C.c_int(nthreads), C.byref(seq_p), C.byref(freq_p), C.byref(k), C.byref(vlen), C.byref(total),
+                                      err, C.c_size_t(_ERRCAP))
+        if rc:
+            raise OracleError(err.value.decode())
+        K, L = int(k.value), int(vlen.value)
+        try:
+            blob = C.string_at(seq_p, K * (L + 1)) if K else b""
+            out = {blob[i * (L + 1): i * (L + 1) + L].decode("latin-1"): int(freq_p[i]) for i in range(K)}
+        finally:
+            self.L.kref_free(seq_p)
+            self.L.kref_free(freq_p)
+        return out, int(total.value)
 
     def count_dual_single_end(self, fastq: str, template: str, strand: int, pools: Sequence[Sequence[str]], mismatches: int,
                               use_first: bool, nthreads: int = 1):

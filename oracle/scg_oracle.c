@@ -1002,6 +1002,40 @@ int scgo_count_dual_single_end(const char *seqs, const uint64_t *offsets, int64_
     return 0;
 }
 
+/* countRandomBarcodes: src/count_random_barcodes.cpp:11-37 over kaori::RandomBarcodeSingleEnd
+ * (handlers/RandomBarcodeSingleEnd.hpp:86-175).  hits[r] = (position << 1) | reverse of the window whose
+ * variable region is tallied for read r, or -1; the caller cuts the strings (forward: raw bytes at the
+ * forward region; reverse: the bytes at the FORWARD region's offset -- :103-105 uses variable_regions()[0]
+ * on both strands -- reverse-complemented).  Returns 0. */
+int scgo_random_hits(const char *seqs, const uint64_t *offsets, int64_t n_reads,
+                     const char *tmpl, int tmpl_len, int strand, int max_mm, int use_first,
+                     int32_t *hits, int32_t *vstart, int32_t *vlen, char *err, size_t errcap) {
+    errbuf e = {err, errcap};
+    tmpl_t T;
+    if (tmpl_init(&T, tmpl, tmpl_len, strand, &e)) return 1;
+    if (T.nreg < 1) return fail(&e, "expected one variable region in the constant template");
+    *vstart = T.fstart[0];
+    *vlen = T.fend[0] - T.fstart[0];
+    for (int64_t r = 0; r < n_reads; ++r) {
+        const char *read = seqs + offsets[r];
+        int n = (int)(offsets[r + 1] - offsets[r]);
+        int out = -1, best = max_mm + 1, code = -1, tied = 0;
+        for (int p = 0; p + T.len <= n && out < 0; ++p) {
+            for (int s = 0; s < 2; ++s) {
+                if (s == 0 ? !T.fwd : !T.rev) continue;
+                int c = const_mm(&T, read, p, s);
+                if (c > max_mm) continue;                       /* has_match(): :78-80 */
+                if (use_first) { out = (p << 1) | s; break; }   /* :121-132 */
+                if (c < best) { best = c; code = (p << 1) | s; tied = 0; }      /* :134-162 */
+                else if (c == best) { tied = 1; }
+            }
+        }
+        if (!use_first && !tied && best <= max_mm) out = code;  /* :164-170 */
+        hits[r] = out;
+    }
+    return 0;
+}
+
 /* countPairedComboBarcodes: src/count_combo_barcodes_paired.cpp:11-55 over
  * kaori::CombinatorialBarcodesPairedEnd (two SimpleSingleMatch matchers, DuplicateAction::ERROR).
  * tuples: capacity 2 * n_pairs, in read order (the caller sorts / run-length encodes, scgo_combo_rle). */

@@ -70,6 +70,8 @@ SIGNATURES = {
                                                       C.c_char_p, C.c_char_p, C.c_int, C.c_int, c_str_p, C.c_int32,
                                                       C.c_int, C.c_int, C.c_int, i32_p, C.POINTER(i32_p), C.POINTER(i32_p), i64_p,
                                                       i32_p, i32_p, i32_p, C.c_char_p, C.c_size_t]),
+    "scg_count_random_barcodes": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p),
+                                            C.POINTER(i32_p), i64_p, i32_p, i32_p, C.c_char_p, C.c_size_t]),
     "scg_count_dual_barcodes_single_end": (C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(c_str_p), i32_p, C.c_int32,
                                                      C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, i32_p, i32_p, C.c_char_p, C.c_size_t]),
     "scg_plan_dual_single_end": (C.c_int, [C.POINTER(C.c_void_p), C.c_char_p, C.c_int, C.POINTER(c_str_p), i32_p, C.c_int32,

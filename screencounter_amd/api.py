@@ -118,6 +118,27 @@ def count_dual_barcodes(path1: str, constant1: str, reverse1: bool, mismatches1:
     return counts[:len(pool1)].copy(), int(total.value)
 
 
+def count_random_barcodes(path: str, constant: str, strand: int, mismatches: int, use_first: bool, nthreads: int = 1):
+    """src/count_random_barcodes.cpp:41-62 -> ((sequences list[str] sorted, freq int32[K]), total)."""
+    L = _lib.load()
+    seq_p = C.c_void_p()
+    freq_p = _lib.i32_p()
+    k, vlen, total = C.c_int64(0), C.c_int32(0), C.c_int32(0)
+    err = errbuf()
+    check(L.scg_count_random_barcodes(os.fspath(path).encode(), constant.encode(), int(strand), int(mismatches), int(bool(use_first)),
+                                      int(nthreads), C.byref(seq_p), C.byref(freq_p), C.byref(k), C.byref(vlen), C.byref(total),
+                                      err, _lib.ERRCAP), err)
+    K, W = int(k.value), int(vlen.value)
+    try:
+        blob = C.string_at(seq_p, K * (W + 1)) if K else b""
+        seqs = [blob[i * (W + 1): i * (W + 1) + W].decode("latin-1") for i in range(K)]
+        freq = np.ctypeslib.as_array(freq_p, shape=(max(K, 1),))[:K].copy().astype(np.int32)
+    finally:
+        L.scg_free(seq_p)
+        L.scg_free(freq_p)
+    return (seqs, freq), int(total.value)
+
+
 def count_dual_barcodes_single_end(path: str, constant: str, pools: Sequence[Sequence[str]], strand: int, mismatches: int,
                                    use_first: bool, diagnostics: bool = False, nthreads: int = 1):
     """src/count_dual_barcodes_single_end.cpp:53-87 (non-diagnostic branch) -> (counts int32[n combinations], total)."""
@@ -451,6 +472,14 @@ def matrixOfDualBarcodesSingleEnd(files: Sequence[str], choices, withDimnames: b
     if withDimnames:
         se.colnames = [os.path.basename(f) for f in files]
     return se
+
+
+def countRandomBarcodes(fastq: str, template: str, substitutions: int = 0, find_best: bool = False, strand: str = "both",
+                        num_threads: int = 1):
+    """R/countRandomBarcodes.R:61-77 -> dict(sequences sorted, counts, nreads)."""
+    (seqs, freq), total = count_random_barcodes(fastq, template.replace("N", "-"), _strand_code(strand), substitutions,
+                                                not find_best, num_threads)
+    return {"sequences": seqs, "counts": freq, "nreads": total}
 
 
 def countPairedComboBarcodes(fastq: Sequence[str], choices, flank5=None, flank3=None, template=None, substitutions=0,

@@ -12,7 +12,9 @@
 #include <cstring>
 #include <memory>
 #include <string>
+#include <functional>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "scg_host.h"
@@ -200,14 +202,14 @@ struct scg_plan {
         tab[0].upload(htab[0]);
         if (kind != SINGLE) tab[1].upload(htab[1]);
         if (kind == DUAL) pairs.upload(hpairs);
-        own_counters.alloc(static_cast<size_t>(n_counters) * sizeof(int32_t));
+        own_counters.alloc(static_cast<size_t>(std::max<int64_t>(n_counters, 1)) * sizeof(int32_t));   // (plans without counters: random barcodes)
         counters = own_counters.as<int32_t>();
-        HIP_CHECK(hipMemset(counters, 0, static_cast<size_t>(n_counters) * sizeof(int32_t)));
+        HIP_CHECK(hipMemset(counters, 0, static_cast<size_t>(std::max<int64_t>(n_counters, 1)) * sizeof(int32_t)));
         // enough replicas that ~2^20 distinct addresses take the atomics
         replica_shift = 0;
         int addr_log2 = 20;
         if (const char* e = std::getenv("SCG_REPLICA_ADDR_LOG2")) addr_log2 = std::atoi(e);     // tuning aid
-        while (replica_shift < 12 && (n_counters << (replica_shift + 1)) <= (int64_t(1) << addr_log2)) ++replica_shift;
+        while (n_counters > 0 && replica_shift < 12 && (n_counters << (replica_shift + 1)) <= (int64_t(1) << addr_log2)) ++replica_shift;
         if (replica_shift > 0) {
             replicas.alloc((static_cast<size_t>(n_counters) << replica_shift) * sizeof(int32_t));
             HIP_CHECK(hipMemset(replicas.p, 0, replicas.bytes));
@@ -525,11 +527,15 @@ struct Stager {
     static const int SLOTS = 2;
     struct Slot {
         hipStream_t stream = nullptr;
-        PinnedBuf h_seqs[2], h_offs[2];
-        DevBuf d_seqs[2], d_offs[2];
+        PinnedBuf h_seqs[2], h_offs[2], h_aux;
+        DevBuf d_seqs[2], d_offs[2], d_aux;
+        int64_t n_reads = 0;         // reads of the batch in flight (for `retire`)
         bool busy = false;
     } slot[SLOTS];
     int next = 0;
+    // Called with a slot whose stream has just been synchronised, before its buffers are reused:
+    // pipelines that bring per-read results back to the host consume them here.
+    std::function<void(Slot&)> retire;
 
     Stager() {
         for (auto& s : slot) HIP_CHECK(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
@@ -541,7 +547,7 @@ struct Stager {
     Slot& acquire() {
         Slot& s = slot[next];
         next = (next + 1) % SLOTS;
-        if (s.busy) { HIP_CHECK(hipStreamSynchronize(s.stream)); s.busy = false; }
+        if (s.busy) { HIP_CHECK(hipStreamSynchronize(s.stream)); s.busy = false; if (retire) retire(s); }
         return s;
     }
 
@@ -569,7 +575,13 @@ struct Stager {
     }
 
     void drain() {
-        for (auto& s : slot) { HIP_CHECK(hipStreamSynchronize(s.stream)); s.busy = false; }
+        // oldest batch first, so that `retire` sees the batches in file order
+        for (int k = 0; k < SLOTS; ++k) {
+            Slot& s = slot[(next + k) % SLOTS];
+            HIP_CHECK(hipStreamSynchronize(s.stream));
+            if (s.busy && retire) { s.busy = false; retire(s); }
+            s.busy = false;
+        }
     }
 };
 
@@ -579,8 +591,16 @@ const int64_t BATCH_BYTES = int64_t(1) << 30;
 // FASTQ file -> counters for single-end plans.  Plain 4-line FASTQ is parsed by several host
 // threads (ParallelFastq); gzip input, and any file the parallel reader finds unusual, goes
 // through the sequential reader, which reproduces the reference's parse and errors exactly.
-void count_single_end_file(scg_plan* P, const char* path, scg::FastqStream& fq, int nthreads) {
+void count_single_end_file(scg_plan* P, const char* path, scg::FastqStream& fq, int nthreads,
+                           const std::function<void(Stager::Slot&, const ScgReads&, int64_t)>& launch = nullptr,
+                           const std::function<void(Stager::Slot&)>& retire = nullptr,
+                           const std::function<void()>& restart = nullptr) {
     Stager st;
+    st.retire = retire;
+    auto run = [&](Stager::Slot& s, const ScgReads& R, int64_t n) {
+        s.n_reads = n;
+        if (launch) launch(s, R, n); else launch_batch(P, R, n, s.stream);
+    };
     const int threads = scg::default_host_threads(nthreads);
     if (threads > 1 && scg::ParallelFastq::is_plain_file(path)) {
         scg::ParallelFastq pf(path, threads);
@@ -595,7 +615,7 @@ void count_single_end_file(scg_plan* P, const char* path, scg::FastqStream& fq, 
                     if (b.size() == 0) continue;
                     auto& s = st.acquire();
                     ScgReads R = st.stage(s, 0, b);
-                    launch_batch(P, R, b.size(), s.stream);
+                    run(s, R, b.size());
                     s.busy = true;
                 }
             } catch (...) {
@@ -609,14 +629,15 @@ void count_single_end_file(scg_plan* P, const char* path, scg::FastqStream& fq, 
         st.drain();
         if (!pf.unusual()) return;
         // start over with the reference-exact sequential reader
-        HIP_CHECK(hipMemset(P->counters, 0, static_cast<size_t>(P->n_counters) * sizeof(int32_t)));
+        if (P->n_counters) HIP_CHECK(hipMemset(P->counters, 0, static_cast<size_t>(P->n_counters) * sizeof(int32_t)));
         P->total = 0;
+        if (restart) restart();
     }
     scg::ReadBatch b;
     while (fq.next_batch(b, BATCH_READS, BATCH_BYTES)) {
         auto& s = st.acquire();
         ScgReads R = st.stage(s, 0, b);
-        launch_batch(P, R, b.size(), s.stream);
+        run(s, R, b.size());
         s.busy = true;
     }
     st.drain();
@@ -1074,6 +1095,96 @@ int scg_count_dual_barcodes_single_end(const char* path, const char* constant, c
         DeviceGuard g(P->device);
         count_single_end_file(P.get(), path, fq, nthreads);
         read_counters(P.get(), counts_out);
+        *total_out = static_cast<int32_t>(P->total);
+    });
+}
+
+// countRandomBarcodes (src/count_random_barcodes.cpp:41-62, kaori::RandomBarcodeSingleEnd): the device
+// locates the template in every read (same scan kernels, no library), the host cuts the variable region
+// out of its copy of the batch and tallies the strings.  Reproduced quirks of the reference:
+//  * the forward-strand string is the raw read bytes (case preserved);
+//  * on the reverse strand the region is taken at the FORWARD template's offset inside the window
+//    (RandomBarcodeSingleEnd.hpp:103-105 reads variable_regions()[0], not the reverse regions) and then
+//    reverse-complemented with complement_base<true>: ACGTN in either case -> upper case, anything
+//    else is the error "cannot complement unknown base".
+// Output order: byte-wise ascending (the reference iterates an unordered_map; its R caller sorts).
+int scg_count_random_barcodes(const char* path, const char* constant, int strand, int mismatches, int use_first, int nthreads,
+                              char** sequences_out, int32_t** freq_out, int64_t* k_out, int32_t* length_out, int32_t* total_out,
+                              char* err, size_t errcap) {
+    return guarded(err, errcap, [&] {
+        if (!path || !constant || !sequences_out || !freq_out || !k_out || !length_out || !total_out) throw Error(SCG_ERR_INVALID, "null argument");
+        scg::FastqStream fq(path);                             // reader first (src/count_random_barcodes.cpp:42)
+        std::unique_ptr<scg_plan> P(new scg_plan);
+        P->kind = scg_plan::SINGLE;
+        P->ht1 = scg::parse_template(constant, strand);
+        const ScgTemplate& t = P->ht1.t;
+        if (t.nreg < 1) throw Error(SCG_ERR_INVALID, "expected one variable region in the constant template");
+        if (t.nreg > SCG_MAX_REGIONS) throw Error(SCG_ERR_UNSUPPORTED, "this engine handles templates with at most 2 variable regions");
+        if (mismatches < 0) throw Error(SCG_ERR_INVALID, "negative number of mismatches");
+        P->scan1 = scg::build_scan(t, mismatches);
+        P->max_mm1 = mismatches;
+        P->use_first = use_first != 0;
+        P->n_counters = 0;
+        P->to_device(-1);
+        DeviceGuard g(P->device);
+        const int vstart = t.fstart[0], vlen = t.flen[0];      // forward coordinates on both strands (see above)
+        std::unordered_map<std::string, int32_t> tally;
+        std::string key(static_cast<size_t>(vlen), ' ');
+        ScgSingleParams sp;
+        sp.scan = P->scan1;
+        sp.tmpl = P->d_tmpl1.as<ScgTemplate>();
+        std::memset(&sp.index, 0, sizeof(sp.index));
+        sp.max_mm = mismatches; sp.use_first = P->use_first;
+        sp.fwd = P->ht1.fwd; sp.rev = P->ht1.rev;
+        auto launch = [&](Stager::Slot& s, const ScgReads& R, int64_t n) {
+            s.d_aux.ensure(static_cast<size_t>(n) * sizeof(int32_t));
+            s.h_aux.ensure(static_cast<size_t>(n) * sizeof(int32_t));
+            HIP_CHECK(scg::launch_random(sp, t.len, R, n, s.d_aux.as<int32_t>(), P->error_flag.as<int32_t>(), s.stream));
+            HIP_CHECK(hipMemcpyAsync(s.h_aux.p, s.d_aux.p, static_cast<size_t>(n) * sizeof(int32_t), hipMemcpyDeviceToHost, s.stream));
+            P->total += n;
+        };
+        auto retire = [&](Stager::Slot& s) {
+            const int32_t* hits = s.h_aux.as<int32_t>();
+            const char* seqs = s.h_seqs[0].as<char>();
+            const uint32_t* offs = s.h_offs[0].as<uint32_t>();
+            for (int64_t i = 0; i < s.n_reads; ++i) {
+                const int32_t h = hits[i];
+                if (h < 0) continue;
+                const char* start = seqs + offs[i] + (h >> 1) + vstart;
+                if (!(h & 1)) {
+                    key.assign(start, static_cast<size_t>(vlen));
+                } else {
+                    for (int j = 0; j < vlen; ++j) {
+                        char b = start[vlen - j - 1], o;
+                        switch (b) {                            // kaori/utils.hpp:41-120, complement_base<true>
+                            case 'A': case 'a': o = 'T'; break;
+                            case 'C': case 'c': o = 'G'; break;
+                            case 'G': case 'g': o = 'C'; break;
+                            case 'T': case 't': o = 'A'; break;
+                            case 'N': case 'n': o = 'N'; break;
+                            default: throw Error(SCG_ERR_INVALID, std::string("cannot complement unknown base '") + b + "'");
+                        }
+                        key[static_cast<size_t>(j)] = o;
+                    }
+                }
+                ++tally[key];
+            }
+        };
+        auto restart = [&] { tally.clear(); };
+        count_single_end_file(P.get(), path, fq, nthreads, launch, retire, restart);
+        read_counters(P.get(), nullptr);                       // surfaces the oversize-read flag
+        std::vector<std::pair<std::string, int32_t> > rows(tally.begin(), tally.end());
+        std::sort(rows.begin(), rows.end());
+        const size_t stride = static_cast<size_t>(vlen) + 1;
+        char* so = static_cast<char*>(std::malloc(rows.size() * stride + 1));
+        int32_t* fo = static_cast<int32_t*>(std::malloc(sizeof(int32_t) * (rows.size() + 1)));
+        if (!so || !fo) { std::free(so); std::free(fo); throw std::bad_alloc(); }
+        for (size_t i = 0; i < rows.size(); ++i) {
+            std::memcpy(so + i * stride, rows[i].first.data(), static_cast<size_t>(vlen));
+            so[i * stride + vlen] = 0;
+            fo[i] = rows[i].second;
+        }
+        *sequences_out = so; *freq_out = fo; *k_out = static_cast<int64_t>(rows.size()); *length_out = vlen;
         *total_out = static_cast<int32_t>(P->total);
     });
 }

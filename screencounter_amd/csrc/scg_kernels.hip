@@ -91,6 +91,40 @@ __global__ __launch_bounds__(BLOCK) void single_kernel(ScgSingleParams P, ScgRea
 }
 
 // ---------------------------------------------------------------------------------------------
+// random barcodes: where does the template sit?  (RandomBarcodeSingleEnd.hpp:117-175)
+// hit = (position << 1) | reverse, or -1.  use_first: first position / strand within the budget;
+// otherwise the unique minimum of constant mismatches (any tie, also across strands => none).
+// ---------------------------------------------------------------------------------------------
+struct BestHit {
+    int best, code;
+    bool tied;
+    __device__ __forceinline__ void offer(int c, int p, bool reverse) {
+        if (c < best) { best = c; code = (p << 1) | (reverse ? 1 : 0); tied = false; }
+        else if (c == best) { tied = true; }
+    }
+};
+
+__global__ __launch_bounds__(BLOCK) void random_kernel(ScgSingleParams P, ScgReads R, int64_t n_reads, int32_t* __restrict__ hits) {
+    int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n_reads) return;
+    Read rd = get_read(R, i);
+    const ScgTemplate* T = P.tmpl;
+    BestHit h{P.max_mm + 1, -1, false};
+    int out = -1;
+    for (int p = 0; p + T->len <= rd.n && out < 0; ++p) {
+        for (int s = 0; s < 2; ++s) {
+            if (s == 0 ? !P.fwd : !P.rev) continue;
+            int c = const_mismatches(T, s != 0, rd.p, p, P.max_mm);
+            if (c > P.max_mm) continue;
+            if (P.use_first) { out = (p << 1) | s; break; }
+            h.offer(c, p, s != 0);
+        }
+    }
+    if (!P.use_first && !h.tied && h.best <= P.max_mm) out = h.code;
+    hits[i] = out;
+}
+
+// ---------------------------------------------------------------------------------------------
 // combo (two variable regions in one template)
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool combo_candidate(const ScgComboParams& P, const Read& rd, int p, bool reverse, int c,
@@ -383,6 +417,46 @@ __global__ __launch_bounds__(STAGE_BLOCK) __attribute__((amdgpu_num_sgpr(80))) v
         idx = single_read_staged<NW, NT, NC, W>(P, tile, strands, sr, R.ablate);
     }
     if (idx >= 0 && !(R.ablate == 3 && idx != 0x7ffffff0)) count_one(counts, idx);
+}
+
+template<int NW, int NT, int NC>
+__global__ __launch_bounds__(STAGE_BLOCK) __attribute__((amdgpu_num_sgpr(80))) void random_staged_kernel(ScgSingleParams P, ScgReads R, int64_t n_reads,
+                                                                   int32_t* __restrict__ hits, int32_t* __restrict__ error_flag) {
+    __shared__ Tile<NW> tile;
+    __shared__ StrandTable<NT> strands;
+    fill_strand_table<NT>(strands, P.scan);
+    const int64_t r0 = (int64_t)blockIdx.x * STAGE_BLOCK;
+    const int nr = (int)((n_reads - r0) < STAGE_BLOCK ? (n_reads - r0) : STAGE_BLOCK);
+    int64_t span0 = 0;
+    const bool staged = (P.scan.len <= 32 * NT) && stage_reads<NW>(R, n_reads, r0, nr, tile, span0);
+    __syncthreads();
+    if ((int)threadIdx.x >= nr) return;
+    Read rd = get_read(R, r0 + threadIdx.x);
+    if (!staged || rd.n > 32 * NW) {
+        *error_flag = 1;
+        return;
+    }
+    StagedRead sr;
+    sr.bit = (int)((int64_t)(rd.p - R.seqs) - span0);
+    sr.n = rd.n;
+    uint32_t candF[NC], candR[NC];
+    scan_read<NW, NC>(tile, sr, P.scan, P.fwd != 0, P.rev != 0, candF, candR);
+    BestHit h{P.max_mm + 1, -1, false};
+    int out = -1;
+    for (;;) {
+        int pf = first_bit<NC>(candF), pr = first_bit<NC>(candR);
+        bool rev = pr < pf;                           // forward first on ties
+        int p = rev ? pr : pf;
+        if (p >= (1 << 30)) break;
+        clear_bit<NC>(candF, rev ? -1 : p);
+        clear_bit<NC>(candR, rev ? p : -1);
+        int c = window_mismatches<NW, NT>(tile, sr.bit + p, strands, rev);
+        if (c > P.max_mm) continue;
+        if (P.use_first) { out = (p << 1) | (rev ? 1 : 0); break; }
+        h.offer(c, p, rev);
+    }
+    if (!P.use_first && !h.tied && h.best <= P.max_mm) out = h.code;
+    hits[r0 + threadIdx.x] = out;
 }
 
 template<int NW, int NT>
@@ -769,6 +843,26 @@ hipError_t launch_single(const ScgSingleParams& P, int tmpl_len, const ScgReads&
         return hipGetLastError();
     }
     return dispatch_shape<LaunchSingle>(R.max_len, tmpl_len, P, R, n, counts, flag, stream);
+}
+
+template<int NW, int NT> struct LaunchRandom {
+    static hipError_t go(const ScgSingleParams& P, const ScgReads& R, int64_t n, int32_t* hits, int32_t* flag, hipStream_t stream) {
+        if (NW == 5 && P.scan.compact_ok && R.max_len - P.scan.len + 1 <= 96) {
+            hipLaunchKernelGGL((random_staged_kernel<NW, NT, (NW == 5 ? 3 : NW)>), dim3(staged_grid(n)), dim3(STAGE_BLOCK), 0, stream, P, R, n, hits, flag);
+        } else {
+            hipLaunchKernelGGL((random_staged_kernel<NW, NT, NW>), dim3(staged_grid(n)), dim3(STAGE_BLOCK), 0, stream, P, R, n, hits, flag);
+        }
+        return hipGetLastError();
+    }
+};
+
+hipError_t launch_random(const ScgSingleParams& P, int tmpl_len, const ScgReads& R, int64_t n, int32_t* d_hits, int32_t* flag, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    if (use_general(R.max_len)) {
+        hipLaunchKernelGGL(random_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, stream, P, R, n, d_hits);
+        return hipGetLastError();
+    }
+    return dispatch_shape<LaunchRandom>(R.max_len, tmpl_len, P, R, n, d_hits, flag, stream);
 }
 
 hipError_t launch_combo(const ScgComboParams& P, int tmpl_len, const ScgReads& R, int64_t n, const ScgCounters& cells, int32_t* flag, hipStream_t stream) {

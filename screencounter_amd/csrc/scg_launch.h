@@ -10,6 +10,8 @@
 namespace scg {
 
 hipError_t launch_single(const ScgSingleParams& P, int tmpl_len, const ScgReads& R, int64_t n, const ScgCounters& counts, int32_t* flag, hipStream_t stream);
+// countRandomBarcodes: d_hits[i] = (position << 1) | reverse of read i's template hit, or -1
+hipError_t launch_random(const ScgSingleParams& P, int tmpl_len, const ScgReads& R, int64_t n, int32_t* d_hits, int32_t* flag, hipStream_t stream);
 hipError_t launch_combo(const ScgComboParams& P, int tmpl_len, const ScgReads& R, int64_t n, const ScgCounters& cells, int32_t* flag, hipStream_t stream);
 hipError_t launch_dual(const ScgDualParams& P, int tmpl_len, const ScgReads& R1, const ScgReads& R2, int64_t n, const ScgCounters& counts, int32_t* flag, hipStream_t stream);
 hipError_t launch_fold(int32_t* replicas, int replica_shift, int64_t n, int32_t* counters, hipStream_t stream);

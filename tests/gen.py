@@ -234,6 +234,32 @@ def random_dual_single_end_case(rng: random.Random, sizes=(1, 30, 150), wide: bo
     return dict(kind="dual_single_end", template=template, strand=strand, pools=pools, mismatches=mm, use_first=first, reads=reads)
 
 
+def random_random_barcode_case(rng: random.Random, sizes=(1, 30, 150)) -> dict:
+    """countRandomBarcodes: unknown sequences in the variable region; asymmetric flanks exercise the
+    reference's use of forward coordinates on the reverse strand, lower case / N its string handling."""
+    vlen = rng.choice([3, 6, 10, 20, 40])
+    template = make_template(rng, 1, [vlen], rng.choice([0, 2, 5]), rng.choice([5, 9, 14]))
+    strand = rng.choice([0, 1, 2])
+    mm = rng.randint(0, 2)
+    first = rng.random() < 0.5
+    alphabet = rng.choice(["AC", BASES])
+    some = [rand_seq(rng, vlen, alphabet) for _ in range(rng.choice([1, 3, 10]))]
+    reads = []
+    p_sub, p_n, p_low = rng.choice([0, 0.02, 0.06]), rng.choice([0, 0.02]), rng.choice([0, 0.1])
+    for _ in range(rng.choice(sizes)):
+        if rng.random() < 0.1:
+            reads.append(rand_seq(rng, rng.randint(0, len(template) + 20)))
+            continue
+        core = mutate(rng, fill_template(template, [rng.choice(some)]), p_sub, p_n, p_low)
+        read = rand_seq(rng, rng.randint(0, 12)) + core + rand_seq(rng, rng.randint(0, 12))
+        if rng.random() < 0.15:
+            read += rand_seq(rng, rng.randint(0, 3)) + mutate(rng, fill_template(template, [rng.choice(some)]), p_sub, p_n, p_low)
+        if strand == 1 or (strand == 2 and rng.random() < 0.5):
+            read = rc(read)
+        reads.append(read)
+    return dict(kind="random", template=template, strand=strand, mismatches=mm, use_first=first, reads=reads)
+
+
 def random_match_case(rng: random.Random) -> dict:
     vlen = rng.choice([3, 5, 8, 12])
     alphabet = rng.choice(["AC", BASES])

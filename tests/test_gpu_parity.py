@@ -173,6 +173,27 @@ def test_template_longer_than_64(sc, oracle, gpu):
             assert got[1] == exp[1] and np.array_equal(got[0], exp[0]), (flank, mm)
 
 
+@pytest.mark.parametrize("seed", range(4))
+def test_random_barcodes_random(sc, oracle, gpu, seed, tmp_path):
+    """countRandomBarcodes through the file-level entry point (the tally lives on the host), plain and
+    multi-threaded staging, against the oracle."""
+    from oracle.pyoracle import OracleError, write_fastq
+    rng = random.Random(7100 + seed)
+    for it in range(15):
+        case = gen.random_random_barcode_case(rng, sizes=(1, 40, 400))
+        fq = str(tmp_path / f"r{it}.fastq")
+        write_fastq(fq, case["reads"])
+        try:
+            exp = oracle.count_random(case["reads"], case["template"], case["strand"], case["mismatches"], case["use_first"])
+        except OracleError:
+            with pytest.raises(sc.ScgError):
+                sc.count_random_barcodes(fq, case["template"], case["strand"], case["mismatches"], case["use_first"], 1)
+            continue
+        for threads in (1, 4):
+            (seqs, freq), total = sc.count_random_barcodes(fq, case["template"], case["strand"], case["mismatches"], case["use_first"], threads)
+            assert total == exp[1] and dict(zip(seqs, freq.tolist())) == exp[0] and seqs == sorted(seqs), (case, exp, seqs, freq)
+
+
 @pytest.mark.parametrize("seed", range(5))
 def test_dual_single_end_random(sc, oracle, gpu, seed):
     """countDualBarcodesSingleEnd: one or two regions concatenated into one (possibly > 32 bp) key."""
