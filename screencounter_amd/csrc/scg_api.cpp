@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <memory>
 #include <string>
 #include <functional>
@@ -176,6 +177,7 @@ struct scg_plan {
     DevPairTable pairs;
     DevBuf own_counters;
     DevBuf replicas;     // privatised counter copies (ScgCounters); empty when n_counters is large
+    std::map<hipStream_t, DevBuf> unit_index;   // tally mode: barcode index per read of the batch in flight on each stream (ScgCounters::unit_index)
     int replica_shift = 0;   // log2(replicas)
     DevBuf error_flag;   // set by a staged kernel that met a read longer than the declared maximum
     int32_t* counters = nullptr;
@@ -473,7 +475,17 @@ ScgCounters plan_counters(const scg_plan* P) {
     } else {
         c.base = P->counters; c.replica_mask = 0; c.replica_shift = 0;
     }
+    c.unit_index = nullptr;
     return c;
+}
+
+// Tally mode pays off when the library is large enough that block-level aggregation finds no repeats
+// (small libraries are served by the replicas) and small enough for a few LDS passes, on batches
+// large enough to amortise the second kernel.  SCG_TALLY=0/1 overrides (measurement aid).
+bool use_tally(const scg_plan* P, int64_t n) {
+    if (P->kind == scg_plan::COMBO || P->diagnostics) return false;      // single barcodes and plain valid-pair counting
+    if (const char* e = std::getenv("SCG_TALLY")) { if (*e) return *e != '0'; }
+    return P->n_counters >= 4096 && P->n_counters <= 4 * 80 * 1024 && n >= (int64_t(1) << 20);
 }
 
 void fold_replicas(scg_plan* P, hipStream_t stream) {
@@ -491,7 +503,20 @@ void launch_batch(scg_plan* P, const ScgReads& R, int64_t n, hipStream_t stream)
         sp.index = P->tab[0].view;
         sp.max_mm = P->max_mm1; sp.use_first = P->use_first;
         sp.fwd = P->ht1.fwd; sp.rev = P->ht1.rev;
-        HIP_CHECK(scg::launch_single(sp, P->ht1.t.len, R, n, plan_counters(P), P->error_flag.as<int32_t>(), stream));
+        ScgCounters counts = plan_counters(P);
+        const bool tally = use_tally(P, n) && R.max_len > 0 && R.max_len <= 320 && !std::getenv("SCG_FORCE_GENERAL");
+        if (tally) {
+            DevBuf& buf = P->unit_index[stream];              // batches on different streams may be in flight together
+            buf.ensure(static_cast<size_t>(n) * sizeof(int32_t));
+            counts.unit_index = buf.as<int32_t>();
+        }
+        HIP_CHECK(scg::launch_single(sp, P->ht1.t.len, R, n, counts, P->error_flag.as<int32_t>(), stream));
+        if (tally) {
+            timer.stop();                                      // kernel statistics cover the counting kernel, as in rocprof
+            HIP_CHECK(scg::launch_tally(counts.unit_index, n, P->counters, P->n_counters, stream));
+            P->total += n;
+            return;
+        }
     } else {
         ScgComboParams cp;
         cp.scan = P->scan1;
@@ -516,9 +541,18 @@ void launch_batch_paired(scg_plan* P, const ScgReads& R1, const ScgReads& R2, in
     dp.rev1 = P->rev1; dp.rev2 = P->rev2; dp.max_mm1 = P->max_mm1; dp.max_mm2 = P->max_mm2;
     dp.randomized = P->randomized; dp.use_first = P->use_first;
     dp.diagnostics = P->diagnostics; dp.n_pool = P->diagnostics == 2 ? 0 : P->n_pool[0]; dp.n_uid2 = static_cast<int32_t>(P->first2.size());
-    HIP_CHECK(scg::launch_dual(dp, std::max(P->ht1.t.len, P->ht2.t.len), R1, R2, n, plan_counters(P), P->error_flag.as<int32_t>(), stream));
+    ScgCounters counts = plan_counters(P);
+    const int lo_len = std::min(R1.max_len, R2.max_len), hi_len = std::max(R1.max_len, R2.max_len);
+    const bool tally = use_tally(P, n) && lo_len > 0 && hi_len <= 320 && !std::getenv("SCG_FORCE_GENERAL");
+    if (tally) {
+        DevBuf& buf = P->unit_index[stream];
+        buf.ensure(static_cast<size_t>(n) * sizeof(int32_t));
+        counts.unit_index = buf.as<int32_t>();
+    }
+    HIP_CHECK(scg::launch_dual(dp, std::max(P->ht1.t.len, P->ht2.t.len), R1, R2, n, counts, P->error_flag.as<int32_t>(), stream));
     timer.stop();
-    fold_replicas(P, stream);
+    if (tally) HIP_CHECK(scg::launch_tally(counts.unit_index, n, P->counters, P->n_counters, stream));
+    else fold_replicas(P, stream);
     P->total += n;
 }
 

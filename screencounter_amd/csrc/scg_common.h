@@ -145,6 +145,10 @@ struct ScgCounters {
     int32_t* base;
     uint32_t replica_mask;      // replicas - 1 (power of two)
     uint32_t replica_shift;     // log2(replicas)
+    // Tally mode (single-barcode kernels, mid-sized libraries): instead of one memory-side atomic per
+    // mapped read the kernel stores the barcode index of read r (or -1) in unit_index[r], and
+    // tally_kernel turns the index stream into counts through LDS histograms (scg_kernels.hip).
+    int32_t* unit_index;        // nullptr: count with atomics
 };
 
 struct ScgReads {

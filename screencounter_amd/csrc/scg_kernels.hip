@@ -416,7 +416,8 @@ __global__ __launch_bounds__(STAGE_BLOCK) __attribute__((amdgpu_num_sgpr(80))) v
     } else {
         idx = single_read_staged<NW, NT, NC, W>(P, tile, strands, sr, R.ablate);
     }
-    if (idx >= 0 && !(R.ablate == 3 && idx != 0x7ffffff0)) count_one(counts, idx);
+    if (counts.unit_index) counts.unit_index[r0 + threadIdx.x] = idx;
+    else if (idx >= 0 && !(R.ablate == 3 && idx != 0x7ffffff0)) count_one(counts, idx);
 }
 
 template<int NW, int NT, int NC>
@@ -672,7 +673,8 @@ __global__ __launch_bounds__(STAGE_BLOCK) void dual_staged_kernel(ScgDualParams 
                 counts);
         }
     }
-    if (idx >= 0) count_one(counts, idx);
+    if (!DIAG && counts.unit_index) counts.unit_index[r0 + threadIdx.x] = idx;       // tally mode (ScgCounters::unit_index)
+    else if (idx >= 0) count_one(counts, idx);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -888,6 +890,55 @@ hipError_t launch_dual(const ScgDualParams& P, int tmpl_len, const ScgReads& R1,
 // counters[i] += sum of counter i's replicas, replicas cleared (see ScgCounters).  Few replicas: one
 // lane per counter; many (small, hot counter arrays): one wave per counter with a shuffle reduction.
 // Exchanges, not load + store: kernels of another stream may be adding to the replicas right now.
+// ---------------------------------------------------------------------------------------------
+// Tally: barcode index per read -> counts, through LDS histograms.
+// Memory-side atomics cost ~6.7 ps each on this part (90 M per 100 M-read launch = 0.6 ms, DESIGN.md
+// section 4); a coalesced 4-byte store per read plus this kernel costs about a third of that.
+// grid = (slices, passes): pass y owns counters [y * bins, (y + 1) * bins), slice x a contiguous range
+// of reads.  Bins are 16-bit, two per LDS dword, so 80 K bins fit one CU's 160 KB; a bin is flushed to
+// its global counter when it reaches 0x8000: the lane that sees the old value 0x7FFF subtracts 0x8000
+// again, and since a workgroup has at most 1024 increments in flight the field cannot run over
+// before that lands.  What is left is added to the global counters at the end (one atomic per
+// non-empty bin and workgroup instead of one per read).
+// ---------------------------------------------------------------------------------------------
+constexpr int TALLY_BLOCK = 1024;
+
+__global__ __launch_bounds__(TALLY_BLOCK) void tally_kernel(const int32_t* __restrict__ unit_index, int64_t n, int32_t* __restrict__ counters,
+                                                            int64_t n_counters, int bins) {
+    extern __shared__ uint32_t tally_bins[];       // bins / 2 dwords
+    const int64_t lo = (int64_t)blockIdx.y * bins;
+    const int nb = (int)((n_counters - lo) < bins ? (n_counters - lo) : bins);
+    for (int i = threadIdx.x; i < (bins + 1) / 2; i += TALLY_BLOCK) tally_bins[i] = 0;
+    __syncthreads();
+    // slice boundaries in units of 4 indices so that 16-byte loads stay aligned
+    const int64_t quads = (n + 3) / 4;
+    const int64_t q0 = quads * blockIdx.x / gridDim.x, q1 = quads * (blockIdx.x + 1) / gridDim.x;
+    auto add = [&](int32_t v) {
+        const uint32_t b = (uint32_t)(v - (int32_t)lo);           // also rejects v = -1 and other passes' bins
+        if (b >= (uint32_t)nb) return;
+        const uint32_t sh = (b & 1u) * 16u;
+        const uint32_t old = atomicAdd(&tally_bins[b >> 1], 1u << sh);
+        if (((old >> sh) & 0xFFFFu) == 0x7FFFu) {
+            atomicSub(&tally_bins[b >> 1], 0x8000u << sh);
+            atomicAdd(&counters[lo + b], 0x8000);
+        }
+    };
+    for (int64_t q = q0 + threadIdx.x; q < q1; q += TALLY_BLOCK) {
+        if (4 * q + 3 < n) {
+            typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
+            const i32x4 v = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(unit_index) + q);
+            add(v.x); add(v.y); add(v.z); add(v.w);
+        } else {
+            for (int64_t i = 4 * q; i < n; ++i) add(unit_index[i]);
+        }
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < nb; b += TALLY_BLOCK) {
+        const uint32_t c = (tally_bins[b >> 1] >> ((b & 1) * 16)) & 0xFFFFu;
+        if (c) atomicAdd(&counters[lo + b], (int32_t)c);
+    }
+}
+
 __global__ __launch_bounds__(BLOCK) void fold_kernel(int32_t* __restrict__ replicas, int shift, int64_t n,
                                                      int32_t* __restrict__ counters) {
     const int R = 1 << shift;
@@ -912,6 +963,26 @@ __global__ __launch_bounds__(BLOCK) void fold_kernel(int32_t* __restrict__ repli
         for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
         if (lane == 0 && sum) atomicAdd(&counters[i], sum);
     }
+}
+
+hipError_t launch_tally(const int32_t* unit_index, int64_t n, int32_t* counters, int64_t n_counters, hipStream_t stream) {
+    if (n <= 0 || n_counters <= 0) return hipSuccess;
+    const int max_bins = 80 * 1024;                       // 160 KB of LDS as 16-bit bins
+    const int passes = (int)((n_counters + max_bins - 1) / max_bins);
+    int bins = (int)((n_counters + passes - 1) / passes);
+    bins = (bins + 1) & ~1;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tally_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_bins * 2);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    int64_t slices = n / (int64_t(1) << 19);              // >= 512 K reads per workgroup: flush traffic stays small
+    if (slices < 1) slices = 1;
+    if (slices * passes > 512) slices = 512 / passes;
+    hipLaunchKernelGGL(tally_kernel, dim3((unsigned)slices, (unsigned)passes), dim3(TALLY_BLOCK), (size_t)bins * 2, stream,
+                       unit_index, n, counters, n_counters, bins);
+    return hipGetLastError();
 }
 
 hipError_t launch_fold(int32_t* replicas, int shift, int64_t n, int32_t* counters, hipStream_t stream) {

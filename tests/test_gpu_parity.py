@@ -173,6 +173,52 @@ def test_template_longer_than_64(sc, oracle, gpu):
             assert got[1] == exp[1] and np.array_equal(got[0], exp[0]), (flank, mm)
 
 
+def test_tally_mode_matches_atomics(sc, oracle, gpu, monkeypatch):
+    """The index-stream + LDS-histogram counting path (ScgCounters::unit_index, tally_kernel) against the
+    atomic path and the oracle: random cases, a hot barcode that crosses the 16-bit flush threshold
+    several times, and a library wide enough for two tally passes."""
+    import torch
+    rng = random.Random(4242)
+    monkeypatch.setenv("SCG_TALLY", "1")
+    for _ in range(25):
+        case = gen.random_single_case(rng, max_vlen=20)
+        try:
+            exp = oracle.count_single(case["reads"], case["template"], case["strand"], case["pool"], case["mismatches"], case["use_first"])
+        except Exception:
+            continue
+        got = run_single(sc, case, gpu)
+        assert got[1] == exp[1] and np.array_equal(got[0], exp[0]), (case, exp, got)
+    for _ in range(15):
+        case = gen.random_dual_case(rng, hazard_free=True)
+        exp = oracle.count_dual(case["reads1"], case["reads2"], case["template1"], case["reverse1"], case["mismatches1"], case["pool1"],
+                                case["template2"], case["reverse2"], case["mismatches2"], case["pool2"], case["randomized"], case["use_first"])
+        got = run_dual(sc, case, gpu)
+        assert got[1] == exp[1] and np.array_equal(got[0], exp[0]), (case, exp, got)
+    # hot bin: 150 000 copies of one construct (> 4 x 0x8000) plus a few others, two launches accumulate
+    template = "ACGTAC" + "-" * 10 + "TGCATG"
+    pool = gen.make_pool(rng, 40, 10, "ACGT")
+    reads = [gen.fill_template(template, [pool[7]])] * 150000 + [gen.fill_template(template, [rng.choice(pool)]) for _ in range(5000)]
+    seqs, offs = sc.upload_reads(reads, gpu)
+    with sc.Plan.single(template, 0, pool, 1, True) as plan:
+        plan.count(seqs, offs)
+        plan.count(seqs, offs)
+        counts, total = plan.read()
+    exp = oracle.count_single(reads, template, 0, pool, 1, True)
+    assert total == 2 * exp[1] and np.array_equal(counts, 2 * exp[0]) and counts[7] >= 300000
+    # two passes: 100 000 barcodes (> 80 K bins), fixed-length batch generated on the device
+    from screencounter_amd import synth
+    w = synth.workload(2, n_reads=300000)
+    dw = synth.DeviceWorkload(w, gpu)
+    dev = dw.generate(300000)
+    results = []
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SCG_TALLY", mode)
+        with dw.plan() as plan:
+            plan.count(dev, fixed_len=w.read_len, n_reads=300000)
+            results.append(plan.read())
+    assert results[0][1] == results[1][1] == 300000 and np.array_equal(results[0][0], results[1][0]) and results[0][0].sum() > 200000
+
+
 @pytest.mark.parametrize("seed", range(4))
 def test_random_barcodes_random(sc, oracle, gpu, seed, tmp_path):
     """countRandomBarcodes through the file-level entry point (the tally lives on the host), plain and
