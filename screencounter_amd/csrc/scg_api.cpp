@@ -483,7 +483,7 @@ ScgCounters plan_counters(const scg_plan* P) {
 // (small libraries are served by the replicas) and small enough for a few LDS passes, on batches
 // large enough to amortise the second kernel.  SCG_TALLY=0/1 overrides (measurement aid).
 bool use_tally(const scg_plan* P, int64_t n) {
-    if (P->kind == scg_plan::COMBO || P->diagnostics) return false;      // single barcodes and plain valid-pair counting
+    if (P->diagnostics) return false;      // the diagnostics kernels count several things per pair
     if (const char* e = std::getenv("SCG_TALLY")) { if (*e) return *e != '0'; }
     return P->n_counters >= 4096 && P->n_counters <= 4 * 80 * 1024 && n >= (int64_t(1) << 20);
 }
@@ -525,7 +525,20 @@ void launch_batch(scg_plan* P, const ScgReads& R, int64_t n, hipStream_t stream)
         cp.n_pool[0] = P->n_pool[0]; cp.n_pool[1] = P->n_pool[1];
         cp.max_mm = P->max_mm1; cp.use_first = P->use_first;
         cp.fwd = P->ht1.fwd; cp.rev = P->ht1.rev;
-        HIP_CHECK(scg::launch_combo(cp, P->ht1.t.len, R, n, plan_counters(P), P->error_flag.as<int32_t>(), stream));
+        ScgCounters counts = plan_counters(P);
+        const bool tally = use_tally(P, n) && R.max_len > 0 && R.max_len <= 320 && !std::getenv("SCG_FORCE_GENERAL");
+        if (tally) {
+            DevBuf& buf = P->unit_index[stream];
+            buf.ensure(static_cast<size_t>(n) * sizeof(int32_t));
+            counts.unit_index = buf.as<int32_t>();
+        }
+        HIP_CHECK(scg::launch_combo(cp, P->ht1.t.len, R, n, counts, P->error_flag.as<int32_t>(), stream));
+        if (tally) {
+            timer.stop();
+            HIP_CHECK(scg::launch_tally(counts.unit_index, n, P->counters, P->n_counters, stream));
+            P->total += n;
+            return;
+        }
     }
     timer.stop();
     fold_replicas(P, stream);

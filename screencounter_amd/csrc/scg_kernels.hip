@@ -530,7 +530,8 @@ __global__ __launch_bounds__(STAGE_BLOCK) __attribute__((amdgpu_num_sgpr(80))) v
             }
         }
     }
-    if (found) count_one(cells, (int64_t)best_id[0] * P.n_pool[1] + best_id[1]);
+    if (cells.unit_index) cells.unit_index[r0 + threadIdx.x] = found ? best_id[0] * P.n_pool[1] + best_id[1] : -1;     // tally mode
+    else if (found) count_one(cells, (int64_t)best_id[0] * P.n_pool[1] + best_id[1]);
 }
 
 // Staged counterpart of mate_search.
@@ -923,10 +924,21 @@ __global__ __launch_bounds__(TALLY_BLOCK) void tally_kernel(const int32_t* __res
             atomicAdd(&counters[lo + b], 0x8000);
         }
     };
-    for (int64_t q = q0 + threadIdx.x; q < q1; q += TALLY_BLOCK) {
-        if (4 * q + 3 < n) {
-            typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
-            const i32x4 v = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(unit_index) + q);
+    typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
+    const i32x4* quad = reinterpret_cast<const i32x4*>(unit_index);
+    const int64_t q_full = n / 4;                  // quads below this are complete
+    constexpr int U = 4;                           // loads in flight per lane: the stream is latency-bound otherwise
+    int64_t q = q0 + threadIdx.x;
+    for (; q + (U - 1) * TALLY_BLOCK < q1 && q + (U - 1) * TALLY_BLOCK < q_full; q += U * TALLY_BLOCK) {
+        i32x4 v[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) v[k] = __builtin_nontemporal_load(quad + q + k * TALLY_BLOCK);
+#pragma unroll
+        for (int k = 0; k < U; ++k) { add(v[k].x); add(v[k].y); add(v[k].z); add(v[k].w); }
+    }
+    for (; q < q1; q += TALLY_BLOCK) {
+        if (q < q_full) {
+            const i32x4 v = __builtin_nontemporal_load(quad + q);
             add(v.x); add(v.y); add(v.z); add(v.w);
         } else {
             for (int64_t i = 4 * q; i < n; ++i) add(unit_index[i]);
@@ -977,9 +989,17 @@ hipError_t launch_tally(const int32_t* unit_index, int64_t n, int32_t* counters,
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    int64_t slices = n / (int64_t(1) << 19);              // >= 512 K reads per workgroup: flush traffic stays small
+    // one workgroup (160 KB of LDS) per CU at a time: aim at one full wave of workgroups, each with
+    // >= 256 K reads so that the final flush (one atomic per non-empty bin and workgroup) stays small
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+    }
+    int64_t slices = n / (int64_t(1) << 18);
     if (slices < 1) slices = 1;
-    if (slices * passes > 512) slices = 512 / passes;
+    if (slices * passes > cus) slices = cus / passes > 0 ? cus / passes : 1;
     hipLaunchKernelGGL(tally_kernel, dim3((unsigned)slices, (unsigned)passes), dim3(TALLY_BLOCK), (size_t)bins * 2, stream,
                        unit_index, n, counters, n_counters, bins);
     return hipGetLastError();

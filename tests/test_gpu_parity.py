@@ -194,6 +194,14 @@ def test_tally_mode_matches_atomics(sc, oracle, gpu, monkeypatch):
                                 case["template2"], case["reverse2"], case["mismatches2"], case["pool2"], case["randomized"], case["use_first"])
         got = run_dual(sc, case, gpu)
         assert got[1] == exp[1] and np.array_equal(got[0], exp[0]), (case, exp, got)
+    for _ in range(15):
+        case = gen.random_combo_case(rng)
+        try:
+            exp = oracle.count_combo(case["reads"], case["template"], case["strand"], case["pool0"], case["pool1"], case["mismatches"], case["use_first"])
+        except Exception:
+            continue
+        got = run_combo(sc, case, gpu)
+        assert got[2] == exp[2] and np.array_equal(got[0], exp[0]) and np.array_equal(got[1], exp[1]), (case, exp, got)
     # hot bin: 150 000 copies of one construct (> 4 x 0x8000) plus a few others, two launches accumulate
     template = "ACGTAC" + "-" * 10 + "TGCATG"
     pool = gen.make_pool(rng, 40, 10, "ACGT")
