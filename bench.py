@@ -154,7 +154,10 @@ def main() -> None:
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "kernel": f"{w.entry}_staged_kernel", "avg_kernel_ms": round(avg_kernel_s * 1e3, 4), "launches": launches,
-                         "algorithmic_bytes_per_launch": algo_bytes, "traffic_source": traffic_source},
+                         "algorithmic_bytes_per_launch": algo_bytes, "traffic_source": traffic_source,
+                         # the whole step (counting kernel + tally / fold kernel [+ all-reduce]) against the same peak
+                         "step_achieved": round(algo_bytes * world / (elapsed / args.steps) / 1e9 / world, 2),
+                         "step_frac": round(algo_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 5)},
             "mapped_fraction": round(mapped / (n * world), 5),
         }
 

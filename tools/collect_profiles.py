@@ -24,11 +24,12 @@ n = line["config"]["reads_per_gpu"]
 algo = line["roofline"]["algorithmic_bytes_per_launch"]
 
 
-def counters(a, name):
+def counters(a, name, sub=None):
+    sub = sub or kernel_sub
     acc = defaultdict(list)
     for f in glob.glob(os.path.join(root, f"pmc_a{a}_{name}", "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
-            if kernel_sub in row["Kernel_Name"]:
+            if sub in row["Kernel_Name"]:
                 acc[(row["Counter_Name"], row["Dispatch_Id"])].append(float(row["Counter_Value"]))
     per = defaultdict(list)
     for (c, d), v in acc.items():
@@ -57,6 +58,13 @@ out["traffic"] = {"read_bytes_per_launch": read_bytes, "write_bytes_per_launch":
                   "total_bytes_per_launch": (read_bytes + write_bytes) if read_bytes is not None else None,
                   "bytes_per_read": ((read_bytes + write_bytes) / n) if read_bytes is not None else None,
                   "vs_algorithmic": ((read_bytes + write_bytes) / algo) if read_bytes is not None else None}
+# the tally kernel that follows the counting kernel in tally mode (ScgCounters::unit_index): its own HBM traffic
+tally = {}
+for name in ("FETCH_SIZE", "WRITE_SIZE"):
+    tally.update(counters(0, name, "tally_kernel"))
+if tally:
+    out["tally_kernel"] = {"FETCH_SIZE_KB": tally.get("FETCH_SIZE"), "WRITE_SIZE_KB": tally.get("WRITE_SIZE"),
+                           "note": "index stream read (4 B per read and pass, coalesced: FETCH_SIZE tallies it at x0.5) + flush atomics"}
 json.dump(out, open(f"profiles/{tag}_config{cfg}_traffic.json", "w"), indent=1)
 # the figure bench.py reports as roofline.traffic
 tj = "profiles/traffic.json"
