@@ -1,0 +1,62 @@
+"""BASELINE.json's full sizes, checked through properties that do not need an oracle run of that size:
+additivity over shards of the read stream, agreement of the two independent counting paths (memory-side
+atomics vs index stream + LDS tally), agreement of the two engines on a slice of the same stream, and
+reset idempotence.  (The bench re-checks a 50 M-read prefix against real kaori in the same run.)"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _count(plan, w, mates, a, b):
+    L = w.read_len
+    if w.entry == "dual":
+        plan.count_paired(mates[0][a * L: b * L], mates[1][a * L: b * L], fixed_len1=L, fixed_len2=L, n_pairs=b - a)
+    else:
+        plan.count(mates[0][a * L: b * L], fixed_len=L, n_reads=b - a)
+
+
+@pytest.mark.parametrize("config", [2, 3, 4])
+def test_full_size_properties(sc, gpu, monkeypatch, config):
+    import torch
+    from screencounter_amd import synth
+    free, _ = torch.cuda.mem_get_info()
+    w = synth.workload(config)                       # 100 M reads (50 M pairs for config 4) x 150 bp
+    need = w.n_reads * w.read_len * (2 if w.entry == "dual" else 1)
+    if free < need * 1.3:
+        pytest.skip("not enough free HBM for the full-size stream")
+    dw = synth.DeviceWorkload(w, gpu)
+    mates = [dw.generate(w.n_reads, mate=0)]
+    if w.entry == "dual":
+        mates.append(dw.generate(w.n_reads, mate=1))
+    n = w.n_reads
+    results = {}
+    for mode in ("1", "0"):                          # tally path, atomic path
+        monkeypatch.setenv("SCG_TALLY", mode)
+        with dw.plan() as plan:
+            _count(plan, w, mates, 0, n)
+            whole, total = plan.read()
+            assert total == n
+            plan.reset()
+            zero, t0 = plan.read()
+            assert t0 == 0 and not zero.any()                        # reset really clears
+            cut = (n // 3) | 1                                       # odd, unaligned shard boundary
+            _count(plan, w, mates, 0, cut)
+            _count(plan, w, mates, cut, n)
+            parts, total2 = plan.read()
+            assert total2 == n and np.array_equal(parts, whole)      # counts are additive over shards
+        results[mode] = whole
+    assert np.array_equal(results["0"], results["1"])               # two independent counting paths agree
+    mapped = int(results["1"].astype(np.int64).sum())
+    assert 0.80 * n < mapped <= n                                    # 5 % junk + reads lost to > budget errors
+    # the byte-wise general engine on a slice of the same stream
+    m = 2_000_000
+    with dw.plan() as plan:
+        _count(plan, w, mates, n - m, n)
+        staged, _ = plan.read()
+    monkeypatch.setenv("SCG_FORCE_GENERAL", "1")
+    with dw.plan() as plan:
+        _count(plan, w, mates, n - m, n)
+        general, _ = plan.read()
+    monkeypatch.delenv("SCG_FORCE_GENERAL")
+    assert np.array_equal(staged, general)
