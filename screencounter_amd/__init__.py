@@ -12,7 +12,7 @@ from ._lib import ScgError, load  # noqa: F401
 from .api import (  # noqa: F401
     count_single_barcodes, count_combo_barcodes_single, count_dual_barcodes, count_combo_barcodes_paired, count_dual_barcodes_single_end, count_random_barcodes, match_barcodes, parse_fastq,
     countSingleBarcodes, countComboBarcodes, countDualBarcodes, countPairedComboBarcodes, countDualBarcodesSingleEnd, countRandomBarcodes, matchBarcodes,
-    matrixOfSingleBarcodes, matrixOfComboBarcodes, matrixOfDualBarcodes, matrixOfPairedComboBarcodes, matrixOfDualBarcodesSingleEnd, combineComboCounts, parseBarcodeTemplate,
+    matrixOfSingleBarcodes, matrixOfComboBarcodes, matrixOfDualBarcodes, matrixOfPairedComboBarcodes, matrixOfDualBarcodesSingleEnd, matrixOfRandomBarcodes, combineComboCounts, parseBarcodeTemplate,
 )
 from .engine import Plan, combo_compact, upload_reads  # noqa: F401
 

@@ -148,6 +148,11 @@ def test_matrix_of_files_scheduled_over_devices(sc, oracle, gpu, tmp_path):
     seq = sc.matrixOfDualBarcodes(pairs[:3], {"a": pool, "b": pool}, template=template, substitutions=1, devices=[0])
     par = sc.matrixOfDualBarcodes(pairs[:3], {"a": pool, "b": pool}, template=template, substitutions=1, devices=[0, 0, 0])
     assert np.array_equal(seq.counts, par.counts) and seq.col_data == par.col_data
+    rnd = sc.matrixOfRandomBarcodes(files[:3], template=template, substitutions=1, devices=[0], jobs_per_device=2)
+    one = [sc.countRandomBarcodes(f, template, substitutions=1) for f in files[:3]]
+    assert rnd.row_data["sequences"] == sorted(set().union(*[o["sequences"] for o in one])) and rnd.col_data["nreads"] == nreads[:3]
+    for c, o in enumerate(one):
+        assert int(rnd.counts[:, c].sum()) == int(o["counts"].sum())
     seq = sc.matrixOfPairedComboBarcodes(pairs[:3], choices=[pool, pool], template=template, substitutions=1, devices=[0])
     par = sc.matrixOfPairedComboBarcodes(pairs[:3], choices=[pool, pool], template=template, substitutions=1, devices=[0, 0])
     assert np.array_equal(seq.counts, par.counts) and seq.row_data == par.row_data and seq.col_data == par.col_data
