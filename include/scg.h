@@ -100,7 +100,8 @@ int scg_count_dual_barcodes(const char* path1, const char* constant1, int revers
  * one read; pools[r][c] over the regions r spells valid combination c.  Replaces
  * src/count_dual_barcodes_single_end.cpp:53-87, non-diagnostic branch (:27-34, kaori::DualBarcodesSingleEnd).
  * pools: n_regions arrays of n_pools[r] strings; counts_out: n_pools[0] entries.  This engine handles 1 or 2
- * regions with at most 64 bases in total and diagnostics = 0 (SCG_ERR_UNSUPPORTED otherwise). */
+ * regions with at most 64 bases in total.  diagnostics must be 0 here: the include.invalid=TRUE branch returns
+ * more outputs and is scg_count_dual_barcodes_single_end_diagnostics below. */
 int scg_count_dual_barcodes_single_end(const char* path, const char* constant,
                                        const char* const* const* pools, const int32_t* n_pools, int32_t n_regions,
                                        int strand, int mismatches, int use_first, int diagnostics, int nthreads,
@@ -113,6 +114,17 @@ int scg_count_dual_barcodes_single_end(const char* path, const char* constant,
 int scg_count_random_barcodes(const char* path, const char* constant, int strand, int mismatches, int use_first,
                               int nthreads, char** sequences_out, int32_t** freq_out, int64_t* k_out,
                               int32_t* length_out, int32_t* total_out, char* err, size_t errcap);
+
+/* countDualBarcodesSingleEnd(include.invalid=TRUE).  Replaces the diagnostics branch of
+ * src/count_dual_barcodes_single_end.cpp:36-50 (kaori::DualBarcodesSingleEndWithDiagnostics<N, 2>): exactly two
+ * variable regions; reads without a valid combination whose two barcodes are both known are reported as a
+ * malloc'd 2 x K matrix of 0-based (pool 1 index, pool 2 index) columns sorted by (first, second) with K
+ * frequencies (release with scg_free).  Mirrors List(counts, List(indices, freq), total). */
+int scg_count_dual_barcodes_single_end_diagnostics(const char* path, const char* constant,
+                                                   const char* const* const* pools, const int32_t* n_pools, int32_t n_regions,
+                                                   int strand, int mismatches, int use_first, int nthreads,
+                                                   int32_t* counts_out, int32_t** invalid_indices_out, int32_t** invalid_freq_out,
+                                                   int64_t* k_out, int32_t* total_out, char* err, size_t errcap);
 
 /* countPairedComboBarcodes hot path: one variable region per mate, every
  * (pool1, pool2) combination counts.  Replaces src/count_combo_barcodes_paired.cpp:57-95

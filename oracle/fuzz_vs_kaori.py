@@ -198,6 +198,26 @@ def fuzz_dual_single_end(rng, ora, ref, tmpdir, it):
     return "ok"
 
 
+def fuzz_dual_single_end_diag(rng, ora, ref, tmpdir, it):
+    from tests import gen
+    c = gen.random_dual_single_end_case(rng, wide=rng.random() < 0.3, diag=True)
+    fq = os.path.join(tmpdir, f"x{it}.fastq")
+    write_fastq(fq, c["reads"])
+    try:
+        exp = ref.count_dual_single_end_diag(fq, c["template"], c["strand"], c["pools"], c["mismatches"], c["use_first"], 1)
+    except OracleError:
+        try:
+            ora.count_dual_single_end_diag(c["reads"], c["template"], c["strand"], c["pools"], c["mismatches"], c["use_first"])
+        except OracleError:
+            return "both-error"
+        raise
+    got = ora.count_dual_single_end_diag(c["reads"], c["template"], c["strand"], c["pools"], c["mismatches"], c["use_first"])
+    for key in exp:
+        if not np.array_equal(np.asarray(exp[key]), np.asarray(got[key])):
+            raise AssertionError(f"dual-single-end-diag mismatch in {key}: {c}\nexp={exp}\ngot={got}")
+    return "ok"
+
+
 def fuzz_random(rng, ora, ref, tmpdir, it):
     from tests import gen
     c = gen.random_random_barcode_case(rng)
@@ -259,6 +279,7 @@ def main():
                              ("combo-paired", lambda: fuzz_combo_paired(rng, ora, ref, tmp, it)),
                              ("dual-single-end", lambda: fuzz_dual_single_end(rng, ora, ref, tmp, it)),
                              ("random", lambda: fuzz_random(rng, ora, ref, tmp, it)),
+                             ("dual-single-end-diag", lambda: fuzz_dual_single_end_diag(rng, ora, ref, tmp, it)),
                              ("match", lambda: fuzz_match(rng, ora, ref))):
                 res = fn()
                 tally[f"{name}:{res}"] = tally.get(f"{name}:{res}", 0) + 1

@@ -70,6 +70,11 @@ def run_case(ref: KaoriRef, case: dict, tmp: str) -> dict:
                                     case["randomized"], case["use_first"], 1)
             out["expect"] = {"counts": d["counts"].tolist(), "indices": d["indices"].tolist(), "freq": d["freq"].tolist(),
                              "total": d["total"], "barcode1_only": d["barcode1_only"], "barcode2_only": d["barcode2_only"]}
+        elif k == "dual_single_end_diag":
+            fq = os.path.join(tmp, "x.fastq")
+            write_fastq(fq, case["reads"])
+            d = ref.count_dual_single_end_diag(fq, case["template"], case["strand"], case["pools"], case["mismatches"], case["use_first"], 1)
+            out["expect"] = {"counts": d["counts"].tolist(), "indices": d["indices"].tolist(), "freq": d["freq"].tolist(), "total": d["total"]}
         elif k == "random":
             fq = os.path.join(tmp, "r.fastq")
             write_fastq(fq, case["reads"])
@@ -262,6 +267,10 @@ def main() -> None:
             rnd.append(run_case(ref, gen.random_single_case(rng, max_vlen=64, sizes=small, min_vlen=33), tmp))
         for _ in range(40):
             rnd.append(run_case(ref, gen.random_random_barcode_case(rng, sizes=small), tmp))
+        for i in range(40):
+            c = gen.random_dual_single_end_case(rng, sizes=small, wide=(i % 3 == 0), diag=True)
+            c["kind"] = "dual_single_end_diag"
+            rnd.append(run_case(ref, c, tmp))
         with open(os.path.join(OUT, "kaori_random.json"), "w") as f:
             json.dump({"generator": "oracle/gen_golden.py", "reference": "kaori v1.1.1 (screenCounter 1.5.1)", "seed": 20261003, "cases": rnd}, f)
 

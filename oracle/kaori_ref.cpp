@@ -247,6 +247,60 @@ int kref_count_dual_diag(const char* path1, const char* tmpl1, int reverse1, int
     return 0;
 }
 
+/* src/count_dual_barcodes_single_end.cpp:36-50 (include.invalid=TRUE): counts, sorted combinations (2 x K,
+ * 0-based) with frequencies, total. */
+int kref_count_dual_single_end_diag(const char* path, const char* tmpl, int strand,
+                                    const char* const* const* pools, const int* n_pools, int n_regions,
+                                    int mm, int use_first, int nthreads, int32_t* counts,
+                                    int32_t** idx_out, int32_t** freq_out, int64_t* k_out, int32_t* total,
+                                    char* err, size_t errcap) {
+    try {
+        byteme::SomeFileReader reader(path);
+        std::vector<kaori::BarcodePool> ptr_pools;
+        for (int r = 0; r < n_regions; ++r) ptr_pools.push_back(make_pool(pools[r], n_pools[r]));
+        std::string constant(tmpl);
+        std::vector<std::array<int, 2> > sorted;
+        auto run = [&](auto tag) {
+            constexpr size_t N = decltype(tag)::value;
+            typename kaori::DualBarcodesSingleEnd<N>::Options options;
+            options.strand = to_strand(strand);
+            options.max_mismatches = mm;
+            options.use_first = use_first != 0;
+            kaori::DualBarcodesSingleEndWithDiagnostics<N, 2> handler(constant.c_str(), constant.size(), ptr_pools, options);
+            kaori::process_single_end_data(&reader, handler, nthreads);
+            handler.sort();
+            const auto& c = handler.get_counts();
+            std::copy(c.begin(), c.end(), counts);
+            sorted = handler.get_combinations();
+            *total = handler.get_total();
+        };
+        size_t len = constant.size();
+        if (len <= 32) run(std::integral_constant<size_t, 32>());
+        else if (len <= 64) run(std::integral_constant<size_t, 64>());
+        else if (len <= 128) run(std::integral_constant<size_t, 128>());
+        else if (len <= 256) run(std::integral_constant<size_t, 256>());
+        else throw std::runtime_error("lacking compile-time support for constant regions longer than 256 bp");
+        std::vector<int32_t> idx, freq;
+        for (size_t i = 0; i < sorted.size(); ++i) {
+            if (i && sorted[i] == sorted[i - 1]) {
+                ++freq.back();
+            } else {
+                idx.push_back(sorted[i][0]);
+                idx.push_back(sorted[i][1]);
+                freq.push_back(1);
+            }
+        }
+        *k_out = static_cast<int64_t>(freq.size());
+        *idx_out = static_cast<int32_t*>(std::malloc(sizeof(int32_t) * (idx.size() + 1)));
+        *freq_out = static_cast<int32_t*>(std::malloc(sizeof(int32_t) * (freq.size() + 1)));
+        std::copy(idx.begin(), idx.end(), *idx_out);
+        std::copy(freq.begin(), freq.end(), *freq_out);
+    } catch (std::exception& e) {
+        return set_err(err, errcap, e.what());
+    }
+    return 0;
+}
+
 /* src/count_random_barcodes.cpp:41-62: *seq_out = K strings of *len_out chars, NUL-terminated, sorted
  * byte-wise (the reference's unordered_map order is unspecified; its R caller sorts); free with kref_free. */
 int kref_count_random(const char* path, const char* tmpl, int strand, int mm, int use_first, int nthreads,

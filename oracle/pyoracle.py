@@ -204,6 +204,29 @@ class Oracle:
         return dict(counts=counts[:len(pool1)].copy(), indices=tuples[:2 * k].reshape(k, 2).T.copy(), freq=freq[:k].copy(),
                     total=int(total.value), barcode1_only=int(b1.value), barcode2_only=int(b2.value))
 
+    def count_dual_single_end_diag(self, reads, template: str, strand: int, pools: Sequence[Sequence[str]], mismatches: int, use_first: bool):
+        """countDualBarcodesSingleEnd(include.invalid=TRUE) -> dict(counts, indices int32[2,K], freq, total)"""
+        s, o = _as_batch(reads)
+        n = len(o) - 1
+        nch = len(pools[0]) if pools else 0
+        counts = np.zeros(max(nch, 1), dtype=np.int32)
+        tuples = np.zeros(2 * max(n, 1), dtype=np.int32)
+        nt = C.c_int64(0)
+        total = C.c_int32(0)
+        err = C.create_string_buffer(_ERRCAP)
+        rows, sizes, _keep = _cstr_matrix(pools)
+        sp, _a = _ptr(s, C.c_char)
+        rc = self.L.scgo_count_dual_single_end_diag(sp, o.ctypes.data_as(C.POINTER(C.c_uint64)), C.c_int64(n),
+                                                    template.encode(), C.c_int(len(template)), C.c_int(strand),
+                                                    rows, sizes, C.c_int(len(pools)), C.c_int(mismatches), C.c_int(int(use_first)),
+                                                    counts.ctypes.data_as(C.POINTER(C.c_int32)), tuples.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                    C.byref(nt), C.byref(total), err, C.c_size_t(_ERRCAP))
+        if rc:
+            raise OracleError(err.value.decode())
+        freq = np.zeros(max(int(nt.value), 1), dtype=np.int32)
+        k = self.L.scgo_combo_rle(tuples.ctypes.data_as(C.POINTER(C.c_int32)), nt, freq.ctypes.data_as(C.POINTER(C.c_int32)))
+        return dict(counts=counts[:nch].copy(), indices=tuples[:2 * k].reshape(k, 2).T.copy(), freq=freq[:k].copy(), total=int(total.value))
+
     def count_random(self, reads, template: str, strand: int, mismatches: int, use_first: bool):
         """countRandomBarcodes -> (dict sequence -> count, total).  The C restatement decides the window of
         every read (scgo_random_hits); the strings are cut here exactly as RandomBarcodeSingleEnd.hpp:86-115 does."""
@@ -414,6 +437,30 @@ class KaoriRef:
             self.L.kref_free(freq_p)
         return dict(counts=counts[:len(pool1)].copy(), indices=idx, freq=freq, total=int(total.value),
                     barcode1_only=int(b1.value), barcode2_only=int(b2.value))
+
+    def count_dual_single_end_diag(self, fastq: str, template: str, strand: int, pools: Sequence[Sequence[str]], mismatches: int,
+                                   use_first: bool, nthreads: int = 1):
+        nch = len(pools[0]) if pools else 0
+        counts = np.zeros(max(nch, 1), dtype=np.int32)
+        idx_p = C.POINTER(C.c_int32)()
+        freq_p = C.POINTER(C.c_int32)()
+        k, total = C.c_int64(0), C.c_int32(0)
+        err = C.create_string_buffer(_ERRCAP)
+        rows, sizes, _keep = _cstr_matrix(pools)
+        rc = self.L.kref_count_dual_single_end_diag(fastq.encode(), template.encode(), C.c_int(strand), rows, sizes, C.c_int(len(pools)),
+                                                    C.c_int(mismatches), C.c_int(int(use_first)), C.c_int(nthreads),
+                                                    counts.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(idx_p), C.byref(freq_p), C.byref(k),
+                                                    C.byref(total), err, C.c_size_t(_ERRCAP))
+        if rc:
+            raise OracleError(err.value.decode())
+        K = int(k.value)
+        try:
+            idx = np.array([idx_p[i] for i in range(2 * K)], dtype=np.int32).reshape(K, 2).T.copy()
+            freq = np.array([freq_p[i] for i in range(K)], dtype=np.int32)
+        finally:
+            self.L.kref_free(idx_p)
+            self.L.kref_free(freq_p)
+        return dict(counts=counts[:nch].copy(), indices=idx, freq=freq, total=int(total.value))
 
     def count_random(self, fastq: str, template: str, strand: int, mismatches: int, use_first: bool, nthreads: int = 1):
         seq_p = C.c_void_p()

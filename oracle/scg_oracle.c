@@ -297,11 +297,15 @@ static int pool_to_sets(const char *const *pool, int n, int reverse, int8_t **ou
     return 0;
 }
 
+static int lib_init_opt(lib_t *L, const char *const *pool, int n, int reverse, int check_dups, errbuf *e);
 static int lib_init(lib_t *L, const char *const *pool, int n, int reverse, errbuf *e) {
+    return lib_init_opt(L, pool, n, reverse, 1, e);
+}
+static int lib_init_opt(lib_t *L, const char *const *pool, int n, int reverse, int check_dups, errbuf *e) {
     int8_t *sets; int len;
     int rc = pool_to_sets(pool, n, reverse, &sets, &len, e);
     if (rc) { L->planes = NULL; return rc; }
-    rc = lib_from_sets(L, sets, n, len, e);
+    rc = lib_from_sets_opt(L, sets, n, len, check_dups, e);
     free(sets);
     if (rc) lib_free(L);
     return rc;
@@ -481,13 +485,13 @@ int scgo_count_single(const char *seqs, const uint64_t *offsets, int64_t n_reads
  * ---------------------------------------------------------------------------------------- */
 #define SCGO_V 2
 
-static int combo_find(const tmpl_t *T, const lib_t *libs /* [V], in scan order for this strand */,
-                      const char *read, int p, int reverse, int c, int max_mm, int32_t *temp, int *total_out) {
+static int combo_find_policy(const tmpl_t *T, const lib_t *libs /* [V], in scan order for this strand */,
+                             const char *read, int p, int reverse, int c, int max_mm, int keep_first, int32_t *temp, int *total_out) {
     int obs = c;
     for (int r = 0; r < SCGO_V; ++r) {
         const char *q = read + p + (reverse ? T->rstart[r] : T->fstart[r]);
         int idx, d;
-        lib_match(&libs[r], q, max_mm - obs, &idx, &d);          /* :168 */
+        lib_match_policy(&libs[r], q, max_mm - obs, keep_first, &idx, &d);          /* :168 */
         if (idx < 0) return 0;
         obs += d;
         if (obs > max_mm) return 0;                               /* :173-176 */
@@ -495,6 +499,11 @@ static int combo_find(const tmpl_t *T, const lib_t *libs /* [V], in scan order f
     }
     *total_out = obs;
     return 1;
+}
+
+static int combo_find(const tmpl_t *T, const lib_t *libs, const char *read, int p, int reverse, int c, int max_mm,
+                      int32_t *temp, int *total_out) {
+    return combo_find_policy(T, libs, read, p, reverse, c, max_mm, 0, temp, total_out);
 }
 
 int scgo_count_combo(const char *seqs, const uint64_t *offsets, int64_t n_reads,
@@ -999,6 +1008,114 @@ int scgo_count_dual_single_end(const char *seqs, const uint64_t *offsets, int64_
     *total = tot;
     free(buffer);
     lib_free(&F); lib_free(&R);
+    return 0;
+}
+
+/* countDualBarcodesSingleEnd(include.invalid=TRUE): src/count_dual_barcodes_single_end.cpp:36-50 over
+ * kaori::DualBarcodesSingleEndWithDiagnostics<N, 2> (handlers/DualBarcodesSingleEndWithDiagnostics.hpp:35-119):
+ * a read without a valid combination is handed to CombinatorialBarcodesSingleEnd<N, 2> built on the same two
+ * pools with DuplicateAction::FIRST; its hits are reported as (pool index 1, pool index 2) tuples in read order
+ * (capacity 2 * n_reads; the caller sorts / run-length encodes with scgo_combo_rle). */
+int scgo_count_dual_single_end_diag(const char *seqs, const uint64_t *offsets, int64_t n_reads,
+                                    const char *tmpl, int tmpl_len, int strand,
+                                    const char *const *const *pools, const int *n_pools, int n_regions,
+                                    int max_mm, int use_first,
+                                    int32_t *counts, int32_t *tuples, int64_t *n_tuples, int32_t *total,
+                                    char *err, size_t errcap) {
+    errbuf e = {err, errcap};
+    /* the valid-combination handler first: its constructor runs first and owns every check it makes */
+    {
+        int32_t t0 = 0;
+        int32_t *scratch = (int32_t *)calloc((size_t)((n_regions > 0 && n_pools[0] > 0) ? n_pools[0] : 1), sizeof(int32_t));
+        uint64_t zero[1] = {0};
+        int rc = scgo_count_dual_single_end("", zero, 0, tmpl, tmpl_len, strand, pools, n_pools, n_regions, max_mm, use_first, scratch, &t0, err, errcap);
+        free(scratch);
+        if (rc) return rc;
+    }
+    tmpl_t T;
+    if (tmpl_init(&T, tmpl, tmpl_len, strand, &e)) return 1;
+    /* CombinatorialBarcodesSingleEnd<N, 2> ctor (handlers/CombinatorialBarcodesSingleEnd.hpp:78-117) */
+    if (T.nreg != SCGO_V) return fail(&e, "expected %d variable regions in the constant template", SCGO_V);
+    if (n_regions != SCGO_V) return fail(&e, "length of 'barcode_pools' should equal the number of variable regions");
+    int clen = 0, plen[SCGO_V];
+    for (int v = 0; v < SCGO_V; ++v) { plen[v] = T.fend[v] - T.fstart[v]; clen += plen[v]; }
+    int n_choices = n_pools[0];
+    char **combined = (char **)malloc(sizeof(char *) * (size_t)(n_choices + 1));
+    for (int c = 0; c < n_choices; ++c) {
+        combined[c] = (char *)malloc((size_t)clen + 1);
+        memcpy(combined[c], pools[0][c], plen[0]);
+        memcpy(combined[c] + plen[0], pools[1][c], plen[1]);
+        combined[c][clen] = 0;
+    }
+    lib_t DF = {0}, DR = {0}, F[SCGO_V], R[SCGO_V];
+    memset(F, 0, sizeof(F)); memset(R, 0, sizeof(R));
+    int rc = 0;
+    if (T.fwd) rc = lib_init(&DF, (const char *const *)combined, n_choices, 0, &e);
+    if (!rc && T.rev) rc = lib_init(&DR, (const char *const *)combined, n_choices, 1, &e);
+    for (int c = 0; c < n_choices; ++c) free(combined[c]);
+    free(combined);
+    if (!rc && T.fwd) for (int v = 0; v < SCGO_V && !rc; ++v) rc = lib_init_opt(&F[v], pools[v], n_pools[v], 0, 0, &e);
+    if (!rc && T.rev) for (int v = 0; v < SCGO_V && !rc; ++v) rc = lib_init_opt(&R[v], pools[SCGO_V - 1 - v], n_pools[SCGO_V - 1 - v], 1, 0, &e);
+    if (rc) { lib_free(&DF); lib_free(&DR); for (int v = 0; v < SCGO_V; ++v) { lib_free(&F[v]); lib_free(&R[v]); } return 1; }
+
+    char *buffer = (char *)malloc((size_t)clen + 1);
+    memset(counts, 0, sizeof(int32_t) * (size_t)n_choices);
+    int32_t tot = 0;
+    int64_t nt = 0;
+    for (int64_t r = 0; r < n_reads; ++r) {
+        const char *read = seqs + offsets[r];
+        int n = (int)(offsets[r + 1] - offsets[r]);
+        ++tot;
+        /* DualBarcodesSingleEnd::process (as in scgo_count_dual_single_end) */
+        int found = 0, index = -1, best = max_mm + 1;
+        for (int p = 0; p + T.len <= n; ++p) {
+            int stop = 0;
+            for (int s = 0; s < 2 && !stop; ++s) {
+                if (s == 0 ? !T.fwd : !T.rev) continue;
+                int c = const_mm(&T, read, p, s);
+                if (c > max_mm) continue;
+                int off = 0;
+                for (int v = 0; v < T.nreg; ++v) {
+                    int a = s ? T.rstart[v] : T.fstart[v], b = s ? T.rend[v] : T.fend[v];
+                    memcpy(buffer + off, read + p + a, (size_t)(b - a));
+                    off += b - a;
+                }
+                int idx, d;
+                lib_match(s ? &DR : &DF, buffer, max_mm - c, &idx, &d);
+                if (idx < 0) continue;
+                int tmm = c + d;
+                if (use_first) { found = 1; index = idx; stop = 1; }
+                else if (tmm == best) { if (index != idx) found = 0; }
+                else if (tmm < best) { found = 1; best = tmm; index = idx; }
+            }
+            if (stop) break;
+        }
+        if (found) { ++counts[index]; continue; }
+        /* CombinatorialBarcodesSingleEnd::process with DuplicateAction::FIRST (as in scgo_count_combo) */
+        int cfound = 0, cbest = max_mm + 1;
+        int32_t best_id[SCGO_V] = {0, 0}, temp[SCGO_V];
+        for (int p = 0; p + T.len <= n; ++p) {
+            int stop = 0;
+            for (int s = 0; s < 2 && !stop; ++s) {
+                if (s == 0 ? !T.fwd : !T.rev) continue;
+                int c = const_mm(&T, read, p, s);
+                if (c > max_mm) continue;
+                int tmm;
+                if (!combo_find_policy(&T, s ? R : F, read, p, s, c, max_mm, 1, temp, &tmm)) continue;
+                if (use_first) { cfound = 1; memcpy(best_id, temp, sizeof(temp)); stop = 1; }
+                else if (tmm <= cbest) {
+                    if (tmm == cbest) { if (memcmp(best_id, temp, sizeof(temp)) != 0) cfound = 0; }
+                    else { cfound = 1; cbest = tmm; memcpy(best_id, temp, sizeof(temp)); }
+                }
+            }
+            if (stop) break;
+        }
+        if (cfound) { tuples[2 * nt] = best_id[0]; tuples[2 * nt + 1] = best_id[1]; ++nt; }
+    }
+    *n_tuples = nt; *total = tot;
+    free(buffer);
+    lib_free(&DF); lib_free(&DR);
+    for (int v = 0; v < SCGO_V; ++v) { lib_free(&F[v]); lib_free(&R[v]); }
     return 0;
 }
 

@@ -74,6 +74,9 @@ SIGNATURES = {
                                             C.POINTER(i32_p), i64_p, i32_p, i32_p, C.c_char_p, C.c_size_t]),
     "scg_count_dual_barcodes_single_end": (C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(c_str_p), i32_p, C.c_int32,
                                                      C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, i32_p, i32_p, C.c_char_p, C.c_size_t]),
+    "scg_count_dual_barcodes_single_end_diagnostics": (C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(c_str_p), i32_p, C.c_int32,
+                                                                 C.c_int, C.c_int, C.c_int, C.c_int, i32_p, C.POINTER(i32_p), C.POINTER(i32_p),
+                                                                 i64_p, i32_p, C.c_char_p, C.c_size_t]),
     "scg_plan_dual_single_end": (C.c_int, [C.POINTER(C.c_void_p), C.c_char_p, C.c_int, C.POINTER(c_str_p), i32_p, C.c_int32,
                                            C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_size_t]),
     "scg_count_combo_barcodes_paired": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_int, c_str_p, C.c_int32,

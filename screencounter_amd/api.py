@@ -141,13 +141,29 @@ def count_random_barcodes(path: str, constant: str, strand: int, mismatches: int
 
 def count_dual_barcodes_single_end(path: str, constant: str, pools: Sequence[Sequence[str]], strand: int, mismatches: int,
                                    use_first: bool, diagnostics: bool = False, nthreads: int = 1):
-    """src/count_dual_barcodes_single_end.cpp:53-87 (non-diagnostic branch) -> (counts int32[n combinations], total)."""
+    """src/count_dual_barcodes_single_end.cpp:53-87 -> (counts int32[n combinations], total), or with diagnostics=True
+    (counts, (indices int32[2, K] 0-based, freq), total) as in its include.invalid=TRUE branch."""
     L = _lib.load()
     nch = len(pools[0]) if pools else 0
     counts = np.zeros(max(nch, 1), dtype=np.int32)
     total = C.c_int32(0)
     err = errbuf()
     rows, sizes, _keep = _lib.cstr_matrix(pools)
+    if diagnostics:
+        idx_p, freq_p = _lib.i32_p(), _lib.i32_p()
+        k = C.c_int64(0)
+        check(L.scg_count_dual_barcodes_single_end_diagnostics(os.fspath(path).encode(), constant.encode(), rows, sizes, len(pools),
+                                                               int(strand), int(mismatches), int(bool(use_first)), int(nthreads),
+                                                               counts.ctypes.data_as(_lib.i32_p), C.byref(idx_p), C.byref(freq_p), C.byref(k),
+                                                               C.byref(total), err, _lib.ERRCAP), err)
+        K = int(k.value)
+        try:
+            idx = np.ctypeslib.as_array(idx_p, shape=(max(2 * K, 1),))[:2 * K].reshape(K, 2).T.copy()
+            freq = np.ctypeslib.as_array(freq_p, shape=(max(K, 1),))[:K].copy()
+        finally:
+            L.scg_free(idx_p)
+            L.scg_free(freq_p)
+        return counts[:nch].copy(), (idx.astype(np.int32), freq.astype(np.int32)), int(total.value)
     check(L.scg_count_dual_barcodes_single_end(os.fspath(path).encode(), constant.encode(), rows, sizes, len(pools),
                                                int(strand), int(mismatches), int(bool(use_first)), int(bool(diagnostics)), int(nthreads),
                                                counts.ctypes.data_as(_lib.i32_p), C.byref(total), err, _lib.ERRCAP), err)
@@ -459,9 +475,16 @@ def countDualBarcodesSingleEnd(fastq: str, choices, template: str, substitutions
     else:
         cols = [list(v) for v in choices]
         names = ["first", "second", "third", "fourth"][:len(cols)]
-    counts, total = count_dual_barcodes_single_end(fastq, re.sub("[nN]", "-", template), cols, _strand_code(strand),
-                                                   substitutions, not find_best, include_invalid, num_threads)
-    return DualCounts(choices=dict(zip(names, cols)), counts=counts, npairs=total)
+    out = count_dual_barcodes_single_end(fastq, re.sub("[nN]", "-", template), cols, _strand_code(strand),
+                                         substitutions, not find_best, include_invalid, num_threads)
+    if not include_invalid:
+        counts, total = out
+        return DualCounts(choices=dict(zip(names, cols)), counts=counts, npairs=total)
+    counts, (idx, freq), total = out                              # R/countDualBarcodesSingleEnd.R:114-121
+    inv = [[cols[r][i] for i in idx[r]] for r in range(2)]
+    return DualCounts(choices={names[r]: cols[r] + inv[r] for r in range(2)},
+                      counts=np.concatenate([counts, freq]).astype(np.int32), npairs=total,
+                      valid=[True] * len(cols[0]) + [False] * len(inv[0]), invalid_pair=int(freq.sum()))
 
 
 def matrixOfDualBarcodesSingleEnd(files: Sequence[str], choices, withDimnames: bool = True, devices=None, jobs_per_device: int = 1, **kwargs) -> CountMatrix:

@@ -157,7 +157,7 @@ struct DevPairTable {
 // Plans
 // -------------------------------------------------------------------------------------------------
 struct scg_plan {
-    enum Kind { SINGLE, COMBO, DUAL } kind = SINGLE;
+    enum Kind { SINGLE, COMBO, DUAL, DUAL_SE_DIAG } kind = SINGLE;   // DUAL_SE_DIAG: single-end dual barcodes, include.invalid=TRUE
     int device = 0;
 
     // host-compiled pieces (valid before any device work)
@@ -177,6 +177,8 @@ struct scg_plan {
     DevPairTable pairs;
     DevBuf own_counters;
     DevBuf replicas;     // privatised counter copies (ScgCounters); empty when n_counters is large
+    scg::HostIndex htab_combined;   // DUAL_SE_DIAG: wide index of the concatenated combinations (tab[0..1] = the per-region pools)
+    DevIndex tab_combined;
     std::map<hipStream_t, DevBuf> unit_index;   // tally mode: barcode index per read of the batch in flight on each stream (ScgCounters::unit_index)
     int replica_shift = 0;   // log2(replicas)
     DevBuf error_flag;   // set by a staged kernel that met a read longer than the declared maximum
@@ -203,6 +205,7 @@ struct scg_plan {
         }
         tab[0].upload(htab[0]);
         if (kind != SINGLE) tab[1].upload(htab[1]);
+        if (kind == DUAL_SE_DIAG) { tab_combined.upload(htab_combined); htab_combined = scg::HostIndex(); }
         if (kind == DUAL) pairs.upload(hpairs);
         own_counters.alloc(static_cast<size_t>(std::max<int64_t>(n_counters, 1)) * sizeof(int32_t));   // (plans without counters: random barcodes)
         counters = own_counters.as<int32_t>();
@@ -425,6 +428,38 @@ std::unique_ptr<scg_plan> compile_dual(const char* constant1, int reverse1, int 
     return P;
 }
 
+// countDualBarcodesSingleEnd(include.invalid=TRUE): DualBarcodesSingleEndWithDiagnostics<N, 2>
+// (handlers/DualBarcodesSingleEndWithDiagnostics.hpp:35-60) = the valid-combination handler plus
+// CombinatorialBarcodesSingleEnd<N, 2> over the same pools with DuplicateAction::FIRST.
+std::unique_ptr<scg_plan> compile_dual_single_end_diag(const char* constant, int strand, const char* const* const* pools, const int32_t* n_pools,
+                                                       int32_t n_regions, int mismatches, int use_first) {
+    auto P = compile_dual_single_end(constant, strand, pools, n_pools, n_regions, mismatches, use_first);   // its constructor runs first
+    const ScgTemplate& t = P->ht1.t;
+    if (t.nreg != 2) throw Error(SCG_ERR_INVALID, "expected 2 variable regions in the constant template");   // CombinatorialBarcodesSingleEnd.hpp:84-86
+    P->kind = scg_plan::DUAL_SE_DIAG;
+    P->htab_combined = std::move(P->htab[0]);
+    std::vector<std::vector<int32_t> > exp0, exp1;
+    std::vector<uint64_t> uk0, uk1;
+    P->htab[0] = scg::build_uid_index(pools[0], n_pools[0], t.flen[0], mismatches, exp0, uk0);   // each region <= 32 bases here
+    P->htab[1] = scg::build_uid_index(pools[1], n_pools[1], t.flen[1], mismatches, exp1, uk1);
+    auto firsts = [&](const std::vector<std::vector<int32_t> >& exp, size_t n_uid) {
+        std::vector<int32_t> f(n_uid, -1);
+        for (size_t i = 0; i < exp.size(); ++i) {
+            for (int32_t u : exp[i]) if (f[u] < 0) f[u] = static_cast<int32_t>(i);
+        }
+        return f;
+    };
+    P->first1 = firsts(exp0, uk0.size());
+    P->first2 = firsts(exp1, uk1.size());
+    int64_t cells = static_cast<int64_t>(uk0.size()) * static_cast<int64_t>(uk1.size());
+    if (cells > (int64_t(1) << 28)) {
+        throw Error(SCG_ERR_UNSUPPORTED, "include.invalid=TRUE needs n_unique1 x n_unique2 <= 2^28 cells in this engine");
+    }
+    P->n_pool[1] = P->n_pool[0];
+    P->n_counters = static_cast<int64_t>(P->n_pool[0]) + 2 + cells;
+    return P;
+}
+
 // countPairedComboBarcodes: two independent SimpleSingleMatch matchers (CombinatorialBarcodesPairedEnd.hpp:85-118).
 std::unique_ptr<scg_plan> compile_paired_combo(const char* constant1, int reverse1, int mismatches1, const char* const* pool1, int32_t n1,
                                                const char* constant2, int reverse2, int mismatches2, const char* const* pool2, int32_t n2,
@@ -494,7 +529,42 @@ void fold_replicas(scg_plan* P, hipStream_t stream) {
     }
 }
 
+// countDualBarcodesSingleEnd(include.invalid=TRUE) in two passes over the batch: the valid-combination search
+// writes its per-read result as an index stream (tallied into counters[0 .. n_pool)), then the combinatorial
+// search runs on the reads that found nothing (ScgComboParams::only_if_negative) with DuplicateAction::FIRST
+// and counts (uid1, uid2) cells behind the two unused diagnostics slots: [n_pool][2][n_uid1 x n_uid2].
+void launch_batch_se_diag(scg_plan* P, const ScgReads& R, int64_t n, hipStream_t stream) {
+    scg_plan::Timer timer(P, stream);
+    DevBuf& buf = P->unit_index[stream];
+    buf.ensure(static_cast<size_t>(n) * sizeof(int32_t));
+    ScgSingleParams sp;
+    sp.scan = P->scan1;
+    sp.tmpl = P->d_tmpl1.as<ScgTemplate>();
+    sp.index = P->tab_combined.view;
+    sp.max_mm = P->max_mm1; sp.use_first = P->use_first;
+    sp.fwd = P->ht1.fwd; sp.rev = P->ht1.rev;
+    ScgCounters c1;
+    c1.base = P->counters; c1.replica_mask = 0; c1.replica_shift = 0;
+    c1.unit_index = buf.as<int32_t>();
+    HIP_CHECK(scg::launch_single(sp, P->ht1.t.len, R, n, c1, P->error_flag.as<int32_t>(), stream));
+    HIP_CHECK(scg::launch_tally(c1.unit_index, n, P->counters, P->n_pool[0], stream));
+    ScgComboParams cp;
+    cp.scan = P->scan1;
+    cp.tmpl = P->d_tmpl1.as<ScgTemplate>();
+    cp.index[0] = P->tab[0].view; cp.index[1] = P->tab[1].view;
+    cp.n_pool[0] = static_cast<int32_t>(P->first1.size()); cp.n_pool[1] = static_cast<int32_t>(P->first2.size());
+    cp.max_mm = P->max_mm1; cp.use_first = P->use_first;
+    cp.fwd = P->ht1.fwd; cp.rev = P->ht1.rev;
+    cp.only_if_negative = c1.unit_index; cp.keep_first = 1; cp.pad = 0;
+    ScgCounters c2;
+    c2.base = P->counters + P->n_pool[0] + 2; c2.replica_mask = 0; c2.replica_shift = 0; c2.unit_index = nullptr;
+    HIP_CHECK(scg::launch_combo(cp, P->ht1.t.len, R, n, c2, P->error_flag.as<int32_t>(), stream));
+    timer.stop();
+    P->total += n;
+}
+
 void launch_batch(scg_plan* P, const ScgReads& R, int64_t n, hipStream_t stream) {
+    if (P->kind == scg_plan::DUAL_SE_DIAG) { launch_batch_se_diag(P, R, n, stream); return; }
     scg_plan::Timer timer(P, stream);
     if (P->kind == scg_plan::SINGLE) {
         ScgSingleParams sp;
@@ -525,6 +595,7 @@ void launch_batch(scg_plan* P, const ScgReads& R, int64_t n, hipStream_t stream)
         cp.n_pool[0] = P->n_pool[0]; cp.n_pool[1] = P->n_pool[1];
         cp.max_mm = P->max_mm1; cp.use_first = P->use_first;
         cp.fwd = P->ht1.fwd; cp.rev = P->ht1.rev;
+        cp.only_if_negative = nullptr; cp.keep_first = 0; cp.pad = 0;
         ScgCounters counts = plan_counters(P);
         const bool tally = use_tally(P, n) && R.max_len > 0 && R.max_len <= 320 && !std::getenv("SCG_FORCE_GENERAL");
         if (tally) {
@@ -1136,7 +1207,7 @@ int scg_count_dual_barcodes_single_end(const char* path, const char* constant, c
         scg::FastqStream fq(path);                             // src/count_dual_barcodes_single_end.cpp:64: reader first
         auto P = compile_dual_single_end(constant, strand, pools, n_pools, n_regions, mismatches, use_first);
         if (diagnostics) {
-            throw Error(SCG_ERR_UNSUPPORTED, "include.invalid=TRUE is not implemented for single-end dual barcodes in this engine");
+            throw Error(SCG_ERR_INVALID, "diagnostics requested: call scg_count_dual_barcodes_single_end_diagnostics, which returns the extra outputs");
         }
         P->to_device(-1);
         DeviceGuard g(P->device);
@@ -1232,6 +1303,25 @@ int scg_count_random_barcodes(const char* path, const char* constant, int strand
             fo[i] = rows[i].second;
         }
         *sequences_out = so; *freq_out = fo; *k_out = static_cast<int64_t>(rows.size()); *length_out = vlen;
+        *total_out = static_cast<int32_t>(P->total);
+    });
+}
+
+int scg_count_dual_barcodes_single_end_diagnostics(const char* path, const char* constant, const char* const* const* pools, const int32_t* n_pools,
+                                                   int32_t n_regions, int strand, int mismatches, int use_first, int nthreads,
+                                                   int32_t* counts_out, int32_t** invalid_indices_out, int32_t** invalid_freq_out, int64_t* k_out,
+                                                   int32_t* total_out, char* err, size_t errcap) {
+    return guarded(err, errcap, [&] {
+        if (!path || !invalid_indices_out || !invalid_freq_out || !k_out || !total_out) throw Error(SCG_ERR_INVALID, "null argument");
+        scg::FastqStream fq(path);
+        auto P = compile_dual_single_end_diag(constant, strand, pools, n_pools, n_regions, mismatches, use_first);
+        P->to_device(-1);
+        DeviceGuard g(P->device);
+        count_single_end_file(P.get(), path, fq, nthreads);
+        std::vector<int32_t> all(static_cast<size_t>(P->n_counters) + 1);
+        read_counters(P.get(), all.data());
+        int32_t b1 = 0, b2 = 0;
+        diagnostics_from_counters(P.get(), all, counts_out, invalid_indices_out, invalid_freq_out, k_out, &b1, &b2);
         *total_out = static_cast<int32_t>(P->total);
     });
 }

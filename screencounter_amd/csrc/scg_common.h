@@ -176,6 +176,12 @@ struct ScgComboParams {
     int32_t max_mm;
     int32_t use_first;
     int32_t fwd, rev;
+    // countDualBarcodesSingleEnd(include.invalid=TRUE) runs this kernel as a second pass: only reads whose
+    // entry of `only_if_negative` is < 0 (no valid combination found by the first pass) are searched, and ties
+    // between barcodes go to the first (DuplicateAction::FIRST; index values are sequence uids).
+    const int32_t* only_if_negative;
+    int32_t keep_first;
+    int32_t pad;
 };
 
 struct ScgDualParams {

@@ -87,7 +87,8 @@ __global__ __launch_bounds__(BLOCK) void single_kernel(ScgSingleParams P, ScgRea
     if (i >= n_reads) return;
     Read rd = get_read(R, i);
     int idx = single_read<W>(P, rd);
-    if (idx >= 0) count_one(counts, idx);
+    if (counts.unit_index) counts.unit_index[i] = idx;       // index-stream output (ScgCounters::unit_index)
+    else if (idx >= 0) count_one(counts, idx);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -138,7 +139,7 @@ __device__ __forceinline__ bool combo_candidate(const ScgComboParams& P, const R
         const ScgIndex& tab = P.index[slot];
         Query q = pack_region(rd.p + p + start, tab.len, reverse);
         int idx, d;
-        index_match(tab, q, P.max_mm - obs, idx, d);   // :168
+        index_match(tab, q, P.max_mm - obs, idx, d, P.keep_first != 0);   // :168
         if (idx < 0) return false;
         obs += d;
         if (obs > P.max_mm) return false;               // :173-176
@@ -179,6 +180,7 @@ __global__ __launch_bounds__(BLOCK) void combo_kernel(ScgComboParams P, ScgReads
                                                        ScgCounters cells) {
     int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n_reads) return;
+    if (P.only_if_negative && P.only_if_negative[i] >= 0) return;      // second pass of the single-end dual diagnostics
     Read rd = get_read(R, i);
     int best_id[SCG_MAX_REGIONS] = {0, 0};
     if (combo_read(P, rd, best_id)) count_one(cells, (int64_t)best_id[0] * P.n_pool[1] + best_id[1]);
@@ -471,7 +473,7 @@ __device__ __forceinline__ bool combo_candidate_staged(const ScgComboParams& P, 
         const ScgIndex& tab = P.index[slot];
         Query q = region_query<NW>(tile, sr.bit + p + start, tab.len, reverse);
         int idx, d;
-        index_match(tab, q, P.max_mm - obs, idx, d);
+        index_match(tab, q, P.max_mm - obs, idx, d, P.keep_first != 0);
         if (idx < 0) return false;
         obs += d;
         if (obs > P.max_mm) return false;
@@ -500,7 +502,7 @@ __global__ __launch_bounds__(STAGE_BLOCK) __attribute__((amdgpu_num_sgpr(80))) v
         *error_flag = 1;
         return;
     }
-    {
+    if (!(P.only_if_negative && P.only_if_negative[r0 + threadIdx.x] >= 0)) {   // (second pass of the single-end dual diagnostics)
         const ScgScan& T = P.scan;
         StagedRead sr;
         sr.bit = (int)((int64_t)(rd.p - R.seqs) - span0);

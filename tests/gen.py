@@ -195,21 +195,24 @@ def random_paired_combo_case(rng: random.Random, sizes=(1, 30, 150), max_mm: int
                 randomized=c["randomized"], use_first=c["use_first"], reads1=c["reads1"], reads2=c["reads2"])
 
 
-def random_dual_single_end_case(rng: random.Random, sizes=(1, 30, 150), wide: bool = None) -> dict:
+def random_dual_single_end_case(rng: random.Random, sizes=(1, 30, 150), wide: bool = None, diag: bool = False) -> dict:
     """countDualBarcodesSingleEnd: one or two variable regions in one read, pools aligned by row
     (row c = valid combination c); `wide` forces a combined key longer than 32 bases."""
-    nreg = rng.choice([1, 2, 2])
+    nreg = 2 if diag else rng.choice([1, 2, 2])
     if wide is None:
         wide = rng.random() < 0.4
     if nreg == 1:
         lens = [rng.choice([33, 40, 64] if wide else [4, 9, 20])]
     else:
-        lens = rng.choice([[20, 20], [17, 30], [32, 32], [5, 40]] if wide else [[4, 6], [8, 8], [12, 20]])
+        # (include.invalid=TRUE searches each region on its own with the narrow index: regions <= 32 bases there)
+        lens = rng.choice(([[20, 20], [17, 30], [32, 32]] if diag else [[20, 20], [17, 30], [32, 32], [5, 40]]) if wide else [[4, 6], [8, 8], [12, 20]])
     alphabet = rng.choice(["AC", BASES])
     n = min(rng.choice([1, 4, 25]), len(alphabet) ** min(sum(lens), 8) // 2)      # distinct rows must exist
     seen, rows = set(), []
     while len(rows) < n:
         row = tuple(rand_seq(rng, l, alphabet) for l in lens)
+        if diag and rows and rng.random() < 0.4:      # a barcode shared by several combinations (duplicates within one column)
+            row = (rng.choice(rows)[0], row[1]) if rng.random() < 0.5 else (row[0], rng.choice(rows)[1])
         if "".join(row) not in seen:
             seen.add("".join(row))
             rows.append(row)

@@ -44,6 +44,11 @@ def run_file_level(sc, c, tmp_path, gz=False):
                                                                     c["randomized"], c["use_first"], True, 1)
         return {"counts": counts.tolist(), "indices": idx.tolist(), "freq": freq.tolist(), "total": total,
                 "barcode1_only": b1, "barcode2_only": b2}
+    if k == "dual_single_end_diag":
+        fq = str(tmp_path / ("x" + ext))
+        write_fastq(fq, c["reads"], gz=gz)
+        counts, (idx, freq), total = sc.count_dual_barcodes_single_end(fq, c["template"], c["pools"], c["strand"], c["mismatches"], c["use_first"], True, 1)
+        return {"counts": counts.tolist(), "indices": idx.tolist(), "freq": freq.tolist(), "total": total}
     if k == "random":
         fq = str(tmp_path / ("r" + ext))
         write_fastq(fq, c["reads"], gz=gz)

@@ -262,6 +262,27 @@ def test_dual_single_end_random(sc, oracle, gpu, seed):
         assert got[1] == exp[1] and np.array_equal(got[0], exp[0]), (case, exp, got)
 
 
+@pytest.mark.parametrize("seed", range(4))
+def test_dual_single_end_diagnostics_random(sc, oracle, gpu, seed, tmp_path):
+    """countDualBarcodesSingleEnd(include.invalid=TRUE): valid counts + invalid (pool1, pool2) combinations."""
+    from oracle.pyoracle import OracleError, write_fastq
+    rng = random.Random(7300 + seed)
+    for it in range(15):
+        case = gen.random_dual_single_end_case(rng, wide=rng.random() < 0.3, diag=True)
+        fq = str(tmp_path / f"x{it}.fastq")
+        write_fastq(fq, case["reads"])
+        try:
+            exp = oracle.count_dual_single_end_diag(case["reads"], case["template"], case["strand"], case["pools"], case["mismatches"], case["use_first"])
+        except OracleError:
+            with pytest.raises(sc.ScgError):
+                sc.count_dual_barcodes_single_end(fq, case["template"], case["pools"], case["strand"], case["mismatches"], case["use_first"], True, 1)
+            continue
+        counts, (idx, freq), total = sc.count_dual_barcodes_single_end(fq, case["template"], case["pools"], case["strand"],
+                                                                      case["mismatches"], case["use_first"], True, 1)
+        assert total == exp["total"] and np.array_equal(counts, exp["counts"]), (case, exp, counts)
+        assert np.array_equal(idx, exp["indices"]) and np.array_equal(freq, exp["freq"]), (case, exp, idx, freq)
+
+
 @pytest.mark.parametrize("seed", range(3))
 def test_wide_single_and_match_random(sc, oracle, gpu, seed):
     """Barcodes of 33..64 bases through the wide-key kernels (countSingleBarcodes, matchBarcodes)."""

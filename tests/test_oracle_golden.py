@@ -28,6 +28,9 @@ def run_oracle(oracle, c):
                                    c["template2"], c["reverse2"], c["mismatches2"], c["pool2"], c["randomized"], c["use_first"])
         return {"counts": d["counts"].tolist(), "indices": d["indices"].tolist(), "freq": d["freq"].tolist(), "total": d["total"],
                 "barcode1_only": d["barcode1_only"], "barcode2_only": d["barcode2_only"]}
+    if k == "dual_single_end_diag":
+        d = oracle.count_dual_single_end_diag(c["reads"], c["template"], c["strand"], c["pools"], c["mismatches"], c["use_first"])
+        return {"counts": d["counts"].tolist(), "indices": d["indices"].tolist(), "freq": d["freq"].tolist(), "total": d["total"]}
     if k == "random":
         tally, total = oracle.count_random(c["reads"], c["template"], c["strand"], c["mismatches"], c["use_first"])
         return {"sequences": sorted(tally), "freq": [tally[s] for s in sorted(tally)], "total": total}
