@@ -419,7 +419,7 @@ __global__ __launch_bounds__(STAGE_BLOCK) __attribute__((amdgpu_num_sgpr(80))) v
         idx = single_read_staged<NW, NT, NC, W>(P, tile, strands, sr, R.ablate);
     }
     if (counts.unit_index) counts.unit_index[r0 + threadIdx.x] = idx;
-    else if (idx >= 0 && !(R.ablate == 3 && idx != 0x7ffffff0)) count_one(counts, idx);
+    else if (idx >= 0 && !(R.ablate == 3 && idx != 0x7ffffff0)) count_one(counts, idx);     // (ablate 3: keep idx live, skip the atomic)
 }
 
 template<int NW, int NT, int NC>
