@@ -176,6 +176,7 @@ struct scg_plan {
     DevIndex tab[2];
     DevPairTable pairs;
     DevBuf own_counters;
+    DevBuf hot;          // diagnostics plans: per-wavefront slots of the two single-address tallies (ScgCounters::hot)
     DevBuf replicas;     // privatised counter copies (ScgCounters); empty when n_counters is large
     scg::HostIndex htab_combined;   // DUAL_SE_DIAG: wide index of the concatenated combinations (tab[0..1] = the per-region pools)
     DevIndex tab_combined;
@@ -218,6 +219,10 @@ struct scg_plan {
         if (replica_shift > 0) {
             replicas.alloc((static_cast<size_t>(n_counters) << replica_shift) * sizeof(int32_t));
             HIP_CHECK(hipMemset(replicas.p, 0, replicas.bytes));
+        }
+        if (kind == DUAL && diagnostics) {
+            hot.alloc(2 * SCG_HOT_SLOTS * sizeof(int32_t));
+            HIP_CHECK(hipMemset(hot.p, 0, hot.bytes));
         }
         error_flag.alloc(sizeof(int32_t));
         HIP_CHECK(hipMemset(error_flag.p, 0, sizeof(int32_t)));
@@ -511,6 +516,7 @@ ScgCounters plan_counters(const scg_plan* P) {
         c.base = P->counters; c.replica_mask = 0; c.replica_shift = 0;
     }
     c.unit_index = nullptr;
+    c.hot = P->hot.p ? P->hot.as<int32_t>() : nullptr;
     return c;
 }
 
@@ -544,7 +550,7 @@ void launch_batch_se_diag(scg_plan* P, const ScgReads& R, int64_t n, hipStream_t
     sp.max_mm = P->max_mm1; sp.use_first = P->use_first;
     sp.fwd = P->ht1.fwd; sp.rev = P->ht1.rev;
     ScgCounters c1;
-    c1.base = P->counters; c1.replica_mask = 0; c1.replica_shift = 0;
+    c1.base = P->counters; c1.replica_mask = 0; c1.replica_shift = 0; c1.hot = nullptr;
     c1.unit_index = buf.as<int32_t>();
     HIP_CHECK(scg::launch_single(sp, P->ht1.t.len, R, n, c1, P->error_flag.as<int32_t>(), stream));
     HIP_CHECK(scg::launch_tally(c1.unit_index, n, P->counters, P->n_pool[0], stream));
@@ -557,7 +563,7 @@ void launch_batch_se_diag(scg_plan* P, const ScgReads& R, int64_t n, hipStream_t
     cp.fwd = P->ht1.fwd; cp.rev = P->ht1.rev;
     cp.only_if_negative = c1.unit_index; cp.keep_first = 1; cp.pad = 0;
     ScgCounters c2;
-    c2.base = P->counters + P->n_pool[0] + 2; c2.replica_mask = 0; c2.replica_shift = 0; c2.unit_index = nullptr;
+    c2.base = P->counters + P->n_pool[0] + 2; c2.replica_mask = 0; c2.replica_shift = 0; c2.unit_index = nullptr; c2.hot = nullptr;
     HIP_CHECK(scg::launch_combo(cp, P->ht1.t.len, R, n, c2, P->error_flag.as<int32_t>(), stream));
     timer.stop();
     P->total += n;
@@ -625,18 +631,41 @@ void launch_batch_paired(scg_plan* P, const ScgReads& R1, const ScgReads& R2, in
     dp.rev1 = P->rev1; dp.rev2 = P->rev2; dp.max_mm1 = P->max_mm1; dp.max_mm2 = P->max_mm2;
     dp.randomized = P->randomized; dp.use_first = P->use_first;
     dp.diagnostics = P->diagnostics; dp.n_pool = P->diagnostics == 2 ? 0 : P->n_pool[0]; dp.n_uid2 = static_cast<int32_t>(P->first2.size());
+    dp.keep_first = P->diagnostics == 1; dp.only_if_negative = nullptr;
     ScgCounters counts = plan_counters(P);
     const int lo_len = std::min(R1.max_len, R2.max_len), hi_len = std::max(R1.max_len, R2.max_len);
-    const bool tally = use_tally(P, n) && lo_len > 0 && hi_len <= 320 && !std::getenv("SCG_FORCE_GENERAL");
+    const bool staged = lo_len > 0 && hi_len <= 320 && !std::getenv("SCG_FORCE_GENERAL");
+    const int tmpl_len = std::max(P->ht1.t.len, P->ht2.t.len);
+    if (P->diagnostics == 1 && staged) {
+        // include.invalid=TRUE in two lean passes: valid pairs as an index stream (tallied), then the mate-by-mate
+        // search on the pairs that found none
+        DevBuf& buf = P->unit_index[stream];
+        buf.ensure(static_cast<size_t>(n) * sizeof(int32_t));
+        ScgCounters c1 = counts;
+        c1.unit_index = buf.as<int32_t>();
+        dp.diagnostics = 0;
+        HIP_CHECK(scg::launch_dual(dp, tmpl_len, R1, R2, n, c1, P->error_flag.as<int32_t>(), stream));
+        HIP_CHECK(scg::launch_tally(c1.unit_index, n, P->counters, P->n_pool[0], stream));
+        dp.diagnostics = 2;
+        dp.only_if_negative = c1.unit_index;
+        HIP_CHECK(scg::launch_dual(dp, tmpl_len, R1, R2, n, counts, P->error_flag.as<int32_t>(), stream));
+        timer.stop();
+        fold_replicas(P, stream);
+        HIP_CHECK(scg::launch_hot_fold(P->hot.as<int32_t>(), P->counters + P->n_pool[0], stream));
+        P->total += n;
+        return;
+    }
+    const bool tally = use_tally(P, n) && staged;
     if (tally) {
         DevBuf& buf = P->unit_index[stream];
         buf.ensure(static_cast<size_t>(n) * sizeof(int32_t));
         counts.unit_index = buf.as<int32_t>();
     }
-    HIP_CHECK(scg::launch_dual(dp, std::max(P->ht1.t.len, P->ht2.t.len), R1, R2, n, counts, P->error_flag.as<int32_t>(), stream));
+    HIP_CHECK(scg::launch_dual(dp, tmpl_len, R1, R2, n, counts, P->error_flag.as<int32_t>(), stream));
     timer.stop();
     if (tally) HIP_CHECK(scg::launch_tally(counts.unit_index, n, P->counters, P->n_counters, stream));
     else fold_replicas(P, stream);
+    if (P->hot.p) HIP_CHECK(scg::launch_hot_fold(P->hot.as<int32_t>(), P->counters + (P->diagnostics == 2 ? 0 : P->n_pool[0]), stream));
     P->total += n;
 }
 

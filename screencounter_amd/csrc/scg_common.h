@@ -24,6 +24,7 @@
 #define SCG_SEED_LEN 10        // constant bases per seed (at most)
 #define SCG_EMPTY_KEY (~0ull)
 #define SCG_SLOT_EMPTY 0xFFFFFFFEu
+#define SCG_HOT_SLOTS 4096
 
 #define SCG_MISSING (-1)
 #define SCG_AMBIGUOUS (-2)
@@ -149,6 +150,10 @@ struct ScgCounters {
     // mapped read the kernel stores the barcode index of read r (or -1) in unit_index[r], and
     // tally_kernel turns the index stream into counts through LDS histograms (scg_kernels.hip).
     int32_t* unit_index;        // nullptr: count with atomics
+    // Diagnostics paths: partial sums of the two single-address tallies (barcode1-only, barcode2-only), one slot
+    // per wavefront modulo SCG_HOT_SLOTS, folded into their counters after the launch (hot_fold_kernel).  Even one
+    // atomic per wavefront on a single address serialises (measured: 5 ms per 20 M pairs).
+    int32_t* hot;               // [2][SCG_HOT_SLOTS] or nullptr
 };
 
 struct ScgReads {
@@ -204,6 +209,8 @@ struct ScgDualParams {
     int32_t diagnostics;
     int32_t n_pool;
     int32_t n_uid2;
+    int32_t keep_first;                  // mate searches: ties go to the first barcode (DuplicateAction::FIRST) instead of being ambiguous
+    const int32_t* only_if_negative;     // diagnostics == 2 as a second pass: search only pairs whose entry is < 0
 };
 
 static inline

@@ -40,6 +40,21 @@ __device__ __forceinline__ void count_one(const ScgCounters& C, int64_t i) {
     atomicAdd(C.base + ((i << C.replica_shift) | (int64_t)(gid & C.replica_mask)), 1);
 }
 
+// The same counter for many lanes at once (the barcode1-only / barcode2-only tallies of the diagnostics paths,
+// `which` = 0 / 1, global index i): one atomic per wavefront carries the number of lanes whose `flag` is set, and
+// goes to the wavefront's slot of ScgCounters::hot when the plan provides it.  Call from converged code.
+__device__ __forceinline__ void count_flagged(const ScgCounters& C, int which, int64_t i, bool flag) {
+    const uint64_t m = __ballot(flag);
+    if (m == 0) return;
+    const int leader = __ffsll((long long)m) - 1;
+    if ((int)(threadIdx.x & 63u) == leader) {
+        const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+        int32_t* dst = C.hot ? C.hot + which * SCG_HOT_SLOTS + ((gid >> 6) & (SCG_HOT_SLOTS - 1))
+                             : C.base + ((i << C.replica_shift) | (int64_t)(gid & C.replica_mask));
+        atomicAdd(dst, (int)__popcll(m));
+    }
+}
+
 __device__ __forceinline__ Read get_read(const ScgReads& R, int64_t i) {
     Read r;
     if (R.offsets) {

@@ -267,47 +267,60 @@ __device__ __forceinline__ bool mate_search(const ScgTemplate* T, const ScgIndex
 
 // CombinatorialBarcodesPairedEnd::process (handlers/CombinatorialBarcodesPairedEnd.hpp:167-242) on a
 // pair the dual search rejected.  S1(x)/S2(x) = search of template 1 / 2 on mate x (0 = a, 1 = b).
-template<class S1, class S2>
-__device__ __forceinline__ void diagnose_pair(const ScgDualParams& P, S1 s1, S2 s2, const ScgCounters& counters) {
+// `M` supplies the two searches as M::search1 / search2(P, mate, index, mismatches).  They take P explicitly:
+// a closure holding a reference to the kernel-argument struct makes the compiler copy all of it (2 KB) to
+// scratch at kernel entry, which cost the diagnostics kernels a factor of 8.
+template<class M>
+__device__ __forceinline__ void diagnose_pair(const ScgDualParams& P, const M& m, const ScgCounters& counters) {
     const int64_t b1_only = P.n_pool, b2_only = b1_only + 1, cells = b2_only + 1;
     auto emit = [&](int u1, int u2) { count_one(counters, cells + (int64_t)u1 * P.n_uid2 + u2); };
-    int i1, m1, i2, m2;
-    const bool f1 = s1(0, i1, m1), f2 = s2(1, i2, m2);
-    if (P.use_first) {
-        if (f1 && f2) {
-            emit(i1, i2);
-        } else if (P.randomized) {
-            int j1, n1, j2, n2;
-            const bool g1 = s1(1, j1, n1), g2 = s2(0, j2, n2);
-            if (g1 && g2) emit(j1, j2);
-            else if (f1 || g1) count_one(counters, b1_only);
-            else if (f2 || g2) count_one(counters, b2_only);
+    // Each of the four searches appears exactly once, in straight-line order: when the same search sits in
+    // several divergent branches the compiler merges the copies and selects the template per lane, which
+    // forces the whole argument struct into scratch.
+    int i1 = -1, m1 = 0, i2 = -1, m2 = 0, j1 = -1, n1 = 0, j2 = -1, n2 = 0;
+    const bool f1 = m.search1(P, 0, i1, m1);
+    const bool f2 = m.search2(P, 1, i2, m2);
+    // the swapped orientation is consulted by every randomized branch except "first match found both"
+    const bool swapped = P.randomized && !(P.use_first && f1 && f2);
+    bool g1 = false, g2 = false;
+    if (swapped) {
+        g1 = m.search1(P, 1, j1, n1);
+        g2 = m.search2(P, 0, j2, n2);
+    }
+    // outcome per lane: 0 nothing, 1 combination (u1, u2), 2 barcode 1 only, 3 barcode 2 only
+    int what = 0, u1 = 0, u2 = 0;
+    auto pick = [&](int x, int y) { what = 1; u1 = x; u2 = y; };
+    if (P.use_first) {                                   // :170-193
+        if (f1 && f2) pick(i1, i2);
+        else if (P.randomized) {
+            if (g1 && g2) pick(j1, j2);
+            else if (f1 || g1) what = 2;
+            else if (f2 || g2) what = 3;
         } else {
-            if (f1) count_one(counters, b1_only);
-            else if (f2) count_one(counters, b2_only);
+            if (f1) what = 2;
+            else if (f2) what = 3;
         }
-    } else if (!P.randomized) {
-        if (f1 && f2) emit(i1, i2);
-        else if (f1) count_one(counters, b1_only);
-        else if (f2) count_one(counters, b2_only);
-    } else if (f1 && f2) {
-        int j1, n1, j2, n2;
-        const bool g1 = s1(1, j1, n1), g2 = s2(0, j2, n2);
+    } else if (!P.randomized) {                          // :195-205
+        if (f1 && f2) pick(i1, i2);
+        else if (f1) what = 2;
+        else if (f2) what = 3;
+    } else if (f1 && f2) {                               // :207-226
         if (g1 && g2) {
             int mism = m1 + m2, rmism = n1 + n2;
-            if (mism > rmism) emit(j1, j2);
-            else if (mism < rmism) emit(i1, i2);
-            else if (i1 == j1 && i2 == j2) emit(i1, i2);
+            if (mism > rmism) pick(j1, j2);
+            else if (mism < rmism) pick(i1, i2);
+            else if (i1 == j1 && i2 == j2) pick(i1, i2);
         } else {
-            emit(i1, i2);
+            pick(i1, i2);
         }
-    } else {
-        int j1, n1, j2, n2;
-        const bool g1 = s1(1, j1, n1), g2 = s2(0, j2, n2);
-        if (g1 && g2) emit(j1, j2);
-        else if (f1 || g1) count_one(counters, b1_only);
-        else if (f2 || g2) count_one(counters, b2_only);
+    } else {                                             // :227-239
+        if (g1 && g2) pick(j1, j2);
+        else if (f1 || g1) what = 2;
+        else if (f2 || g2) what = 3;
     }
+    if (what == 1) emit(u1, u2);
+    count_flagged(counters, 0, b1_only, what == 2);      // single hot addresses: one atomic per wavefront, spread over slots
+    count_flagged(counters, 1, b2_only, what == 3);
 }
 
 __device__ __forceinline__ int dual_pair(const ScgDualParams& P, const Read& a, const Read& b) {
@@ -328,20 +341,27 @@ __device__ __forceinline__ int dual_pair(const ScgDualParams& P, const Read& a, 
     return idx;
 }
 
+struct GeneralMates {
+    Read a, b;
+    __device__ __forceinline__ bool search1(const ScgDualParams& P, int which, int& index, int& mism) const {
+        return mate_search(P.tmpl1, P.index1, P.rev1 != 0, P.max_mm1, P.use_first != 0, P.keep_first != 0, which ? b : a, index, mism);
+    }
+    __device__ __forceinline__ bool search2(const ScgDualParams& P, int which, int& index, int& mism) const {
+        return mate_search(P.tmpl2, P.index2, P.rev2 != 0, P.max_mm2, P.use_first != 0, P.keep_first != 0, which ? b : a, index, mism);
+    }
+};
+
 __global__ __launch_bounds__(BLOCK) void dual_kernel(ScgDualParams P, ScgReads R1, ScgReads R2, int64_t n_pairs,
                                                       ScgCounters counts) {
     int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n_pairs) return;
+    if (P.diagnostics == 2 && P.only_if_negative && P.only_if_negative[i] >= 0) return;   // second pass of include.invalid=TRUE
     Read a = get_read(R1, i), b = get_read(R2, i);
     int idx = P.diagnostics == 2 ? -1 : dual_pair(P, a, b);
     if (idx >= 0) {
         count_one(counts, idx);
     } else if (P.diagnostics) {
-        const bool keep_first = P.diagnostics == 1;
-        diagnose_pair(P,
-            [&](int which, int& index, int& mism) { return mate_search(P.tmpl1, P.index1, P.rev1 != 0, P.max_mm1, P.use_first != 0, keep_first, which ? b : a, index, mism); },
-            [&](int which, int& index, int& mism) { return mate_search(P.tmpl2, P.index2, P.rev2 != 0, P.max_mm2, P.use_first != 0, keep_first, which ? b : a, index, mism); },
-            counts);
+        diagnose_pair(P, GeneralMates{a, b}, counts);
     }
 }
 
@@ -615,9 +635,27 @@ __device__ __forceinline__ void dual_orientation_staged(const ScgDualParams& P, 
     }
 }
 
-// DIAG: include.invalid=TRUE -- rejected pairs are also searched mate by mate (separate instantiation so
-// that the ordinary kernel does not pay for it).
-template<int NW, int NT, int NC, bool DIAG>
+// The two mate searches of diagnose_pair on staged tiles.
+template<int NW, int NT, int NC>
+struct StagedMates {
+    const Tile<NW>& tile1;
+    const Tile<NW>& tile2;
+    StagedRead sa, sb;
+    __device__ __forceinline__ bool search1(const ScgDualParams& P, int which, int& index, int& mism) const {
+        return mate_search_staged<NW, NT, NC>(which ? tile2 : tile1, which ? sb : sa, P.scan1, P.index1, P.rev1 != 0,
+                                              P.max_mm1, P.use_first != 0, P.keep_first != 0, index, mism);
+    }
+    __device__ __forceinline__ bool search2(const ScgDualParams& P, int which, int& index, int& mism) const {
+        return mate_search_staged<NW, NT, NC>(which ? tile2 : tile1, which ? sb : sa, P.scan2, P.index2, P.rev2 != 0,
+                                              P.max_mm2, P.use_first != 0, P.keep_first != 0, index, mism);
+    }
+};
+
+// MATES_ONLY: no search for valid pairs, only the mate-by-mate search of diagnose_pair -- countPairedComboBarcodes,
+// and the second pass of include.invalid=TRUE over the pairs the plain kernel rejected
+// (ScgDualParams::only_if_negative).  Two lean kernels instead of one: the nested pair search next to four
+// inlined mate searches needed 256 VGPRs plus a scratch copy of the arguments and ran 8 x slower.
+template<int NW, int NT, int NC, bool MATES_ONLY>
 __global__ __launch_bounds__(STAGE_BLOCK) void dual_staged_kernel(ScgDualParams P, ScgReads R1, ScgReads R2, int64_t n_pairs,
                                                                  ScgCounters counts, int32_t* __restrict__ error_flag) {
     __shared__ Tile<NW> tile1;
@@ -643,7 +681,8 @@ __global__ __launch_bounds__(STAGE_BLOCK) void dual_staged_kernel(ScgDualParams 
         // One body for both orientations (template 1 on mate 1 / on mate 2 when randomized) and
         // both policies: DualBarcodesPairedEnd.hpp:353-381.
         const bool best_mode = !P.use_first;
-        const int norient = (DIAG && P.diagnostics == 2) ? 0 : (P.randomized ? 2 : 1);     // 2: no valid-pair list to search
+        if (MATES_ONLY && P.only_if_negative && P.only_if_negative[r0 + threadIdx.x] >= 0) return;   // a valid pair was counted by the first pass
+        const int norient = MATES_ONLY ? 0 : (P.randomized ? 2 : 1);
         int best = 0;
         idx = -1;
         for (int o = 0; o < norient; ++o) {
@@ -662,21 +701,11 @@ __global__ __launch_bounds__(STAGE_BLOCK) void dual_staged_kernel(ScgDualParams 
                 else if (best == cb && idx != ci) { idx = -1; }
             }
         }
-        if (DIAG && idx < 0) {
-            const bool keep_first = P.diagnostics == 1;
-            diagnose_pair(P,
-                [&](int which, int& index, int& mism) {
-                    return mate_search_staged<NW, NT, NC>(which ? tile2 : tile1, which ? sb : sa, P.scan1, P.index1, P.rev1 != 0,
-                                                          P.max_mm1, P.use_first != 0, keep_first, index, mism);
-                },
-                [&](int which, int& index, int& mism) {
-                    return mate_search_staged<NW, NT, NC>(which ? tile2 : tile1, which ? sb : sa, P.scan2, P.index2, P.rev2 != 0,
-                                                          P.max_mm2, P.use_first != 0, keep_first, index, mism);
-                },
-                counts);
+        if (MATES_ONLY) {
+            diagnose_pair(P, StagedMates<NW, NT, NC>{tile1, tile2, sa, sb}, counts);
         }
     }
-    if (!DIAG && counts.unit_index) counts.unit_index[r0 + threadIdx.x] = idx;       // tally mode (ScgCounters::unit_index)
+    if (!MATES_ONLY && counts.unit_index) counts.unit_index[r0 + threadIdx.x] = idx;       // index stream (ScgCounters::unit_index)
     else if (idx >= 0) count_one(counts, idx);
 }
 
@@ -823,7 +852,7 @@ template<int NW, int NT> struct LaunchDual {
         const int max_len = R1.max_len > R2.max_len ? R1.max_len : R2.max_len;
         const int min_t = P.scan1.len < P.scan2.len ? P.scan1.len : P.scan2.len;
         const bool compact = NW == 5 && P.scan1.compact_ok && P.scan2.compact_ok && max_len - min_t + 1 <= 96;
-        if (P.diagnostics) {
+        if (P.diagnostics) {      // 2 (mates only); the host runs include.invalid=TRUE (1) as a plain pass followed by a masked pass of 2
             if (compact) hipLaunchKernelGGL((dual_staged_kernel<NW, NT, (NW == 5 ? 3 : NW), true>), dim3(staged_grid(n)), dim3(STAGE_BLOCK), 0, stream, P, R1, R2, n, counts, flag);
             else hipLaunchKernelGGL((dual_staged_kernel<NW, NT, NW, true>), dim3(staged_grid(n)), dim3(STAGE_BLOCK), 0, stream, P, R1, R2, n, counts, flag);
         } else {
@@ -953,6 +982,26 @@ __global__ __launch_bounds__(TALLY_BLOCK) void tally_kernel(const int32_t* __res
     }
 }
 
+// Sums the per-wavefront slots of ScgCounters::hot into the two counters they stand for and clears them.
+__global__ __launch_bounds__(BLOCK) void hot_fold_kernel(int32_t* __restrict__ hot, int32_t* __restrict__ pair_of_counters) {
+    __shared__ int sums[2][BLOCK / 64];
+    for (int which = 0; which < 2; ++which) {
+        int acc = 0;
+        for (int i = threadIdx.x; i < SCG_HOT_SLOTS; i += BLOCK) {
+            acc += hot[which * SCG_HOT_SLOTS + i];
+            hot[which * SCG_HOT_SLOTS + i] = 0;
+        }
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+        if ((threadIdx.x & 63) == 0) sums[which][threadIdx.x >> 6] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        int tot = 0;
+        for (int w = 0; w < BLOCK / 64; ++w) tot += sums[threadIdx.x][w];
+        if (tot) atomicAdd(&pair_of_counters[threadIdx.x], tot);
+    }
+}
+
 __global__ __launch_bounds__(BLOCK) void fold_kernel(int32_t* __restrict__ replicas, int shift, int64_t n,
                                                      int32_t* __restrict__ counters) {
     const int R = 1 << shift;
@@ -977,6 +1026,11 @@ __global__ __launch_bounds__(BLOCK) void fold_kernel(int32_t* __restrict__ repli
         for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
         if (lane == 0 && sum) atomicAdd(&counters[i], sum);
     }
+}
+
+hipError_t launch_hot_fold(int32_t* hot, int32_t* pair_of_counters, hipStream_t stream) {
+    hipLaunchKernelGGL(hot_fold_kernel, dim3(1), dim3(BLOCK), 0, stream, hot, pair_of_counters);
+    return hipGetLastError();
 }
 
 hipError_t launch_tally(const int32_t* unit_index, int64_t n, int32_t* counters, int64_t n_counters, hipStream_t stream) {

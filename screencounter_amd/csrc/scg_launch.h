@@ -15,6 +15,8 @@ hipError_t launch_random(const ScgSingleParams& P, int tmpl_len, const ScgReads&
 hipError_t launch_combo(const ScgComboParams& P, int tmpl_len, const ScgReads& R, int64_t n, const ScgCounters& cells, int32_t* flag, hipStream_t stream);
 hipError_t launch_dual(const ScgDualParams& P, int tmpl_len, const ScgReads& R1, const ScgReads& R2, int64_t n, const ScgCounters& counts, int32_t* flag, hipStream_t stream);
 hipError_t launch_fold(int32_t* replicas, int replica_shift, int64_t n, int32_t* counters, hipStream_t stream);
+// hot[2][SCG_HOT_SLOTS] -> pair_of_counters[0], [1] (and clears the slots); ScgCounters::hot
+hipError_t launch_hot_fold(int32_t* hot, int32_t* pair_of_counters, hipStream_t stream);
 // counters[unit_index[r]] += 1 for every r with unit_index[r] >= 0, through LDS histograms (ScgCounters::unit_index)
 hipError_t launch_tally(const int32_t* unit_index, int64_t n, int32_t* counters, int64_t n_counters, hipStream_t stream);
 hipError_t launch_match(const ScgIndex& tab, const uint8_t* d_seqs, int32_t n, int cap, int reverse,
