@@ -122,6 +122,8 @@ def load() -> C.CDLL:
         pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
+        if os.environ.get("SCG_LIB") and not hasattr(lib, name):
+            continue              # an older build under tools/ab/ (A/B timing of entry points both builds have)
         fn = getattr(lib, name)   # AttributeError here means the .so is stale: rebuild
         fn.restype = res
         fn.argtypes = args

@@ -482,7 +482,9 @@ __global__ __launch_bounds__(STAGE_BLOCK) __attribute__((amdgpu_num_sgpr(80))) v
     hits[r0 + threadIdx.x] = out;
 }
 
-template<int NW, int NT>
+// SECOND: the masked DuplicateAction::FIRST pass of the single-end dual diagnostics -- a compile-time variant, so that
+// the ordinary combination kernel keeps its code (a run-time flag here cost it 9 %).
+template<int NW, int NT, bool SECOND>
 __device__ __forceinline__ bool combo_candidate_staged(const ScgComboParams& P, const Tile<NW>& tile, const StrandTable<NT>& st, const StagedRead& sr,
                                                        int p, bool reverse, int c, int out[SCG_MAX_REGIONS], int& total) {
     int obs = c;
@@ -493,7 +495,7 @@ __device__ __forceinline__ bool combo_candidate_staged(const ScgComboParams& P, 
         const ScgIndex& tab = P.index[slot];
         Query q = region_query<NW>(tile, sr.bit + p + start, tab.len, reverse);
         int idx, d;
-        index_match(tab, q, P.max_mm - obs, idx, d, P.keep_first != 0);
+        index_match(tab, q, P.max_mm - obs, idx, d, SECOND);
         if (idx < 0) return false;
         obs += d;
         if (obs > P.max_mm) return false;
@@ -503,7 +505,7 @@ __device__ __forceinline__ bool combo_candidate_staged(const ScgComboParams& P, 
     return true;
 }
 
-template<int NW, int NT, int NC>
+template<int NW, int NT, int NC, bool SECOND>
 __global__ __launch_bounds__(STAGE_BLOCK) __attribute__((amdgpu_num_sgpr(80))) void combo_staged_kernel(ScgComboParams P, ScgReads R, int64_t n_reads,
                                                                   ScgCounters cells, int32_t* __restrict__ error_flag) {
     __shared__ Tile<NW> tile;
@@ -522,7 +524,7 @@ __global__ __launch_bounds__(STAGE_BLOCK) __attribute__((amdgpu_num_sgpr(80))) v
         *error_flag = 1;
         return;
     }
-    if (!(P.only_if_negative && P.only_if_negative[r0 + threadIdx.x] >= 0)) {   // (second pass of the single-end dual diagnostics)
+    if (!(SECOND && P.only_if_negative[r0 + threadIdx.x] >= 0)) {   // (second pass: only reads the first pass left without a combination)
         const ScgScan& T = P.scan;
         StagedRead sr;
         sr.bit = (int)((int64_t)(rd.p - R.seqs) - span0);
@@ -539,7 +541,7 @@ __global__ __launch_bounds__(STAGE_BLOCK) __attribute__((amdgpu_num_sgpr(80))) v
             int c = window_mismatches<NW, NT>(tile, sr.bit + p, strands, rev);
             if (c > P.max_mm) continue;
             int cand[SCG_MAX_REGIONS], tot;
-            if (!combo_candidate_staged<NW, NT>(P, tile, strands, sr, p, rev, c, cand, tot)) continue;
+            if (!combo_candidate_staged<NW, NT, SECOND>(P, tile, strands, sr, p, rev, c, cand, tot)) continue;
             if (P.use_first) {
                 found = 1; best_id[0] = cand[0]; best_id[1] = cand[1];
                 break;
@@ -840,9 +842,11 @@ template<int NW, int NT> struct LaunchSingle {
 template<int NW, int NT> struct LaunchCombo {
     static hipError_t go(const ScgComboParams& P, const ScgReads& R, int64_t n, const ScgCounters& cells, int32_t* flag, hipStream_t stream) {
         if (NW == 5 && P.scan.compact_ok && R.max_len - P.scan.len + 1 <= 96) {
-            hipLaunchKernelGGL((combo_staged_kernel<NW, NT, (NW == 5 ? 3 : NW)>), dim3(staged_grid(n)), dim3(STAGE_BLOCK), 0, stream, P, R, n, cells, flag);
+            if (P.only_if_negative) hipLaunchKernelGGL((combo_staged_kernel<NW, NT, (NW == 5 ? 3 : NW), true>), dim3(staged_grid(n)), dim3(STAGE_BLOCK), 0, stream, P, R, n, cells, flag);
+            else hipLaunchKernelGGL((combo_staged_kernel<NW, NT, (NW == 5 ? 3 : NW), false>), dim3(staged_grid(n)), dim3(STAGE_BLOCK), 0, stream, P, R, n, cells, flag);
         } else {
-            hipLaunchKernelGGL((combo_staged_kernel<NW, NT, NW>), dim3(staged_grid(n)), dim3(STAGE_BLOCK), 0, stream, P, R, n, cells, flag);
+            if (P.only_if_negative) hipLaunchKernelGGL((combo_staged_kernel<NW, NT, NW, true>), dim3(staged_grid(n)), dim3(STAGE_BLOCK), 0, stream, P, R, n, cells, flag);
+            else hipLaunchKernelGGL((combo_staged_kernel<NW, NT, NW, false>), dim3(staged_grid(n)), dim3(STAGE_BLOCK), 0, stream, P, R, n, cells, flag);
         }
         return hipGetLastError();
     }
