@@ -108,6 +108,21 @@ def test_valid_plan_needs_a_device_or_works(sc):
         expect_error(sc, _lib.SCG_ERR_DEVICE, "no HIP device", sc.Plan.dual, "AC--GT", False, 0, ["AA", "AA"], "AC--GT", False, 0, ["CC", "GG"])
 
 
+def test_set_device_reports_missing_or_bad_devices(sc):
+    """scg_set_device (worker threads of the matrixOf* scheduler): loud errors, never a silent default."""
+    from screencounter_amd import _lib
+    from screencounter_amd._lib import ERRCAP, errbuf
+    L = sc.load()
+    err = errbuf()
+    n = L.scg_device_count()
+    if n == 0:
+        assert L.scg_set_device(0, err, ERRCAP) == _lib.SCG_ERR_DEVICE and b"no HIP device" in err.value
+    else:
+        assert L.scg_set_device(0, err, ERRCAP) == _lib.SCG_OK
+        assert L.scg_set_device(n, err, ERRCAP) == _lib.SCG_ERR_DEVICE and b"out of range" in err.value
+        assert L.scg_set_device(-1, err, ERRCAP) == _lib.SCG_ERR_DEVICE
+
+
 def test_file_level_error_order(sc, tmp_path):
     """Missing file is reported first, like byteme::SomeFileReader in src/count_single_barcodes.cpp:30."""
     from screencounter_amd import _lib
