@@ -8,6 +8,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -580,7 +581,7 @@ void launch_batch(scg_plan* P, const ScgReads& R, int64_t n, hipStream_t stream)
         sp.max_mm = P->max_mm1; sp.use_first = P->use_first;
         sp.fwd = P->ht1.fwd; sp.rev = P->ht1.rev;
         ScgCounters counts = plan_counters(P);
-        const bool tally = use_tally(P, n) && R.max_len > 0 && R.max_len <= 320 && !std::getenv("SCG_FORCE_GENERAL");
+        const bool tally = use_tally(P, n) && R.max_len > 0 && R.max_len <= 320 && !scg::force_general();
         if (tally) {
             DevBuf& buf = P->unit_index[stream];              // batches on different streams may be in flight together
             buf.ensure(static_cast<size_t>(n) * sizeof(int32_t));
@@ -603,7 +604,7 @@ void launch_batch(scg_plan* P, const ScgReads& R, int64_t n, hipStream_t stream)
         cp.fwd = P->ht1.fwd; cp.rev = P->ht1.rev;
         cp.only_if_negative = nullptr; cp.keep_first = 0; cp.pad = 0;
         ScgCounters counts = plan_counters(P);
-        const bool tally = use_tally(P, n) && R.max_len > 0 && R.max_len <= 320 && !std::getenv("SCG_FORCE_GENERAL");
+        const bool tally = use_tally(P, n) && R.max_len > 0 && R.max_len <= 320 && !scg::force_general();
         if (tally) {
             DevBuf& buf = P->unit_index[stream];
             buf.ensure(static_cast<size_t>(n) * sizeof(int32_t));
@@ -634,7 +635,7 @@ void launch_batch_paired(scg_plan* P, const ScgReads& R1, const ScgReads& R2, in
     dp.keep_first = P->diagnostics == 1; dp.only_if_negative = nullptr;
     ScgCounters counts = plan_counters(P);
     const int lo_len = std::min(R1.max_len, R2.max_len), hi_len = std::max(R1.max_len, R2.max_len);
-    const bool staged = lo_len > 0 && hi_len <= 320 && !std::getenv("SCG_FORCE_GENERAL");
+    const bool staged = lo_len > 0 && hi_len <= 320 && !scg::force_general();
     const int tmpl_len = std::max(P->ht1.t.len, P->ht2.t.len);
     if (P->diagnostics == 1 && staged) {
         // include.invalid=TRUE in two lean passes: valid pairs as an index stream (tallied), then the mate-by-mate

@@ -806,14 +806,14 @@ inline unsigned staged_grid(int64_t n) { return (unsigned)((n + STAGE_BLOCK - 1)
 
 namespace scg {
 
-namespace {
-
 // Test hook: SCG_FORCE_GENERAL=1 runs the byte-wise engine alone (read at every launch so that a
-// test process can flip it).
+// test process can flip it).  One definition for kernels and host pipelines alike (scg_launch.h).
 bool force_general() {
     const char* e = std::getenv("SCG_FORCE_GENERAL");
     return e && *e && *e != '0';
 }
+
+namespace {
 
 // NW in {5, 10}: plane words per read; NT in {2, 4, 8}: plane words per template window.
 template<template<int, int> class Launch, class... Args>
@@ -856,7 +856,8 @@ template<int NW, int NT> struct LaunchDual {
         const int max_len = R1.max_len > R2.max_len ? R1.max_len : R2.max_len;
         const int min_t = P.scan1.len < P.scan2.len ? P.scan1.len : P.scan2.len;
         const bool compact = NW == 5 && P.scan1.compact_ok && P.scan2.compact_ok && max_len - min_t + 1 <= 96;
-        if (P.diagnostics) {      // 2 (mates only); the host runs include.invalid=TRUE (1) as a plain pass followed by a masked pass of 2
+        if (P.diagnostics == 1) return hipErrorInvalidValue;   // the host runs include.invalid=TRUE as a plain pass followed by a masked pass of 2
+        if (P.diagnostics) {      // 2 (mates only)
             if (compact) hipLaunchKernelGGL((dual_staged_kernel<NW, NT, (NW == 5 ? 3 : NW), true>), dim3(staged_grid(n)), dim3(STAGE_BLOCK), 0, stream, P, R1, R2, n, counts, flag);
             else hipLaunchKernelGGL((dual_staged_kernel<NW, NT, NW, true>), dim3(staged_grid(n)), dim3(STAGE_BLOCK), 0, stream, P, R1, R2, n, counts, flag);
         } else {

@@ -9,6 +9,9 @@
 
 namespace scg {
 
+// Test hook: SCG_FORCE_GENERAL=1 (any value but empty / 0) runs the byte-wise engine alone; read at every launch.
+bool force_general();
+
 hipError_t launch_single(const ScgSingleParams& P, int tmpl_len, const ScgReads& R, int64_t n, const ScgCounters& counts, int32_t* flag, hipStream_t stream);
 // countRandomBarcodes: d_hits[i] = (position << 1) | reverse of read i's template hit, or -1
 hipError_t launch_random(const ScgSingleParams& P, int tmpl_len, const ScgReads& R, int64_t n, int32_t* d_hits, int32_t* flag, hipStream_t stream);
