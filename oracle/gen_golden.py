@@ -177,6 +177,17 @@ def known_answers() -> list:
     cases.append(dual("test-dual.R:206-207", r1, r2, 0, 1, 3, randomized=True, pool1=one, pool2=one, t1=tv, t2=tv, rexp={"counts": [3]}))
     cases.append(dual("test-dual.R:213-216", r1, r2, 1, 1, 4, randomized=True, pool1=["AAAAAAAAA", "AAAAAACAA"], pool2=["AAAAAAAAA", "AAAAAAAAA"],
                       t1=tv, t2=tv, rexp={"counts": [2, 2]}))
+
+    # tests/testthat/test-countDualBarcodesSingleEnd.R:38-59 -- both variable regions in one read, one shared
+    # substitution budget (defaults: strand = "both", find.best = FALSE); choices2 is recycled over the 4 rows
+    se_reads = ["ACGTGGGGGGGGGGTGCAAGGAAAAAAAAAAAAAAAAAGGA",
+                "ACGTGGGGGGGGGGTGCAAGGAAAAAAAAAAATAAAAAGGA",
+                "ACGTGGGGCGGGGGTGCAAGGAAAAAAAAAAATAAAAAGGA"]
+    se_tmpl = "ACGT" + "-" * 10 + "TGCAAGGA" + "-" * 15 + "AGGA"
+    for subs, line, exp in ((0, "50-51", [0, 0, 1, 0]), (1, "53-54", [0, 0, 2, 0]), (2, "56-57", [0, 0, 3, 0])):
+        cases.append(dict(kind="dual_single_end", source=f"test-countDualBarcodesSingleEnd.R:{line}", template=se_tmpl, strand=2,
+                          pools=[poly, ["A" * 15] * 4], mismatches=subs, use_first=True, reads=se_reads,
+                          r_expect={"counts": exp}))
     return cases
 
 

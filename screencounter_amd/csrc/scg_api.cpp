@@ -8,6 +8,8 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <climits>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -257,8 +259,13 @@ ScgReads make_reads(const char* d_seqs, const uint32_t* d_offsets, int32_t fixed
     r.offsets = d_offsets;
     r.fixed_len = d_offsets ? 0 : fixed_len;
     r.max_len = d_offsets ? max_len : fixed_len;
-    const char* ab = std::getenv("SCG_ABLATE");   // profiling aid only: results are wrong when set
+#ifdef SCG_ABLATE
+    // measurement builds only (make EXTRA=-DSCG_ABLATE OUT=...): the product library has no such switch
+    const char* ab = std::getenv("SCG_ABLATE");
     r.ablate = ab ? std::atoi(ab) : 0;
+#else
+    r.ablate = 0;
+#endif
     return r;
 }
 
@@ -791,6 +798,16 @@ void count_single_end_file(scg_plan* P, const char* path, scg::FastqStream& fq, 
     st.drain();
 }
 
+// The reference's totals and counters are 32-bit `int`s (SingleBarcodeSingleEnd.hpp:132-133) and R integers
+// are 32-bit; a file with more reads than that would overflow them silently there.  Here the total is kept
+// in 64 bits and narrowing at the ABI is checked; no counter can exceed the total.
+int32_t narrow_total(int64_t total) {
+    if (total > static_cast<int64_t>(INT32_MAX)) {
+        throw Error(SCG_ERR_INVALID, "number of reads (" + std::to_string(total) + ") exceeds the 32-bit range of the count vectors");
+    }
+    return static_cast<int32_t>(total);
+}
+
 void read_counters(scg_plan* P, int32_t* counts_out) {
     int32_t flag = 0;
     HIP_CHECK(hipMemcpy(&flag, P->error_flag.p, sizeof(flag), hipMemcpyDeviceToHost));
@@ -939,6 +956,7 @@ void count_paired_files(scg_plan* P, const char* path1, const char* path2, scg::
 // -------------------------------------------------------------------------------------------------
 // C ABI
 // -------------------------------------------------------------------------------------------------
+#pragma GCC visibility push(default)     // the C ABI is the library's whole export list (csrc/Makefile: -fvisibility=hidden)
 extern "C" {
 
 const char* scg_version(void) { return "scg 0.1.0 (gfx950)"; }
@@ -1162,7 +1180,7 @@ int scg_count_single_barcodes(const char* path, const char* constant, int strand
         DeviceGuard g(P->device);
         count_single_end_file(P.get(), path, fq, nthreads);
         read_counters(P.get(), counts_out);
-        *total_out = static_cast<int32_t>(P->total);
+        *total_out = narrow_total(P->total);
     });
 }
 
@@ -1181,7 +1199,7 @@ int scg_count_combo_barcodes_single(const char* path, const char* constant, int 
         std::vector<int32_t> cells(static_cast<size_t>(P->n_counters) + 1);
         read_counters(P.get(), cells.data());
         combo_compact(cells.data(), n_pool0, n_pool1, indices_out, freq_out, k_out);
-        *total_out = static_cast<int32_t>(P->total);
+        *total_out = narrow_total(P->total);
     });
 }
 
@@ -1201,7 +1219,7 @@ int scg_count_dual_barcodes(const char* path1, const char* constant1, int revers
         DeviceGuard g(P->device);
         count_paired_files(P.get(), path1, path2, fq1, fq2, nthreads);
         read_counters(P.get(), counts_out);
-        *total_out = static_cast<int32_t>(P->total);
+        *total_out = narrow_total(P->total);
     });
 }
 
@@ -1225,7 +1243,7 @@ int scg_count_dual_barcodes_diagnostics(const char* path1, const char* constant1
         std::vector<int32_t> all(static_cast<size_t>(P->n_counters) + 1);
         read_counters(P.get(), all.data());
         diagnostics_from_counters(P.get(), all, counts_out, invalid_indices_out, invalid_freq_out, k_out, barcode1_only_out, barcode2_only_out);
-        *total_out = static_cast<int32_t>(P->total);
+        *total_out = narrow_total(P->total);
     });
 }
 
@@ -1243,7 +1261,7 @@ int scg_count_dual_barcodes_single_end(const char* path, const char* constant, c
         DeviceGuard g(P->device);
         count_single_end_file(P.get(), path, fq, nthreads);
         read_counters(P.get(), counts_out);
-        *total_out = static_cast<int32_t>(P->total);
+        *total_out = narrow_total(P->total);
     });
 }
 
@@ -1333,7 +1351,7 @@ int scg_count_random_barcodes(const char* path, const char* constant, int strand
             fo[i] = rows[i].second;
         }
         *sequences_out = so; *freq_out = fo; *k_out = static_cast<int64_t>(rows.size()); *length_out = vlen;
-        *total_out = static_cast<int32_t>(P->total);
+        *total_out = narrow_total(P->total);
     });
 }
 
@@ -1352,7 +1370,7 @@ int scg_count_dual_barcodes_single_end_diagnostics(const char* path, const char*
         read_counters(P.get(), all.data());
         int32_t b1 = 0, b2 = 0;
         diagnostics_from_counters(P.get(), all, counts_out, invalid_indices_out, invalid_freq_out, k_out, &b1, &b2);
-        *total_out = static_cast<int32_t>(P->total);
+        *total_out = narrow_total(P->total);
     });
 }
 
@@ -1378,7 +1396,7 @@ int scg_count_combo_barcodes_paired(const char* path1, const char* constant1, in
         std::vector<int32_t> all(static_cast<size_t>(P->n_counters) + 1);
         read_counters(P.get(), all.data());
         diagnostics_from_counters(P.get(), all, nullptr, indices_out, freq_out, k_out, barcode1_only_out, barcode2_only_out);
-        *total_out = static_cast<int32_t>(P->total);
+        *total_out = narrow_total(P->total);
     });
 }
 
@@ -1441,3 +1459,4 @@ int scg_synth_reads(const scg_synth_spec* spec, char* d_seqs_out, int64_t n_read
 }
 
 } // extern "C"
+#pragma GCC visibility pop

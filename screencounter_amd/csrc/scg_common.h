@@ -161,8 +161,8 @@ struct ScgReads {
     const uint32_t* offsets;  // n + 1 entries, or nullptr for fixed-length reads
     int32_t fixed_len;
     int32_t max_len;          // hint: upper bound on the read lengths (0 = unknown); picks the LDS tile shape only
-    int32_t ablate;           // profiling aid (SCG_ABLATE, tools/ablate*.sh): 1 = skip phase C, 2 = skip phases B and C,
-                              // 3 = everything but the counter atomics; 0 in production (never set by the product or the tests)
+    int32_t ablate;           // measurement builds compiled with -DSCG_ABLATE only (tools/ablate_build.sh): 1 = skip phase C,
+                              // 2 = skip phases B and C, 3 = everything but the counter atomics; the product library ignores it
 };
 
 struct ScgSingleParams {

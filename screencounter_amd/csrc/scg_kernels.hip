@@ -376,7 +376,9 @@ __device__ __forceinline__ int single_read_staged(const ScgSingleParams& P, cons
     const int max_mm = P.max_mm;
     uint32_t candF[NC], candR[NC];
     scan_read<NW, NC>(tile, sr, T, P.fwd != 0, P.rev != 0, candF, candR);
+#ifdef SCG_ABLATE
     if (ablate == 1) return (candF[0] ^ candR[NC - 1]) == 0x12345u ? 0 : -1;
+#endif
     int found = 0, index = -1, best = max_mm + 1;
     for (;;) {
         int pf = first_bit<NC>(candF), pr = first_bit<NC>(candR);
@@ -433,13 +435,18 @@ __global__ __launch_bounds__(STAGE_BLOCK) __attribute__((amdgpu_num_sgpr(80))) v
     sr.bit = (int)((int64_t)(rd.p - R.seqs) - span0);
     sr.n = rd.n;
     int idx;
+#ifdef SCG_ABLATE      // measurement builds only (phase ablation, tools/ablate_build.sh); never in the product library
     if (R.ablate == 2) {
         idx = (tile.p0[threadIdx.x] == 0xdeadbeefu) ? 0 : -1;
     } else {
         idx = single_read_staged<NW, NT, NC, W>(P, tile, strands, sr, R.ablate);
     }
+    if (R.ablate == 3 && idx != 0x7ffffff0 && !counts.unit_index) return;     // keep idx live, skip the atomic
+#else
+    idx = single_read_staged<NW, NT, NC, W>(P, tile, strands, sr);
+#endif
     if (counts.unit_index) counts.unit_index[r0 + threadIdx.x] = idx;
-    else if (idx >= 0 && !(R.ablate == 3 && idx != 0x7ffffff0)) count_one(counts, idx);     // (ablate 3: keep idx live, skip the atomic)
+    else if (idx >= 0) count_one(counts, idx);
 }
 
 template<int NW, int NT, int NC>

@@ -35,8 +35,18 @@ def test_header_symbols_are_exported(sc):
 def test_exports_nothing_else(sc):
     from screencounter_amd import _lib
     out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH], text=True)
-    exported = sorted(line.split()[-1] for line in out.splitlines() if " T " in line and line.split()[-1].startswith("scg_"))
+    # every defined dynamic symbol of any kind (T, W, D, B ...), not only the scg_-prefixed ones: the library is
+    # built with -fvisibility=hidden and a version script (csrc/scg.map), so C++ helpers, kernel stubs and
+    # libstdc++ instantiations must not leak
+    exported = sorted(line.split()[-1] for line in out.splitlines() if len(line.split()) >= 3)
     assert exported == declared_symbols()
+
+
+def test_no_ablation_switch_in_product():
+    """SCG_ABLATE (phase ablation, wrong counts by design) exists only in -DSCG_ABLATE measurement builds."""
+    from screencounter_amd import _lib
+    blob = open(_lib.LIB_PATH, "rb").read()
+    assert b"SCG_ABLATE" not in blob
 
 
 def test_no_oracle_in_product():

@@ -1,5 +1,7 @@
 #!/bin/bash
-# GPU box: VALU/SALU instruction counts of the headline kernel with phases switched off (SCG_ABLATE).
+# GPU box: VALU/SALU instruction counts of the headline kernel with phases switched off (SCG_ABLATE; needs the
+# measurement build of tools/ablate_build.sh, made in the container before gpurun).
+export SCG_LIB=$GRAFT_REPO_ROOT/tools/ablate/libscg_ablate.so
 cd /tmp && export TMPDIR=/tmp
 for A in 0 1 2; do
   OUT=$GRAFT_REPO_ROOT/gpurun_out/ablate_$A
