@@ -4,19 +4,27 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2] [--reads R]
 
 A *step* is one pass of the hot path (constant-flank scan -> variable-region extraction ->
-library match -> per-barcode atomic count [-> RCCL all-reduce of the count vectors when N > 1])
-over one batch of synthetic reads that is already resident in HBM.  At N = 1 the batch is
-BASELINE.json configs[1]: countSingleBarcodes, 100 M x 150 bp reads against a 100 k-barcode
-library, <=1 mismatch, both strands.  With N > 1 (launched by
-torch.distributed.run, one rank per GPU) every rank holds its own shard of that size (weak
+library match -> per-barcode count [-> RCCL all-reduce of the count vectors when N > 1]) over one
+batch of synthetic reads that is already resident in HBM.  At N = 1 the batch is BASELINE.json
+configs[1]: countSingleBarcodes, 100 M x 150 bp reads against a 100 k-barcode library, <= 1
+mismatch, both strands.  With N > 1 every rank holds its own shard of that size (weak
 scaling, no data-path collective other than the final count reduce).
+
+Launching.  `python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts its own
+ranks: a child `python -m torch.distributed.run --nproc-per-node N bench.py ...` is spawned BEFORE this
+process imports torch or touches HIP, its output is relayed and its exit code returned (a process that
+has initialised the GPU is never re-exec'ed).  Under torch.distributed.run (the driver's form) each rank
+reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment as usual.
 
 Rank 0 prints ONE JSON line: metric/value as BASELINE.json names them, plus
   roofline     -- algorithmic bytes (sum of read lengths) / average counting-kernel duration
                   measured with HIP events on the launch stream, against the 8 TB/s HBM peak
   cpu_baseline -- the reference CPU path (real kaori via oracle/_ref when present) timed on this
                   box's host cores on a bounded prefix of the same stream, N = 1 only, with the
-                  GPU counts on that prefix checked bit-exact against it.
+                  GPU counts on that prefix checked bit-exact against it
+  e2e          -- (N = 1) PCIe-inclusive rates on bounded samples of the same stream, never `value`:
+                  parsed batches in pinned host memory -> counts on the host (SURVEY.md 8d metric 1),
+                  and FASTQ file (tmpfs) -> counts through the file-level C ABI entry point.
 """
 from __future__ import annotations
 
@@ -24,6 +32,8 @@ import argparse
 import json
 import os
 import shutil
+import socket
+import subprocess
 import sys
 import tempfile
 import time
@@ -33,19 +43,81 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (guides/MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+KERNEL_OF = {"single": "single_staged_kernel", "combo": "combo_staged_kernel", "dual": "dual_staged_kernel"}
 
 
-def main() -> None:
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=500, help="timed steps (default 500: ~2 s of back-to-back launches)")
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--settle", type=float, default=1.5,
+                    help="seconds of untimed back-to-back steps after the warm-up, so that the timed steps run at sustained clocks")
     ap.add_argument("--config", type=int, default=2, help="BASELINE.json config: 2 single (default), 3 combo, 4 dual, 5 single <=2mm")
     ap.add_argument("--reads", type=int, default=None, help="reads (pairs) per GPU; default = the config's full size")
     ap.add_argument("--library", type=int, default=None, help="override the library size (tests only)")
     ap.add_argument("--cpu-sample", type=int, default=None, help="reads in the CPU-baseline sample (0 disables)")
-    ap.add_argument("--cpu-cores", type=int, default=16)
-    args = ap.parse_args()
+    ap.add_argument("--cpu-cores", type=int, default=None, help="worker processes of the CPU baseline (default: this lease's CPU share)")
+    ap.add_argument("--e2e-sample", type=int, default=None, help="reads in the pinned-batch end-to-end sample (0 disables)")
+    ap.add_argument("--e2e-file-sample", type=int, default=None, help="reads in the FASTQ-file end-to-end sample (0 disables)")
+    return ap.parse_args()
+
+
+def self_launch(args) -> None:
+    """--gpus N > 1 outside torch.distributed.run: become the launcher (before any GPU / torch import)."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    rc = subprocess.call(cmd, env=env, cwd=ROOT)
+    sys.exit(rc)
+
+
+def cpu_share():
+    """(cores to use, visible cores, why): the host cores this process may really occupy.  A 1-GPU lease of a
+    shared 8-GPU host sees every hardware thread but owns a share of them."""
+    visible = os.cpu_count() or 1
+    use, why = visible, "os.cpu_count()"
+    try:
+        aff = len(os.sched_getaffinity(0))
+        if aff < use:
+            use, why = aff, "sched_getaffinity"
+    except (AttributeError, OSError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            q = max(1, int(int(quota) / int(period)))
+            if q < use:
+                use, why = q, "cgroup cpu.max"
+    except (OSError, ValueError):
+        pass
+    cap = os.environ.get("SCG_BENCH_CPU_SHARE")
+    if cap:
+        return max(1, min(use, int(cap))), visible, "SCG_BENCH_CPU_SHARE"
+    if why == "os.cpu_count()":
+        # no quota is enforced: a lease of g of an 8-GPU host's cards owns g/8 of its hardware threads
+        # (256 threads / 8 = 32 per GPU on the MI355X hosts); --cpu-cores overrides
+        try:
+            import torch
+            g = max(1, min(8, torch.cuda.device_count()))
+        except Exception:
+            g = 8
+        if g < 8 and visible >= 64:
+            use, why = max(1, visible * g // 8), f"{g}/8 of {visible} visible hardware threads (1-GPU lease of an 8-GPU host)"
+    return use, visible, why
+
+
+def main() -> None:
+    args = parse_args()
+    self_launch(args)
 
     import numpy as np
     import torch
@@ -55,10 +127,15 @@ def main() -> None:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     # one rank per GPU; SCG_BENCH_SHARE_GPU=1 lets several ranks share a card (rehearsal on a 1-GPU box, gloo)
     share = os.environ.get("SCG_BENCH_SHARE_GPU") == "1"
-    dev_index = local_rank % max(torch.cuda.device_count(), 1) if share else local_rank
+    n_dev = torch.cuda.device_count()
+    if n_dev == 0:
+        raise SystemExit("bench.py needs a GPU: libscg has no CPU fallback")
+    if world > n_dev and not share:
+        raise SystemExit(f"--gpus {world} but only {n_dev} visible (SCG_BENCH_SHARE_GPU=1 rehearses ranks on one card over gloo)")
+    dev_index = local_rank % n_dev if share else local_rank
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     if world > 1:
@@ -84,6 +161,7 @@ def main() -> None:
     plan = dw.plan()
     counters = torch.zeros(plan.num_counters, dtype=torch.int32, device=device)
     plan.bind_counters(counters)
+    reduce_dev = counters if not share else None     # gloo rehearsal reduces a host copy
 
     def step():
         plan.reset()
@@ -92,10 +170,24 @@ def main() -> None:
         else:
             plan.count(mates[0], fixed_len=L, n_reads=n)
         if world > 1:
-            dist.all_reduce(counters, op=dist.ReduceOp.SUM)   # the path's one exchange step
+            if reduce_dev is not None:
+                dist.all_reduce(reduce_dev, op=dist.ReduceOp.SUM)   # the path's one exchange step
+            else:
+                h = counters.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM)
+                counters.copy_(h)
 
     for _ in range(args.warmup):
         step()
+    torch.cuda.synchronize()
+    # clocks: a 70 ms timed region right after start-up runs at boost clocks the chip does not sustain
+    settle_steps = 0
+    t_settle = time.perf_counter()
+    while time.perf_counter() - t_settle < args.settle:
+        for _ in range(10):
+            step()
+        settle_steps += 10
+        torch.cuda.synchronize()
     plan.set_profiling(True)
     if world > 1:
         dist.barrier()
@@ -108,7 +200,7 @@ def main() -> None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if not share else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kernel_ms, launches = plan.kernel_stats()
@@ -150,13 +242,15 @@ def main() -> None:
             "data": "synthetic",
             "config": {"workload": w.describe(), "reads_per_gpu": n, "read_len": L, "library": [len(p) for p in w.pools],
                        "max_mismatches": w.mismatches, "strand": ["forward", "reverse", "both"][w.strand] if w.entry != "dual" else "original/original",
-                       "parallelism": f"read-sharded x{world}" + (" + RCCL all-reduce of counts" if world > 1 else "")},
+                       "parallelism": f"read-sharded x{world}" + (" + RCCL all-reduce of counts" if world > 1 and not share else "")
+                                      + (" (gloo rehearsal, ranks share one GPU)" if share and world > 1 else ""),
+                       "inputs": "resident in HBM", "settle_s": args.settle, "settle_steps": settle_steps},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "kernel": f"{w.entry}_staged_kernel", "avg_kernel_ms": round(avg_kernel_s * 1e3, 4), "launches": launches,
+                         "kernel": KERNEL_OF[w.entry], "avg_kernel_ms": round(avg_kernel_s * 1e3, 4), "launches": launches,
                          "algorithmic_bytes_per_launch": algo_bytes, "traffic_source": traffic_source,
                          # the whole step (counting kernel + tally / fold kernel [+ all-reduce]) against the same peak
-                         "step_achieved": round(algo_bytes * world / (elapsed / args.steps) / 1e9 / world, 2),
+                         "step_achieved": round(algo_bytes / (elapsed / args.steps) / 1e9, 2),
                          "step_frac": round(algo_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 5)},
             "mapped_fraction": round(mapped / (n * world), 5),
         }
@@ -165,9 +259,11 @@ def main() -> None:
         if sample is None:
             sample = min(n, 50_000_000 if w.entry != "dual" else 20_000_000)
         if world == 1 and sample > 0:
-            sys.path.insert(0, ROOT)
             from oracle import cpu_baseline
             sample = min(sample, n)
+            cores, visible, why = cpu_share()
+            if args.cpu_cores:
+                cores, why = args.cpu_cores, "--cpu-cores"
             host = [m[:sample * L].cpu().numpy() for m in mates]
             # GPU counts on exactly the sample, for the same-run parity check
             plan.reset()
@@ -178,21 +274,112 @@ def main() -> None:
             gpu_counts, gpu_total = plan.read()
             workdir = tempfile.mkdtemp(prefix="scg_cpu_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
             try:
-                info, cpu_counts, cpu_total = cpu_baseline.run(w, host, args.cpu_cores, workdir)
+                info, cpu_counts, cpu_total = cpu_baseline.run(w, host, cores, workdir)
             finally:
                 shutil.rmtree(workdir, ignore_errors=True)
+            info["host_cores_visible"] = visible
+            info["cores_source"] = why
             info["parity"] = bool(gpu_total == cpu_total and np.array_equal(gpu_counts.astype(np.int64), cpu_counts))
             out["cpu_baseline"] = info
             if not info["parity"]:
                 out["cpu_baseline"]["parity_note"] = "GPU counts differ from the CPU reference on the sample"
+            del host
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
+
+        out["e2e"] = None
+        if world == 1:
+            try:
+                out["e2e"] = end_to_end(sc, synth, torch, np, w, plan, mates, args)
+            except Exception as e:      # the PCIe legs are informative; the headline line must still print
+                out["e2e"] = {"error": f"{type(e).__name__}: {e}"}
+        print(json.dumps(out), flush=True)
 
     plan.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def end_to_end(sc, synth, torch, np, w, plan, mates, args) -> dict:
+    """PCIe-inclusive legs on bounded samples of the benchmark stream (never `value`)."""
+    L, n = w.read_len, w.n_reads
+    unit = "Mpairs/s" if w.entry == "dual" else "Mreads/s"
+    res = {}
+    # (1) parsed batches in pinned host memory -> counts on the host: H2D copies on two streams overlapped with
+    #     the counting kernel, 4 M reads per batch like the file-level stager (SURVEY.md 8d metric 1)
+    s1 = args.e2e_sample
+    if s1 is None:
+        s1 = min(n, 24_000_000 if w.entry != "dual" else 12_000_000)
+    s1 = min(s1, n)
+    if s1 > 0:
+        pinned = [m[: s1 * L].cpu().pin_memory() for m in mates]
+        B = 1 << 22
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        bufs = [[torch.empty(B * L, dtype=torch.uint8, device=mates[0].device) for _ in mates] for _ in streams]
+        best = None
+        for rep in range(3):                        # first pass warms up
+            plan.reset()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for k, a in enumerate(range(0, s1, B)):
+                b = min(a + B, s1)
+                st = streams[k % 2]
+                with torch.cuda.stream(st):
+                    dst = [bufs[k % 2][m][: (b - a) * L] for m in range(len(mates))]
+                    for m in range(len(mates)):
+                        dst[m].copy_(pinned[m][a * L: b * L], non_blocking=True)
+                    if w.entry == "dual":
+                        plan.count_paired(dst[0], dst[1], fixed_len1=L, fixed_len2=L, n_pairs=b - a, stream=st)
+                    else:
+                        plan.count(dst[0], None, fixed_len=L, n_reads=b - a, stream=st)
+            for st in streams:
+                st.synchronize()
+            counts, total = plan.read()
+            dt = time.perf_counter() - t0
+            if rep and (best is None or dt < best):
+                best = dt
+        res["pinned_batches"] = {"value": round(s1 / best / 1e6, 2), "unit": unit, "pcie_gbs": round(s1 * w.bytes_per_unit / best / 1e9, 2),
+                                 "sample": f"first {s1} of the stream, 4 Mi-read batches, 2 streams, counts copied to the host",
+                                 "total": int(total), "mapped": int(counts.astype(np.int64).sum())}
+        del pinned, bufs
+    # (2) FASTQ file on tmpfs -> counts through the file-level C ABI entry (parse + stage + H2D + kernels + D2H)
+    s2 = args.e2e_file_sample
+    if s2 is None:
+        s2 = min(n, 8_000_000 if w.entry != "dual" else 4_000_000)
+    s2 = min(s2, n)
+    if s2 > 0:
+        d = tempfile.mkdtemp(prefix="scg_e2e_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+        try:
+            paths = []
+            for m, t in enumerate(mates):
+                p = os.path.join(d, f"reads_{m}.fastq")
+                synth.reads_to_fastq(p, t[: s2 * L].cpu().numpy(), L)
+                paths.append(p)
+            size = sum(os.path.getsize(p) for p in paths)
+
+            def call(pools, mm):
+                if w.entry == "single":
+                    c, t = sc.count_single_barcodes(paths[0], w.template, w.strand, pools[0], mm, w.use_first, 16)
+                    return int(c.astype(np.int64).sum()), t
+                if w.entry == "combo":
+                    _i, f, t = sc.count_combo_barcodes_single(paths[0], w.template, w.strand, pools, mm, w.use_first, 16)
+                    return int(f.astype(np.int64).sum()), t
+                c, t = sc.count_dual_barcodes(paths[0], w.template, False, mm, pools[0], paths[1], w.template2, False, mm, pools[1],
+                                              False, w.use_first, False, 16)
+                return int(c.astype(np.int64).sum()), t
+
+            call([p[:16] for p in w.pools], 0)                 # warm-up: context, page cache
+            t0 = time.perf_counter()
+            mapped, total = call(w.pools, w.mismatches)
+            dt = time.perf_counter() - t0
+            res["fastq_file"] = {"value": round(total / dt / 1e6, 2), "unit": unit, "fastq_gbs": round(size / dt / 1e9, 2),
+                                 "sample": f"first {s2} of the stream as plain 4-line FASTQ on tmpfs ({size / 1e9:.2f} GB), "
+                                           f"one {('scg_count_' + w.entry + '_barcodes')} call incl. library build",
+                                 "total": int(total), "mapped": mapped}
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return res
 
 
 if __name__ == "__main__":

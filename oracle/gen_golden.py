@@ -245,6 +245,29 @@ def fastq_cases(ref: KaoriRef, tmp: str) -> list:
     return out
 
 
+def config1_fixture(ref: KaoriRef, tmp: str) -> None:
+    """BASELINE.json configs[0] (countSingleBarcodes, 1 M x 75 bp, 1 k-barcode library, exact,
+    forward strand) run through real kaori on the benchmark generator's own stream (screencounter_amd.synth.generate_host,
+    byte-identical to the device generator).  The fixture holds the outputs and a digest of the inputs."""
+    import hashlib
+    from screencounter_amd import synth
+    w = synth.workload(1)
+    reads = synth.generate_host(w, w.n_reads)
+    fq = os.path.join(tmp, "config1.fastq")
+    synth.reads_to_fastq(fq, reads, w.read_len)
+    counts, total = ref.count_single(fq, w.template, w.strand, w.pools[0], w.mismatches, w.use_first, 1)
+    counts3, total3 = ref.count_single(fq, w.template, w.strand, w.pools[0], w.mismatches, w.use_first, 3)
+    assert total == total3 and (counts == counts3).all()
+    with open(os.path.join(OUT, "config1_kaori.json"), "w") as f:
+        json.dump({"generator": "oracle/gen_golden.py::config1_fixture", "reference": "kaori v1.1.1 (screenCounter 1.5.1)",
+                   "workload": w.describe(), "n_reads": w.n_reads, "read_len": w.read_len, "template": w.template,
+                   "strand": w.strand, "mismatches": w.mismatches, "use_first": w.use_first,
+                   "reads_sha256": hashlib.sha256(reads.tobytes()).hexdigest(),
+                   "pool_sha256": hashlib.sha256("\n".join(w.pools[0]).encode()).hexdigest(),
+                   "expect": {"counts": counts.tolist(), "total": int(total)}}, f)
+    print(f"config 1: {int(counts.sum())} of {total} reads mapped")
+
+
 def main() -> None:
     ref = KaoriRef()
     os.makedirs(OUT, exist_ok=True)
@@ -288,6 +311,7 @@ def main() -> None:
         fq = fastq_cases(ref, tmp)
         with open(os.path.join(OUT, "fastq_cases.json"), "w") as f:
             json.dump({"generator": "oracle/gen_golden.py", "reference": "kaori::FastqReader v1.1.1 over byteme v1.0.1", "cases": fq}, f, indent=1)
+        config1_fixture(ref, tmp)
     n_err = sum(1 for c in rnd if "error" in c["expect"])
     print(f"known answers: {len(ka)}  random: {len(rnd)} ({n_err} expected errors)  fastq: {len(fq)}")
     for c in fq:

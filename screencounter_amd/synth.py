@@ -210,6 +210,102 @@ class DeviceWorkload:
                          randomized=False, use_first=w.use_first, device=dev)
 
 
+# ---------------------------------------------------------------------------------------------
+# Host generator: a numpy restatement of synth_kernel (csrc/scg_kernels.hip), byte-identical to the
+# device generator for the same (workload, first_read, mate).  It exists so that CPU-only tiers (the
+# config-1 fixture, the gloo rehearsal, oracle tests) can produce the benchmark stream without a GPU;
+# tests/test_gpu_config_parity.py checks the two generators against each other.
+# ---------------------------------------------------------------------------------------------
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+class _SplitMix:
+    """splitmix64 streams, one per read, advanced only where `mask` is set (the device generator's draws
+    are data-dependent)."""
+
+    def __init__(self, state: np.ndarray):
+        self.s = state.astype(np.uint64)
+
+    def next(self, mask=None) -> np.ndarray:
+        with np.errstate(over="ignore"):
+            s = self.s + np.uint64(0x9E3779B97F4A7C15)
+            if mask is not None:
+                s = np.where(mask, s, self.s)
+            self.s = s
+            z = s
+            z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+            z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+            return z ^ (z >> np.uint64(31))
+
+    def u01(self, mask=None) -> np.ndarray:
+        return (self.next(mask) >> np.uint64(40)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+
+    def below(self, n: int, mask=None) -> np.ndarray:
+        return (((self.next(mask) >> np.uint64(32)) * np.uint64(n)) >> np.uint64(32)).astype(np.int64)
+
+
+def generate_host(w: Workload, n_reads: int, first_read: int = 0, mate: int = 0) -> np.ndarray:
+    """uint8 array of n_reads * read_len bytes: the same stream DeviceWorkload.generate produces."""
+    L = w.read_len
+    tmpl = w.template if mate == 0 else w.template2
+    T = len(tmpl)
+    regs = _regions(tmpl)
+    B = np.frombuffer(b"ACGT", dtype=np.uint8)
+    g = (np.arange(n_reads, dtype=np.uint64) + np.uint64(first_read))
+    with np.errstate(over="ignore"):
+        seed = np.uint64(w.seed)
+        shared = _SplitMix(seed ^ (g * np.uint64(0xD1342543DE82EF95)))
+        pair_column = mate if w.entry == "dual" else 0
+        priv = _SplitMix((seed + np.uint64(0x632BE59BD9B4E019) * np.uint64(pair_column + 1)) ^ (g * np.uint64(0xA0761D6478BD642F)))
+    junk = (shared.u01() < np.float32(w.p_junk)) | (T > L)
+    flip = shared.u01() < np.float32(w.p_reverse)
+    if w.entry == "dual":
+        pools = [np.frombuffer("".join(w.pools[mate]).encode(), dtype=np.uint8).reshape(len(w.pools[mate]), -1)]
+        invalid = shared.u01() < np.float32(w.p_invalid_pair)
+        row = shared.below(int(w.pair_index.shape[0]))
+        row2 = shared.below(int(w.pair_index.shape[0]))
+        r = np.where(invalid & (pair_column == 1), row2, row)
+        k = [w.pair_index[r, pair_column].astype(np.int64), None]
+    else:
+        pools = [np.frombuffer("".join(p).encode(), dtype=np.uint8).reshape(len(p), -1) for p in w.pools]
+        n0 = len(w.pools[0]) if len(w.pools) > 0 and len(w.pools[0]) > 0 else 1
+        n1 = len(w.pools[1]) if len(w.pools) > 1 and len(w.pools[1]) > 0 else 1
+        k = [shared.below(n0), shared.below(n1)]
+    offset = np.where(junk, 0, shared.below(max(L - T + 1, 1)))
+    tb = np.frombuffer(tmpl.encode(), dtype=np.uint8)
+    out = np.empty((n_reads, L), dtype=np.uint8)
+    code_of = np.zeros(256, dtype=np.int64)
+    code_of[ord("C")] = 1
+    code_of[ord("G")] = 2
+    code_of[ord("T")] = 3
+    p_sub, p_n = np.float32(w.p_sub), np.float32(w.p_n)
+    for j in range(L):
+        c = B[priv.below(4)]
+        t = j - offset
+        inside = ~junk & (t >= 0) & (t < T)
+        tt = np.clip(t, 0, T - 1)
+        tc = tb[tt]
+        cc = np.where(tc != ord("-"), tc, c)
+        for r, (st, ln) in enumerate(regs):
+            rel = tt - st
+            hit = inside & (rel >= 0) & (rel < ln)
+            if hit.any():
+                cc = np.where(hit, pools[r][np.where(hit, k[r], 0), np.clip(rel, 0, ln - 1)], cc)
+        c = np.where(inside, cc, c)
+        sub = inside & (priv.u01(inside) < p_sub)
+        if sub.any():
+            alt = B[(code_of[c] + 1 + priv.below(3, sub)) & 3]
+            c = np.where(sub, alt, c)
+        c = np.where(priv.u01() < p_n, np.uint8(ord("N")), c)
+        out[:, j] = c
+    if flip.any():
+        comp = np.arange(256, dtype=np.uint8)
+        for a, b in zip(b"ACGT", b"TGCA"):
+            comp[a] = b
+        out[flip] = comp[out[flip][:, ::-1]]
+    return out.reshape(-1)
+
+
 def reads_to_fastq(path: str, seqs: np.ndarray, read_len: int, start_index: int = 0) -> int:
     """Write fixed-length reads (uint8 array of n*read_len bytes) as a 4-line FASTQ; returns n."""
     n = seqs.size // read_len

@@ -16,7 +16,7 @@ def _count(plan, w, mates, a, b):
         plan.count(mates[0][a * L: b * L], fixed_len=L, n_reads=b - a)
 
 
-@pytest.mark.parametrize("config", [2, 3, 4])
+@pytest.mark.parametrize("config", [2, 3, 4, 5])
 def test_full_size_properties(sc, gpu, monkeypatch, config):
     import torch
     from screencounter_amd import synth

@@ -15,7 +15,7 @@ PASSES=(
 )
 i=0
 for P in "${PASSES[@]}"; do
-  timeout -k 10 240 rocprofv3 --kernel-trace --pmc $P --output-format csv -d $OUT/pass$i -- python3 $GRAFT_REPO_ROOT/bench.py --cpu-sample 0 "$@" > $OUT/pass$i.log 2>&1
+  timeout -k 10 240 rocprofv3 --kernel-trace --pmc $P --output-format csv -d $OUT/pass$i -- python3 $GRAFT_REPO_ROOT/bench.py --cpu-sample 0 --e2e-sample 0 --e2e-file-sample 0 --settle 0 "$@" > $OUT/pass$i.log 2>&1
   echo "pass$i rc=$? : $P"
   i=$((i+1))
 done

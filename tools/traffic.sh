@@ -6,7 +6,7 @@ for A in 2 0; do
   for C in FETCH_SIZE WRITE_SIZE "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_HIT_sum TCC_MISS_sum"; do
     TAG=$(echo $C | tr ' ' '_')
     OUT=$GRAFT_REPO_ROOT/gpurun_out/traffic_a${A}_$TAG
-    SCG_LIB=$GRAFT_REPO_ROOT/tools/ablate/libscg_ablate.so SCG_ABLATE=$A timeout -k 10 200 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT -- python3 $GRAFT_REPO_ROOT/bench.py --cpu-sample 0 --reads 20000000 --steps 2 --warmup 1 > $OUT.log 2>&1
+    SCG_LIB=$GRAFT_REPO_ROOT/tools/ablate/libscg_ablate.so SCG_ABLATE=$A timeout -k 10 200 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT -- python3 $GRAFT_REPO_ROOT/bench.py --cpu-sample 0 --e2e-sample 0 --e2e-file-sample 0 --settle 0 --reads 20000000 --steps 2 --warmup 1 > $OUT.log 2>&1
     python3 - <<PY
 import csv,glob
 from collections import defaultdict
