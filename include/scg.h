@@ -157,6 +157,41 @@ int scg_count_dual_barcodes_diagnostics(const char* path1, const char* constant1
                                         int32_t* barcode1_only_out, int32_t* barcode2_only_out,
                                         char* err, size_t errcap);
 
+/* ---------------------------------------------------------------------------------------------
+ * Many files in one call: what the matrixOf* functions of the reference do with BiocParallel workers, one
+ * file per worker (R/countSingleBarcodes.R:112-126, R/countComboBarcodes.R:149-164, R/countDualBarcodes.R:205-254).
+ * The template and the pools are compiled once, every device ($SCG_DEVICES, default: all visible) runs one file
+ * at a time and takes the next unprocessed one when it is done; results come back in file order.  Each file gives
+ * exactly what the single-file entry point gives for it; the error of the lowest-numbered failing file is reported.
+ * ------------------------------------------------------------------------------------------- */
+
+/* counts_out: n_pool x n_files, column-major (column f = file f: the `counts` assay of matrixOfSingleBarcodes
+ * before its cbind, R/countSingleBarcodes.R:114-117); totals_out: n_files. */
+int scg_count_single_barcodes_files(const char* const* paths, int32_t n_files, const char* constant, int strand,
+                                    const char* const* pool, int32_t n_pool,
+                                    int mismatches, int use_first, int nthreads,
+                                    int32_t* counts_out, int32_t* totals_out,
+                                    char* err, size_t errcap);
+
+/* indices_out / freq_out / k_out: n_files entries each, caller-allocated arrays; entry f receives file f's malloc'd
+ * 2 x K_f matrix, K_f frequencies and K_f exactly as scg_count_combo_barcodes_single returns them (release every
+ * entry with scg_free).  The caller merges them as combineComboCounts does (R/combineComboCounts.R:31-57). */
+int scg_count_combo_barcodes_single_files(const char* const* paths, int32_t n_files, const char* constant, int strand,
+                                          const char* const* pool0, int32_t n_pool0,
+                                          const char* const* pool1, int32_t n_pool1,
+                                          int mismatches, int use_first, int nthreads,
+                                          int32_t** indices_out, int32_t** freq_out, int64_t* k_out,
+                                          int32_t* totals_out, char* err, size_t errcap);
+
+/* counts_out: n_pool x n_files, column-major; totals_out: n_files (the `npairs` of R/countDualBarcodes.R:236). */
+int scg_count_dual_barcodes_files(const char* const* paths1, const char* constant1, int reverse1, int mismatches1,
+                                  const char* const* pool1,
+                                  const char* const* paths2, const char* constant2, int reverse2, int mismatches2,
+                                  const char* const* pool2, int32_t n_pool, int32_t n_files,
+                                  int randomized, int use_first, int nthreads,
+                                  int32_t* counts_out, int32_t* totals_out,
+                                  char* err, size_t errcap);
+
 /* matchBarcodes.  Replaces src/match_barcodes.cpp:6-37.  index_out[i] is the 0-based index of the
  * unique best choice within `substitutions` mismatches or -1 (R: NA); mismatches_out likewise. */
 int scg_match_barcodes(const char* const* sequences, int32_t n_sequences,
@@ -175,6 +210,17 @@ void scg_free(void* p);
  * ------------------------------------------------------------------------------------------- */
 int scg_parse_fastq(const char* path, char** seqs_out, uint64_t** offsets_out, int64_t* n_reads_out,
                     char* err, size_t errcap);
+
+/* The raw-text side of the staging (host only, no device needed): the windows in which the file-level entry points
+ * ship a FASTQ file to the GPU for the device-side record scan -- plain files copied from the page cache, BGZF
+ * ("blocked gzip", as written by bgzip: members carry their size) inflated member-parallel, any other gzip through
+ * one zlib stream.  Every window holds whole records.  On success *text_out is the malloc'd concatenation of the
+ * windows (= the decompressed file, plus a final newline if it lacked one), *cuts_out the n_windows + 1 window
+ * boundaries within it, kind_out[16] "plain" / "bgzf" / "gzip"; release both with scg_free.  SCG_ERR_UNSUPPORTED when
+ * the text cannot be cut at record boundaries (multi-line records ...): such files take the sequential reader. */
+int scg_fastq_text_windows(const char* path, int64_t window_bytes, int nthreads,
+                           char** text_out, int64_t* n_bytes_out, int64_t** cuts_out, int64_t* n_windows_out,
+                           char* kind_out, char* err, size_t errcap);
 
 /* ---------------------------------------------------------------------------------------------
  * Plans: a compiled (template, library, options) bound to one device, reusable across batches.

@@ -10,7 +10,8 @@ Package contents (only what the path needs):
 """
 from ._lib import ScgError, load  # noqa: F401
 from .api import (  # noqa: F401
-    count_single_barcodes, count_combo_barcodes_single, count_dual_barcodes, count_combo_barcodes_paired, count_dual_barcodes_single_end, count_random_barcodes, match_barcodes, parse_fastq,
+    count_single_barcodes, count_combo_barcodes_single, count_dual_barcodes, count_combo_barcodes_paired,
+    count_single_barcodes_files, count_combo_barcodes_single_files, count_dual_barcodes_files, count_dual_barcodes_single_end, count_random_barcodes, match_barcodes, parse_fastq,
     countSingleBarcodes, countComboBarcodes, countDualBarcodes, countPairedComboBarcodes, countDualBarcodesSingleEnd, countRandomBarcodes, matchBarcodes,
     matrixOfSingleBarcodes, matrixOfComboBarcodes, matrixOfDualBarcodes, matrixOfPairedComboBarcodes, matrixOfDualBarcodesSingleEnd, matrixOfRandomBarcodes, combineComboCounts, parseBarcodeTemplate,
 )

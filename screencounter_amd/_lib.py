@@ -58,6 +58,16 @@ SIGNATURES = {
                                           C.c_char_p, C.c_char_p, C.c_int, C.c_int, c_str_p, C.c_int32,
                                           C.c_int, C.c_int, C.c_int, C.c_int, i32_p, i32_p, C.c_char_p, C.c_size_t]),
     "scg_match_barcodes": (C.c_int, [c_str_p, C.c_int32, c_str_p, C.c_int32, C.c_int, C.c_int, i32_p, i32_p, C.c_char_p, C.c_size_t]),
+    "scg_count_single_barcodes_files": (C.c_int, [c_str_p, C.c_int32, C.c_char_p, C.c_int, c_str_p, C.c_int32, C.c_int, C.c_int, C.c_int,
+                                                  i32_p, i32_p, C.c_char_p, C.c_size_t]),
+    "scg_count_combo_barcodes_single_files": (C.c_int, [c_str_p, C.c_int32, C.c_char_p, C.c_int, c_str_p, C.c_int32, c_str_p, C.c_int32,
+                                                        C.c_int, C.c_int, C.c_int, C.POINTER(i32_p), C.POINTER(i32_p), i64_p, i32_p,
+                                                        C.c_char_p, C.c_size_t]),
+    "scg_count_dual_barcodes_files": (C.c_int, [c_str_p, C.c_char_p, C.c_int, C.c_int, c_str_p,
+                                                c_str_p, C.c_char_p, C.c_int, C.c_int, c_str_p, C.c_int32, C.c_int32,
+                                                C.c_int, C.c_int, C.c_int, i32_p, i32_p, C.c_char_p, C.c_size_t]),
+    "scg_fastq_text_windows": (C.c_int, [C.c_char_p, C.c_int64, C.c_int, C.POINTER(C.c_void_p), i64_p, C.POINTER(C.c_void_p), i64_p,
+                                         C.c_char_p, C.c_char_p, C.c_size_t]),
     "scg_free": (None, [C.c_void_p]),
     "scg_parse_fastq": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), i64_p, C.c_char_p, C.c_size_t]),
     "scg_plan_single": (C.c_int, [C.POINTER(C.c_void_p), C.c_char_p, C.c_int, c_str_p, C.c_int32, C.c_int, C.c_int, C.c_int,

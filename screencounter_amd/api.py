@@ -75,6 +75,113 @@ def count_combo_barcodes_single(path: str, constant: str, strand: int, pool: Seq
     return idx.astype(np.int32), freq.astype(np.int32), int(total.value)
 
 
+import contextlib
+
+
+@contextlib.contextmanager
+def _devices_env(devices):
+    """`devices=` of the matrixOf* mirrors -> $SCG_DEVICES for the duration of one native call (the C ABI's device
+    list; an id may repeat to keep several files in flight on one card)."""
+    if devices is None:
+        yield
+        return
+    old = os.environ.get("SCG_DEVICES")
+    os.environ["SCG_DEVICES"] = ",".join(str(int(d)) for d in devices)
+    try:
+        yield
+    finally:
+        if old is None:
+            os.environ.pop("SCG_DEVICES", None)
+        else:
+            os.environ["SCG_DEVICES"] = old
+
+
+def count_single_barcodes_files(paths: Sequence[str], constant: str, strand: int, pool: Sequence[str], mismatches: int,
+                                use_first: bool, nthreads: int = 1, devices=None):
+    """scg_count_single_barcodes_files: every file of matrixOfSingleBarcodes in one native call
+    -> (counts int32[len(pool), len(paths)], totals list)."""
+    L = _lib.load()
+    n = len(paths)
+    counts = np.zeros((max(n, 1), max(len(pool), 1)), dtype=np.int32)      # row f = column f of the column-major output
+    totals = (C.c_int32 * max(n, 1))()
+    err = errbuf()
+    parr, _keep = cstr_array(pool)
+    farr, _fk = cstr_array([os.fspath(x) for x in paths])
+    with _devices_env(devices):
+        check(L.scg_count_single_barcodes_files(farr, n, constant.encode(), int(strand), parr, len(pool), int(mismatches),
+                                                int(bool(use_first)), int(nthreads), _files_out(counts, len(pool)), totals,
+                                                err, _lib.ERRCAP), err)
+    return _files_matrix(counts, len(pool), n), [int(totals[i]) for i in range(n)]
+
+
+def _files_out(buf: np.ndarray, n_pool: int):
+    """A contiguous int32 buffer of n_pool * n_files entries inside `buf` (allocated with >= 1 row / column)."""
+    return buf.reshape(-1).ctypes.data_as(_lib.i32_p)
+
+
+def _files_matrix(buf: np.ndarray, n_pool: int, n_files: int) -> np.ndarray:
+    flat = buf.reshape(-1)[: n_pool * n_files]
+    return flat.reshape(n_files, n_pool).T.copy()          # column-major n_pool x n_files -> [n_pool, n_files]
+
+
+def count_combo_barcodes_single_files(paths: Sequence[str], constant: str, strand: int, pool: Sequence[Sequence[str]], mismatches: int,
+                                      use_first: bool, nthreads: int = 1, devices=None):
+    """scg_count_combo_barcodes_single_files -> list of (indices int32[2, K], freq int32[K], total), one per file."""
+    if len(pool) != 2:
+        raise ScgError(_lib.SCG_ERR_INVALID, "currently expecting only 2 variable regions for single-end combinatorial barcodes")
+    L = _lib.load()
+    n = len(paths)
+    idx = (_lib.i32_p * max(n, 1))()
+    freq = (_lib.i32_p * max(n, 1))()
+    ks = (C.c_int64 * max(n, 1))()
+    totals = (C.c_int32 * max(n, 1))()
+    err = errbuf()
+    p0, _k0 = cstr_array(pool[0])
+    p1, _k1 = cstr_array(pool[1])
+    farr, _fk = cstr_array([os.fspath(x) for x in paths])
+    with _devices_env(devices):
+        check(L.scg_count_combo_barcodes_single_files(farr, n, constant.encode(), int(strand), p0, len(pool[0]), p1, len(pool[1]),
+                                                      int(mismatches), int(bool(use_first)), int(nthreads), idx, freq, ks, totals,
+                                                      err, _lib.ERRCAP), err)
+    out = []
+    try:
+        for f in range(n):
+            K = int(ks[f])
+            i2 = np.ctypeslib.as_array(idx[f], shape=(max(2 * K, 1),))[:2 * K].reshape(K, 2).T.copy() if K else np.zeros((2, 0), dtype=np.int32)
+            fr = np.ctypeslib.as_array(freq[f], shape=(max(K, 1),))[:K].copy() if K else np.zeros(0, dtype=np.int32)
+            out.append((i2.astype(np.int32), fr.astype(np.int32), int(totals[f])))
+    finally:
+        for f in range(n):
+            L.scg_free(idx[f])
+            L.scg_free(freq[f])
+    return out
+
+
+def count_dual_barcodes_files(paths1: Sequence[str], constant1: str, reverse1: bool, mismatches1: int, pool1: Sequence[str],
+                              paths2: Sequence[str], constant2: str, reverse2: bool, mismatches2: int, pool2: Sequence[str],
+                              randomized: bool, use_first: bool, nthreads: int = 1, devices=None):
+    """scg_count_dual_barcodes_files -> (counts int32[len(pool1), n_files], totals list)."""
+    if len(pool1) != len(pool2):
+        raise ScgError(_lib.SCG_ERR_INVALID, "both barcode pools should be of the same length")
+    if len(paths1) != len(paths2):
+        raise ValueError("paths1 and paths2 differ in length")
+    L = _lib.load()
+    n = len(paths1)
+    counts = np.zeros((max(n, 1), max(len(pool1), 1)), dtype=np.int32)
+    totals = (C.c_int32 * max(n, 1))()
+    err = errbuf()
+    a1, _k1 = cstr_array(pool1)
+    a2, _k2 = cstr_array(pool2)
+    f1, _fk1 = cstr_array([os.fspath(x) for x in paths1])
+    f2, _fk2 = cstr_array([os.fspath(x) for x in paths2])
+    with _devices_env(devices):
+        check(L.scg_count_dual_barcodes_files(f1, constant1.encode(), int(bool(reverse1)), int(mismatches1), a1,
+                                              f2, constant2.encode(), int(bool(reverse2)), int(mismatches2), a2, len(pool1), n,
+                                              int(bool(randomized)), int(bool(use_first)), int(nthreads),
+                                              _files_out(counts, len(pool1)), totals, err, _lib.ERRCAP), err)
+    return _files_matrix(counts, len(pool1), n), [int(totals[i]) for i in range(n)]
+
+
 def count_dual_barcodes(path1: str, constant1: str, reverse1: bool, mismatches1: int, pool1: Sequence[str],
                         path2: str, constant2: str, reverse2: bool, mismatches2: int, pool2: Sequence[str],
                         randomized: bool, use_first: bool, diagnostics: bool = False, nthreads: int = 1):
@@ -333,12 +440,25 @@ def _map_files(fn, files, devices=None, jobs_per_device: int = 1):
         return list(pool.map(job, files))
 
 
-def matrixOfSingleBarcodes(files: Sequence[str], choices: Sequence[str], withDimnames: bool = True, devices=None, jobs_per_device: int = 1, **kwargs) -> CountMatrix:
-    """R/countSingleBarcodes.R:112-126; files are spread over the visible GPUs (`devices`)."""
-    out = _map_files(lambda f: countSingleBarcodes(f, choices, **kwargs), files, devices, jobs_per_device)
-    mat = np.stack([o.counts for o in out], axis=1) if out else np.zeros((len(choices), 0), dtype=np.int32)
+def matrixOfSingleBarcodes(files: Sequence[str], choices: Sequence[str], withDimnames: bool = True, devices=None, jobs_per_device: int = 1,
+                           flank5: str = "", flank3: str = "", template: Optional[str] = None, substitutions: int = 0, find_best: bool = False,
+                           strand: str = "both", num_threads: int = 1) -> CountMatrix:
+    """R/countSingleBarcodes.R:112-126.  The files are scheduled over the GPUs INSIDE one native call
+    (scg_count_single_barcodes_files: library compiled once, one file at a time per device, results in file order)
+    instead of BiocParallel worker processes; `devices` / `jobs_per_device` become its device list."""
+    files = list(files)
+    choices = list(choices)
+    if template is not None:
+        template = template.replace("N", "-")
+    else:
+        template = flank5 + "-" * (len(choices[0]) if choices else 0) + flank3
+    if devices is not None:
+        devices = [d for d in devices for _ in range(max(int(jobs_per_device), 1))]
+    elif jobs_per_device > 1:
+        devices = [d for d in range(max(int(_lib.load().scg_device_count()), 1)) for _ in range(int(jobs_per_device))]
+    mat, totals = count_single_barcodes_files(files, template, _strand_code(strand), choices, substitutions, not find_best, num_threads, devices)
     se = CountMatrix(counts=mat, row_data={"choices": list(choices)},
-                     col_data={"paths": list(files), "nreads": [o.nreads for o in out], "nmapped": mat.sum(axis=0).astype(np.int64).tolist()})
+                     col_data={"paths": list(files), "nreads": totals, "nmapped": mat.sum(axis=0).astype(np.int64).tolist()})
     if withDimnames:
         se.rownames = list(choices)
         se.colnames = [os.path.basename(f) for f in files]
@@ -355,9 +475,8 @@ def parseBarcodeTemplate(template: str):
     return {"variable": {"pos": pos, "len": lens}, "constant": constants}
 
 
-def countComboBarcodes(fastq: str, template: str, choices, substitutions: int = 0, find_best: bool = False,
-                       strand: str = "both", num_threads: int = 1, indices: bool = False) -> ComboCounts:
-    """R/countComboBarcodes.R:87-124.  `choices` is a list of two pools or a dict name -> pool."""
+def _combo_setup(template: str, choices, strand: str):
+    """Argument handling of R/countComboBarcodes.R:87-118 -> (names, pools, native template, strand code)."""
     if isinstance(choices, dict):
         names = list(choices.keys())
         pools = [list(v) for v in choices.values()]
@@ -374,14 +493,24 @@ def countComboBarcodes(fastq: str, template: str, choices, substitutions: int = 
     for i in range(nvariables):                                     # :111-115
         if not all(len(s) == n_len[i] for s in pools[i]):
             raise ScgError(_lib.SCG_ERR_INVALID, "each column of 'choices' must have same width as variable region in 'template'")
-    idx, freq, total = count_combo_barcodes_single(fastq, template.replace("N", "-"), _strand_code(strand), pools,
-                                                   substitutions, not find_best, num_threads)
+    return names, pools, template.replace("N", "-"), _strand_code(strand)
+
+
+def _combo_result(names, pools, indices: bool, idx, freq, total) -> ComboCounts:
     keys = idx + 1                                                  # :128
     combos: Dict[str, list] = {}
     for i, nm in enumerate(names):
         col = keys[i].tolist()
         combos[nm] = col if indices else [pools[i][k - 1] for k in col]   # :136-140
     return ComboCounts(names=names, combinations=combos, counts=freq, nreads=total)
+
+
+def countComboBarcodes(fastq: str, template: str, choices, substitutions: int = 0, find_best: bool = False,
+                       strand: str = "both", num_threads: int = 1, indices: bool = False) -> ComboCounts:
+    """R/countComboBarcodes.R:87-124.  `choices` is a list of two pools or a dict name -> pool."""
+    names, pools, native_template, strand_code = _combo_setup(template, choices, strand)
+    idx, freq, total = count_combo_barcodes_single(fastq, native_template, strand_code, pools, substitutions, not find_best, num_threads)
+    return _combo_result(names, pools, indices, idx, freq, total)
 
 
 def combineComboCounts(*results: ComboCounts):
@@ -397,9 +526,23 @@ def combineComboCounts(*results: ComboCounts):
     return combos, mat
 
 
-def matrixOfComboBarcodes(files: Sequence[str], withDimnames: bool = True, devices=None, jobs_per_device: int = 1, **kwargs) -> CountMatrix:
-    """R/countComboBarcodes.R:149-164."""
-    out = _map_files(lambda f: countComboBarcodes(f, **kwargs), files, devices, jobs_per_device)
+def _device_jobs(devices, jobs_per_device: int):
+    if devices is not None:
+        return [d for d in devices for _ in range(max(int(jobs_per_device), 1))]
+    if jobs_per_device > 1:
+        return [d for d in range(max(int(_lib.load().scg_device_count()), 1)) for _ in range(int(jobs_per_device))]
+    return None
+
+
+def matrixOfComboBarcodes(files: Sequence[str], template: str, choices, substitutions: int = 0, find_best: bool = False, strand: str = "both",
+                          num_threads: int = 1, indices: bool = False, withDimnames: bool = True, devices=None, jobs_per_device: int = 1) -> CountMatrix:
+    """R/countComboBarcodes.R:149-164: all files in one native call (scg_count_combo_barcodes_single_files), then
+    combineComboCounts (R/combineComboCounts.R:31-57)."""
+    files = list(files)
+    names, pools, native_template, strand_code = _combo_setup(template, choices, strand)
+    per_file = count_combo_barcodes_single_files(files, native_template, strand_code, pools, substitutions, not find_best, num_threads,
+                                                 _device_jobs(devices, jobs_per_device))
+    out = [_combo_result(names, pools, indices, idx, freq, total) for idx, freq, total in per_file]
     combos, mat = combineComboCounts(*out)
     se = CountMatrix(counts=mat, row_data=combos,
                      col_data={"paths": list(files), "nreads": [o.nreads for o in out], "nmapped": mat.sum(axis=0).astype(np.int64).tolist()})
@@ -416,10 +559,8 @@ def _rep2(x):
     return [x[i % len(x)] for i in range(2)]
 
 
-def countDualBarcodes(fastq: Sequence[str], choices, flank5=None, flank3=None, template=None, substitutions=0,
-                      find_best: bool = False, strand="original", randomized: bool = False, include_invalid: bool = False,
-                      num_threads: int = 1) -> DualCounts:
-    """R/countDualBarcodes.R:118-160.  `choices` is a dict / pair of two equally long columns."""
+def _dual_setup(choices, flank5, flank3, template, substitutions, strand):
+    """Argument handling of R/countDualBarcodes.R:118-182 -> (names, col1, col2, template1, template2, subs[2], reverse[2])."""
     if isinstance(choices, dict):
         names = list(choices.keys())
         col1, col2 = [list(v) for v in choices.values()]
@@ -433,13 +574,20 @@ def countDualBarcodes(fastq: Sequence[str], choices, flank5=None, flank3=None, t
         f5, f3 = _rep2(flank5), _rep2(flank3)
         template1 = f5[0] + "-" * len(col1[0]) + f3[0]
         template2 = f5[1] + "-" * len(col2[0]) + f3[1]
-    subs = _rep2(substitutions)
+    subs = [int(x) for x in _rep2(substitutions)]
     strands = _rep2(strand)
-    for s in strands:                                               # :176-182
-        if s not in ("original", "reverse"):
+    for st in strands:                                              # :176-182
+        if st not in ("original", "reverse"):
             raise ValueError("'strand' should be one of 'original', 'reverse'")
-    out = count_dual_barcodes(fastq[0], template1, strands[0] == "reverse", int(subs[0]), col1,
-                              fastq[1], template2, strands[1] == "reverse", int(subs[1]), col2,
+    return names, col1, col2, template1, template2, subs, [st == "reverse" for st in strands]
+
+
+def countDualBarcodes(fastq: Sequence[str], choices, flank5=None, flank3=None, template=None, substitutions=0,
+                      find_best: bool = False, strand="original", randomized: bool = False, include_invalid: bool = False,
+                      num_threads: int = 1) -> DualCounts:
+    """R/countDualBarcodes.R:118-160.  `choices` is a dict / pair of two equally long columns."""
+    names, col1, col2, template1, template2, subs, rev = _dual_setup(choices, flank5, flank3, template, substitutions, strand)
+    out = count_dual_barcodes(fastq[0], template1, rev[0], subs[0], col1, fastq[1], template2, rev[1], subs[1], col2,
                               randomized, not find_best, include_invalid, num_threads)
     if not include_invalid:
         counts, total = out
@@ -453,13 +601,26 @@ def countDualBarcodes(fastq: Sequence[str], choices, flank5=None, flank3=None, t
                       barcode1_only=b1, barcode2_only=b2, invalid_pair=int(freq.sum()))
 
 
-def matrixOfDualBarcodes(files: Sequence[Sequence[str]], choices, withDimnames: bool = True, devices=None, jobs_per_device: int = 1, **kwargs) -> CountMatrix:
-    """R/countDualBarcodes.R:205-224 (include.invalid=FALSE)."""
-    out = _map_files(lambda f: countDualBarcodes(f, choices, **kwargs), files, devices, jobs_per_device)
-    nrow = len(out[0].counts) if out else 0
-    mat = np.stack([o.counts for o in out], axis=1) if out else np.zeros((nrow, 0), dtype=np.int32)
-    se = CountMatrix(counts=mat, row_data=out[0].choices if out else {},
-                     col_data={"paths1": [f[0] for f in files], "paths2": [f[1] for f in files], "npairs": [o.npairs for o in out]})
+def matrixOfDualBarcodes(files: Sequence[Sequence[str]], choices, withDimnames: bool = True, devices=None, jobs_per_device: int = 1,
+                         flank5=None, flank3=None, template=None, substitutions=0, find_best: bool = False, strand="original",
+                         randomized: bool = False, include_invalid: bool = False, num_threads: int = 1) -> CountMatrix:
+    """R/countDualBarcodes.R:205-224: all file pairs in one native call (scg_count_dual_barcodes_files); with
+    include.invalid=TRUE the rows differ from file to file (:226-254), so the pairs are counted one call each."""
+    files = [list(f) for f in files]
+    if include_invalid:
+        out = _map_files(lambda f: countDualBarcodes(f, choices, flank5, flank3, template, substitutions, find_best, strand, randomized,
+                                                     True, num_threads), files, devices, jobs_per_device)
+        mat = np.stack([o.counts for o in out], axis=1) if out else np.zeros((0, 0), dtype=np.int32)
+        row_data = out[0].choices if out else {}
+        npairs = [o.npairs for o in out]
+    else:
+        names, col1, col2, template1, template2, subs, rev = _dual_setup(choices, flank5, flank3, template, substitutions, strand)
+        mat, npairs = count_dual_barcodes_files([f[0] for f in files], template1, rev[0], subs[0], col1,
+                                                [f[1] for f in files], template2, rev[1], subs[1], col2,
+                                                randomized, not find_best, num_threads, _device_jobs(devices, jobs_per_device))
+        row_data = {names[0]: col1, names[1]: col2}
+    se = CountMatrix(counts=mat, row_data=row_data,
+                     col_data={"paths1": [f[0] for f in files], "paths2": [f[1] for f in files], "npairs": npairs})
     if withDimnames:
         se.colnames = [os.path.basename(f[0]) for f in files]
     return se

@@ -14,6 +14,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
+#include <atomic>
+#include <sys/stat.h>
 #include <memory>
 #include <string>
 #include <functional>
@@ -22,7 +25,9 @@
 #include <vector>
 
 #include "scg_host.h"
+#include "scg_ingest.h"
 #include "scg_launch.h"
+#include "scg_textscan.h"
 
 using scg::Error;
 
@@ -587,7 +592,7 @@ void launch_batch(scg_plan* P, const ScgReads& R, int64_t n, hipStream_t stream)
         sp.index = P->tab[0].view;
         sp.max_mm = P->max_mm1; sp.use_first = P->use_first;
         sp.fwd = P->ht1.fwd; sp.rev = P->ht1.rev;
-        ScgCounters counts = plan_counters(P);
+            ScgCounters counts = plan_counters(P);
         const bool tally = use_tally(P, n) && R.max_len > 0 && R.max_len <= 320 && !scg::force_general();
         if (tally) {
             DevBuf& buf = P->unit_index[stream];              // batches on different streams may be in flight together
@@ -798,6 +803,150 @@ void count_single_end_file(scg_plan* P, const char* path, scg::FastqStream& fq, 
     st.drain();
 }
 
+// -------------------------------------------------------------------------------------------------
+// Device-scan pipeline (single-end): raw FASTQ text -> pinned window -> HBM -> record scan -> counting kernels.
+//
+// The host moves bytes only (scg_ingest.cpp: file pages or inflated gzip blocks, cut at record boundaries); the
+// records are found and validated on the GPU (scg_textscan.hip), so the text crosses PCIe once and no host thread
+// parses it.  Windows go round-robin over the plans (one per device), each device working through a few slots with
+// their own streams: while window k is copied and scanned, the host fills window k + 1 and the counting kernels of
+// window k - 1 run.  Replaces kaori::process_single_end_data (process_data.hpp:105-190).  Anything the scan reports
+// as out of the ordinary raises UnusualInput and the caller redoes the file with the sequential reader.
+// -------------------------------------------------------------------------------------------------
+struct UnusualInput {};
+
+struct ScanSlot {
+    scg_plan* plan = nullptr;
+    hipStream_t stream = nullptr;
+    PinnedBuf text, h_result;
+    DevBuf d_text, d_counts, d_nl, d_offsets, d_seqs, d_result;
+    scg::TextScanBuffers B;
+    size_t cap = 0;
+    bool pending = false;      // scan enqueued; the counting kernels still have to be launched
+    bool busy = false;         // work of an earlier window may still be running on the stream
+
+    void init(scg_plan* P, size_t window) {
+        plan = P;
+        cap = window;
+        DeviceGuard g(P->device);
+        HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        text.ensure(cap);
+        h_result.ensure(sizeof(scg::TextScanResult));
+        B.cap_blocks = scg::text_scan_blocks(cap) + 1;
+        B.cap_lines = cap / 16 + 1024;              // lines shorter than 16 bytes on average: left to the sequential reader
+        B.cap_records = B.cap_lines / 4 + 1;
+        B.cap_seq_bytes = cap / 2 + 64;
+        d_text.alloc(scg::text_scan_padded(cap) + 16);
+        d_counts.alloc(B.cap_blocks * sizeof(uint32_t));
+        d_nl.alloc(B.cap_lines * sizeof(uint32_t));
+        d_offsets.alloc((B.cap_records + 1) * sizeof(uint32_t));
+        d_seqs.alloc(B.cap_seq_bytes + 64);
+        d_result.alloc(sizeof(scg::TextScanResult));
+        B.block_counts = d_counts.as<uint32_t>();
+        B.nl = d_nl.as<uint32_t>();
+        B.offsets = d_offsets.as<uint32_t>();
+        B.seqs = d_seqs.as<char>();
+        B.result = d_result.as<scg::TextScanResult>();
+    }
+    ~ScanSlot() {
+        if (stream) {
+            int prev = -1;
+            if (plan && hipGetDevice(&prev) == hipSuccess && prev != plan->device) (void)hipSetDevice(plan->device); else prev = -1;
+            (void)hipStreamSynchronize(stream);
+            (void)hipStreamDestroy(stream);
+            if (prev >= 0) (void)hipSetDevice(prev);
+        }
+    }
+};
+
+size_t scan_window_bytes(uint64_t hint) {
+    size_t w = size_t(128) << 20;
+    if (const char* e = std::getenv("SCG_WINDOW_KB")) {          // test hook: tiny windows force many hand-overs
+        const long kb = std::atol(e);
+        if (kb > 0) w = static_cast<size_t>(kb) << 10;
+    }
+    const size_t floor = std::getenv("SCG_WINDOW_KB") ? size_t(4) << 10 : scg::TextSource::min_capacity();
+    const uint64_t need = hint + (hint >> 4) + 4096;             // the whole input in one window when it is small
+    if (need < w) w = static_cast<size_t>(need);
+    return std::max(w, floor);
+}
+
+void count_text_stream(const std::vector<scg_plan*>& plans, scg::TextSource& src) {
+    const int slots_per_plan = 3;
+    const size_t window = scan_window_bytes(src.size_hint());
+    std::vector<std::unique_ptr<ScanSlot> > slots;
+    for (int k = 0; k < slots_per_plan; ++k) {
+        for (scg_plan* P : plans) {
+            slots.emplace_back(new ScanSlot);
+            slots.back()->init(P, window);
+        }
+    }
+    auto finish = [&](ScanSlot& s) {
+        DeviceGuard g(s.plan->device);
+        HIP_CHECK(hipStreamSynchronize(s.stream));                // copy + scan + result are in
+        s.pending = false;
+        const scg::TextScanResult r = *s.h_result.as<scg::TextScanResult>();
+        if (r.flags) throw UnusualInput();
+        if (r.n_records) {
+            launch_batch(s.plan, make_reads(s.B.seqs, s.B.offsets, 0, static_cast<int32_t>(std::min<uint32_t>(r.max_len, 1u << 30))),
+                         static_cast<int64_t>(r.n_records), s.stream);
+        }
+        s.busy = true;
+    };
+    ScanSlot* prev = nullptr;
+    for (size_t k = 0;; ++k) {
+        ScanSlot& s = *slots[k % slots.size()];
+        DeviceGuard g(s.plan->device);
+        if (s.busy) { HIP_CHECK(hipStreamSynchronize(s.stream)); s.busy = false; }
+        const size_t bytes = src.next(s.text.as<char>(), s.cap);
+        if (src.unusual()) throw UnusualInput();
+        if (bytes == 0) break;
+        HIP_CHECK(hipMemcpyAsync(s.d_text.p, s.text.p, bytes, hipMemcpyHostToDevice, s.stream));
+        HIP_CHECK(scg::launch_text_scan(s.d_text.as<char>(), bytes, s.B, s.stream));
+        HIP_CHECK(hipMemcpyAsync(s.h_result.p, s.d_result.p, sizeof(scg::TextScanResult), hipMemcpyDeviceToHost, s.stream));
+        s.pending = true;
+        if (prev) finish(*prev);
+        prev = &s;
+    }
+    if (prev && prev->pending) finish(*prev);
+    for (auto& s : slots) {
+        DeviceGuard g(s->plan->device);
+        HIP_CHECK(hipStreamSynchronize(s->stream));
+        s->busy = false;
+    }
+}
+
+void reset_plan(scg_plan* P) {
+    DeviceGuard g(P->device);
+    if (P->n_counters) HIP_CHECK(hipMemset(P->counters, 0, static_cast<size_t>(P->n_counters) * sizeof(int32_t)));
+    if (P->replica_shift > 0) HIP_CHECK(hipMemset(P->replicas.p, 0, P->replicas.bytes));
+    P->total = 0;
+}
+
+bool device_scan_enabled() {
+    const char* e = std::getenv("SCG_DEVICE_SCAN");          // test hook: 0 keeps the host parsers
+    return !(e && *e == '0');
+}
+
+// One single-end file on a set of plans (one per device).  Ordinary files go through the device scan; whatever it
+// declines is redone on the first plan by the host readers (count_single_end_file), which end in the sequential
+// reference-exact parser.
+void count_single_end(const std::vector<scg_plan*>& plans, const char* path, scg::FastqStream& fq, int nthreads) {
+    if (device_scan_enabled()) {
+        bool done = false;
+        try {
+            std::unique_ptr<scg::TextSource> src = scg::TextSource::open(path, scg::default_host_threads(nthreads));
+            count_text_stream(plans, *src);
+            done = true;
+        } catch (const UnusualInput&) {
+            for (scg_plan* P : plans) reset_plan(P);
+        }
+        if (done) return;
+    }
+    DeviceGuard g(plans[0]->device);
+    count_single_end_file(plans[0], path, fq, nthreads, nullptr, nullptr, nullptr);
+}
+
 // The reference's totals and counters are 32-bit `int`s (SingleBarcodeSingleEnd.hpp:132-133) and R integers
 // are 32-bit; a file with more reads than that would overflow them silently there.  Here the total is kept
 // in 64 bits and narrowing at the ABI is checked; no counter can exceed the total.
@@ -817,6 +966,159 @@ void read_counters(scg_plan* P, int32_t* counts_out) {
     if (counts_out && P->n_counters) {
         HIP_CHECK(hipMemcpy(counts_out, P->counters, static_cast<size_t>(P->n_counters) * sizeof(int32_t), hipMemcpyDeviceToHost));
     }
+}
+
+// ---- devices and plan sets ---------------------------------------------------------------------------------
+// Which devices a file-level call may use: $SCG_DEVICES ("all", or a comma list in which an id may repeat: several
+// pipelines on one card) if set; else every visible device, the calling thread's current one ($SCG_DEVICE) first.
+std::vector<int> device_list(bool* explicit_list = nullptr) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        throw Error(SCG_ERR_DEVICE, "no HIP device available: libscg has no CPU fallback");
+    }
+    std::vector<int> out;
+    const char* env = std::getenv("SCG_DEVICES");
+    if (explicit_list) *explicit_list = env && *env && std::strcmp(env, "all") != 0;
+    if (env && *env && std::strcmp(env, "all") != 0) {
+        const char* p = env;
+        while (*p) {
+            char* end = nullptr;
+            const long v = std::strtol(p, &end, 10);
+            if (end == p) throw Error(SCG_ERR_DEVICE, std::string("cannot parse SCG_DEVICES='") + env + "'");
+            if (v < 0 || v >= n) throw Error(SCG_ERR_DEVICE, "HIP device " + std::to_string(v) + " out of range (" + std::to_string(n) + " visible)");
+            out.push_back(static_cast<int>(v));
+            p = end;
+            while (*p == ',' || *p == ' ') ++p;
+        }
+        if (out.empty()) throw Error(SCG_ERR_DEVICE, "SCG_DEVICES lists no device");
+        return out;
+    }
+    const int first = resolve_device(-1);
+    const bool only_one = std::getenv("SCG_DEVICE") && *std::getenv("SCG_DEVICE") && !(env && *env);
+    out.push_back(first);
+    if (!only_one) for (int d = 0; d < n; ++d) if (d != first) out.push_back(d);
+    return out;
+}
+
+// Devices for ONE input of about `text_bytes` of FASTQ text: an explicit $SCG_DEVICES is taken as given; otherwise one
+// more device per four windows of text, so that small files do not pay for contexts and pinned buffers they cannot use.
+std::vector<int> devices_for_input(uint64_t text_bytes) {
+    bool given = false;
+    std::vector<int> all = device_list(&given);
+    if (given) return all;
+    const uint64_t per_device = uint64_t(4) * scan_window_bytes(~uint64_t(0) >> 8);
+    const size_t want = static_cast<size_t>(std::max<uint64_t>(1, text_bytes / per_device));
+    if (all.size() > want) all.resize(want);
+    return all;
+}
+
+uint64_t text_bytes_hint(const char* path) {
+    struct stat st;
+    if (!path || ::stat(path, &st) != 0) return 0;
+    unsigned char h[2] = {0, 0};
+    FILE* f = std::fopen(path, "rb");
+    size_t got = 0;
+    if (f) { got = std::fread(h, 1, 2, f); std::fclose(f); }
+    const bool gz = got == 2 && h[0] == 0x1f && h[1] == 0x8b;
+    return static_cast<uint64_t>(st.st_size) * (gz ? 5 : 1);
+}
+
+// A second plan with the same compiled (host-side) content, for another device.  Call before to_device().
+std::unique_ptr<scg_plan> clone_compiled(const scg_plan& a) {
+    std::unique_ptr<scg_plan> b(new scg_plan);
+    b->kind = a.kind;
+    b->ht1 = a.ht1; b->ht2 = a.ht2;
+    b->scan1 = a.scan1; b->scan2 = a.scan2;
+    b->htab[0] = a.htab[0]; b->htab[1] = a.htab[1];
+    b->hpairs = a.hpairs;
+    b->htab_combined = a.htab_combined;
+    b->n_pool[0] = a.n_pool[0]; b->n_pool[1] = a.n_pool[1];
+    b->max_mm1 = a.max_mm1; b->max_mm2 = a.max_mm2;
+    b->rev1 = a.rev1; b->rev2 = a.rev2; b->randomized = a.randomized; b->use_first = a.use_first;
+    b->diagnostics = a.diagnostics;
+    b->first1 = a.first1; b->first2 = a.first2;
+    b->n_counters = a.n_counters;
+    return b;
+}
+
+// One compiled plan on each of `devices` (the reference's counterpart: one handler state per worker thread,
+// process_data.hpp:126-147; the per-device results are summed like its serial reduce(), :115-124).
+struct PlanSet {
+    std::vector<std::unique_ptr<scg_plan> > plans;
+
+    PlanSet(std::unique_ptr<scg_plan> compiled, const std::vector<int>& devices) {
+        for (size_t i = 1; i < devices.size(); ++i) plans.push_back(clone_compiled(*compiled));
+        plans.insert(plans.begin(), std::move(compiled));
+        for (size_t i = 0; i < plans.size(); ++i) plans[i]->to_device(devices[i]);
+    }
+    std::vector<scg_plan*> all() const {
+        std::vector<scg_plan*> v;
+        for (auto& p : plans) v.push_back(p.get());
+        return v;
+    }
+    scg_plan* first() const { return plans[0].get(); }
+    int64_t total() const {
+        int64_t t = 0;
+        for (auto& p : plans) t += p->total;
+        return t;
+    }
+    // Sum of the devices' counters (every count is bounded by the total, which the callers check against int32).
+    void read(int32_t* counts_out) const {
+        if (plans.size() == 1) {
+            DeviceGuard g(plans[0]->device);
+            read_counters(plans[0].get(), counts_out);
+            return;
+        }
+        const size_t n = static_cast<size_t>(plans[0]->n_counters);
+        std::vector<int64_t> acc(n, 0);
+        std::vector<int32_t> part(n + 1);
+        for (auto& p : plans) {
+            DeviceGuard g(p->device);
+            read_counters(p.get(), part.data());
+            for (size_t i = 0; i < n; ++i) acc[i] += part[i];
+        }
+        if (counts_out) {
+            for (size_t i = 0; i < n; ++i) {
+                if (acc[i] > static_cast<int64_t>(INT32_MAX)) throw Error(SCG_ERR_INVALID, "a count exceeds the 32-bit range of the count vectors");
+                counts_out[i] = static_cast<int32_t>(acc[i]);
+            }
+        }
+    }
+    void reset() const { for (auto& p : plans) reset_plan(p.get()); }
+};
+
+// Files over devices inside one call (the matrixOf* functions: R/countSingleBarcodes.R:112-126, R/countComboBarcodes.R:149-164,
+// R/countDualBarcodes.R:205-254 hand the files to BiocParallel workers): every device runs one pipeline at a time and takes
+// the next unprocessed file when it is done; per_file(plan, i) counts file i and stores its column.  The error of the
+// lowest-numbered failing file is reported, as a serial loop over the files would.
+void schedule_files(int32_t n_files, const PlanSet& set, const std::function<void(scg_plan*, int32_t)>& per_file) {
+    std::atomic<int32_t> next(0);
+    std::mutex mu;
+    int32_t bad = n_files;
+    int bad_code = 0;
+    std::string bad_msg;
+    auto worker = [&](scg_plan* P) {
+        for (;;) {
+            const int32_t i = next.fetch_add(1);
+            if (i >= n_files) return;
+            int code = 0;
+            std::string msg;
+            try {
+                DeviceGuard g(P->device);
+                per_file(P, i);
+                continue;
+            } catch (const Error& e) { code = e.code; msg = e.what();
+            } catch (const std::bad_alloc&) { code = SCG_ERR_DEVICE; msg = "out of host memory";
+            } catch (const std::exception& e) { code = SCG_ERR_INVALID; msg = e.what(); }
+            std::lock_guard<std::mutex> g(mu);
+            if (i < bad) { bad = i; bad_code = code; bad_msg = msg; }
+        }
+    };
+    std::vector<std::thread> th;
+    for (size_t d = 1; d < set.plans.size(); ++d) th.emplace_back(worker, set.plans[d].get());
+    worker(set.plans[0].get());
+    for (auto& t : th) t.join();
+    if (bad < n_files) throw Error(bad_code, bad_msg);
 }
 
 void combo_compact(const int32_t* cells, int32_t n0, int32_t n1, int32_t** indices_out, int32_t** freq_out, int64_t* k_out) {
@@ -1004,6 +1306,31 @@ int scg_parse_fastq(const char* path, char** seqs_out, uint64_t** offsets_out, i
     });
 }
 
+int scg_fastq_text_windows(const char* path, int64_t window_bytes, int nthreads, char** text_out, int64_t* n_bytes_out,
+                           int64_t** cuts_out, int64_t* n_windows_out, char* kind_out, char* err, size_t errcap) {
+    return guarded(err, errcap, [&] {
+        if (!path || !text_out || !n_bytes_out || !cuts_out || !n_windows_out || window_bytes < 64) throw Error(SCG_ERR_INVALID, "null argument");
+        std::unique_ptr<scg::TextSource> src = scg::TextSource::open(path, scg::default_host_threads(nthreads));
+        if (kind_out) { std::strncpy(kind_out, src->kind(), 15); kind_out[15] = 0; }
+        std::vector<char> all, window(static_cast<size_t>(window_bytes));
+        std::vector<int64_t> cuts(1, 0);
+        for (;;) {
+            const size_t got = src->next(window.data(), window.size());
+            if (src->unusual()) throw Error(SCG_ERR_UNSUPPORTED, "the text cannot be cut into windows of whole 4-line records");
+            if (!got) break;
+            all.insert(all.end(), window.begin(), window.begin() + got);
+            cuts.push_back(static_cast<int64_t>(all.size()));
+        }
+        char* t = static_cast<char*>(std::malloc(all.size() + 1));
+        int64_t* c = static_cast<int64_t*>(std::malloc(sizeof(int64_t) * cuts.size()));
+        if (!t || !c) { std::free(t); std::free(c); throw std::bad_alloc(); }
+        if (!all.empty()) std::memcpy(t, all.data(), all.size());
+        std::memcpy(c, cuts.data(), sizeof(int64_t) * cuts.size());
+        *text_out = t; *n_bytes_out = static_cast<int64_t>(all.size());
+        *cuts_out = c; *n_windows_out = static_cast<int64_t>(cuts.size()) - 1;
+    });
+}
+
 int scg_set_device(int device, char* err, size_t errcap) {
     return guarded(err, errcap, [&] {
         int n = 0;
@@ -1175,12 +1502,11 @@ int scg_count_single_barcodes(const char* path, const char* constant, int strand
     return guarded(err, errcap, [&] {
         if (!path || !counts_out || !total_out) throw Error(SCG_ERR_INVALID, "null argument");
         scg::FastqStream fq(path);                                           // src/count_single_barcodes.cpp:30
-        auto P = compile_single(constant, strand, pool, n_pool, mismatches, use_first);   // :31-47
-        P->to_device(-1);
-        DeviceGuard g(P->device);
-        count_single_end_file(P.get(), path, fq, nthreads);
-        read_counters(P.get(), counts_out);
-        *total_out = narrow_total(P->total);
+        PlanSet set(compile_single(constant, strand, pool, n_pool, mismatches, use_first),   // :31-47
+                    devices_for_input(text_bytes_hint(path)));
+        count_single_end(set.all(), path, fq, nthreads);
+        set.read(counts_out);
+        *total_out = narrow_total(set.total());
     });
 }
 
@@ -1192,14 +1518,14 @@ int scg_count_combo_barcodes_single(const char* path, const char* constant, int 
     return guarded(err, errcap, [&] {
         if (!path || !indices_out || !freq_out || !k_out || !total_out) throw Error(SCG_ERR_INVALID, "null argument");
         scg::FastqStream fq(path);
-        auto P = compile_combo(constant, strand, pool0, n_pool0, pool1, n_pool1, mismatches, use_first);
-        P->to_device(-1);
-        DeviceGuard g(P->device);
-        count_single_end_file(P.get(), path, fq, nthreads);
-        std::vector<int32_t> cells(static_cast<size_t>(P->n_counters) + 1);
-        read_counters(P.get(), cells.data());
+        PlanSet set(compile_combo(constant, strand, pool0, n_pool0, pool1, n_pool1, mismatches, use_first),
+                    devices_for_input(text_bytes_hint(path)));
+        count_single_end(set.all(), path, fq, nthreads);
+        std::vector<int32_t> cells(static_cast<size_t>(set.first()->n_counters) + 1);
+        set.read(cells.data());
+        const int32_t total = narrow_total(set.total());
         combo_compact(cells.data(), n_pool0, n_pool1, indices_out, freq_out, k_out);
-        *total_out = narrow_total(P->total);
+        *total_out = total;
     });
 }
 
@@ -1257,11 +1583,10 @@ int scg_count_dual_barcodes_single_end(const char* path, const char* constant, c
         if (diagnostics) {
             throw Error(SCG_ERR_INVALID, "diagnostics requested: call scg_count_dual_barcodes_single_end_diagnostics, which returns the extra outputs");
         }
-        P->to_device(-1);
-        DeviceGuard g(P->device);
-        count_single_end_file(P.get(), path, fq, nthreads);
-        read_counters(P.get(), counts_out);
-        *total_out = narrow_total(P->total);
+        PlanSet set(std::move(P), devices_for_input(text_bytes_hint(path)));
+        count_single_end(set.all(), path, fq, nthreads);
+        set.read(counts_out);
+        *total_out = narrow_total(set.total());
     });
 }
 
@@ -1362,15 +1687,15 @@ int scg_count_dual_barcodes_single_end_diagnostics(const char* path, const char*
     return guarded(err, errcap, [&] {
         if (!path || !invalid_indices_out || !invalid_freq_out || !k_out || !total_out) throw Error(SCG_ERR_INVALID, "null argument");
         scg::FastqStream fq(path);
-        auto P = compile_dual_single_end_diag(constant, strand, pools, n_pools, n_regions, mismatches, use_first);
-        P->to_device(-1);
-        DeviceGuard g(P->device);
-        count_single_end_file(P.get(), path, fq, nthreads);
-        std::vector<int32_t> all(static_cast<size_t>(P->n_counters) + 1);
-        read_counters(P.get(), all.data());
+        PlanSet set(compile_dual_single_end_diag(constant, strand, pools, n_pools, n_regions, mismatches, use_first),
+                    devices_for_input(text_bytes_hint(path)));
+        count_single_end(set.all(), path, fq, nthreads);
+        std::vector<int32_t> all(static_cast<size_t>(set.first()->n_counters) + 1);
+        set.read(all.data());
+        const int32_t total = narrow_total(set.total());
         int32_t b1 = 0, b2 = 0;
-        diagnostics_from_counters(P.get(), all, counts_out, invalid_indices_out, invalid_freq_out, k_out, &b1, &b2);
-        *total_out = narrow_total(P->total);
+        diagnostics_from_counters(set.first(), all, counts_out, invalid_indices_out, invalid_freq_out, k_out, &b1, &b2);
+        *total_out = total;
     });
 }
 
@@ -1397,6 +1722,94 @@ int scg_count_combo_barcodes_paired(const char* path1, const char* constant1, in
         read_counters(P.get(), all.data());
         diagnostics_from_counters(P.get(), all, nullptr, indices_out, freq_out, k_out, barcode1_only_out, barcode2_only_out);
         *total_out = narrow_total(P->total);
+    });
+}
+
+// ---- many files in one call (matrixOf*) ---------------------------------------------------------------------
+
+int scg_count_single_barcodes_files(const char* const* paths, int32_t n_files, const char* constant, int strand,
+                                    const char* const* pool, int32_t n_pool, int mismatches, int use_first, int nthreads,
+                                    int32_t* counts_out, int32_t* totals_out, char* err, size_t errcap) {
+    return guarded(err, errcap, [&] {
+        if (n_files < 0 || (n_files > 0 && (!paths || !totals_out || (n_pool > 0 && !counts_out)))) throw Error(SCG_ERR_INVALID, "null argument");
+        for (int32_t f = 0; f < n_files; ++f) if (!paths[f]) throw Error(SCG_ERR_INVALID, "null argument");
+        if (n_files == 0) return;
+        if (n_files == 1) {      // one file: all devices share it
+            const int rc = scg_count_single_barcodes(paths[0], constant, strand, pool, n_pool, mismatches, use_first, nthreads,
+                                                     counts_out, totals_out, err, errcap);
+            if (rc != SCG_OK) throw Error(rc, err ? err : "");
+            return;
+        }
+        scg::FastqStream probe(paths[0]);                          // the first file's reader comes before the argument checks, as in a loop over files
+        std::vector<int> devices = device_list();
+        if (devices.size() > static_cast<size_t>(n_files)) devices.resize(static_cast<size_t>(n_files));
+        PlanSet set(compile_single(constant, strand, pool, n_pool, mismatches, use_first), devices);
+        const size_t stride = static_cast<size_t>(n_pool);
+        schedule_files(n_files, set, [&](scg_plan* P, int32_t f) {
+            scg::FastqStream fq(paths[f]);
+            reset_plan(P);
+            count_single_end(std::vector<scg_plan*>(1, P), paths[f], fq, nthreads);
+            read_counters(P, counts_out + stride * static_cast<size_t>(f));
+            totals_out[f] = narrow_total(P->total);
+        });
+    });
+}
+
+int scg_count_combo_barcodes_single_files(const char* const* paths, int32_t n_files, const char* constant, int strand,
+                                          const char* const* pool0, int32_t n_pool0, const char* const* pool1, int32_t n_pool1,
+                                          int mismatches, int use_first, int nthreads,
+                                          int32_t** indices_out, int32_t** freq_out, int64_t* k_out, int32_t* totals_out,
+                                          char* err, size_t errcap) {
+    return guarded(err, errcap, [&] {
+        if (n_files < 0 || (n_files > 0 && (!paths || !indices_out || !freq_out || !k_out || !totals_out))) throw Error(SCG_ERR_INVALID, "null argument");
+        for (int32_t f = 0; f < n_files; ++f) {
+            if (!paths[f]) throw Error(SCG_ERR_INVALID, "null argument");
+            indices_out[f] = nullptr; freq_out[f] = nullptr; k_out[f] = 0;
+        }
+        if (n_files == 0) return;
+        try {
+            scg::FastqStream probe(paths[0]);
+            std::vector<int> devices = device_list();
+            if (devices.size() > static_cast<size_t>(n_files)) devices.resize(static_cast<size_t>(n_files));
+            PlanSet set(compile_combo(constant, strand, pool0, n_pool0, pool1, n_pool1, mismatches, use_first), devices);
+            const size_t cells = static_cast<size_t>(set.first()->n_counters);
+            schedule_files(n_files, set, [&](scg_plan* P, int32_t f) {
+                scg::FastqStream fq(paths[f]);
+                reset_plan(P);
+                count_single_end(std::vector<scg_plan*>(1, P), paths[f], fq, nthreads);
+                std::vector<int32_t> dense(cells + 1);
+                read_counters(P, dense.data());
+                totals_out[f] = narrow_total(P->total);
+                combo_compact(dense.data(), n_pool0, n_pool1, &indices_out[f], &freq_out[f], &k_out[f]);
+            });
+        } catch (...) {
+            for (int32_t f = 0; f < n_files; ++f) { std::free(indices_out[f]); std::free(freq_out[f]); indices_out[f] = nullptr; freq_out[f] = nullptr; k_out[f] = 0; }
+            throw;
+        }
+    });
+}
+
+int scg_count_dual_barcodes_files(const char* const* paths1, const char* constant1, int reverse1, int mismatches1, const char* const* pool1,
+                                  const char* const* paths2, const char* constant2, int reverse2, int mismatches2, const char* const* pool2,
+                                  int32_t n_pool, int32_t n_files, int randomized, int use_first, int nthreads,
+                                  int32_t* counts_out, int32_t* totals_out, char* err, size_t errcap) {
+    return guarded(err, errcap, [&] {
+        if (n_files < 0 || (n_files > 0 && (!paths1 || !paths2 || !totals_out || (n_pool > 0 && !counts_out)))) throw Error(SCG_ERR_INVALID, "null argument");
+        for (int32_t f = 0; f < n_files; ++f) if (!paths1[f] || !paths2[f]) throw Error(SCG_ERR_INVALID, "null argument");
+        if (n_files == 0) return;
+        { scg::FastqStream probe1(paths1[0]); scg::FastqStream probe2(paths2[0]); }
+        std::vector<int> devices = device_list();
+        if (devices.size() > static_cast<size_t>(n_files)) devices.resize(static_cast<size_t>(n_files));
+        PlanSet set(compile_dual(constant1, reverse1, mismatches1, pool1, constant2, reverse2, mismatches2, pool2, n_pool, randomized, use_first), devices);
+        const size_t stride = static_cast<size_t>(n_pool);
+        schedule_files(n_files, set, [&](scg_plan* P, int32_t f) {
+            scg::FastqStream fq1(paths1[f]);
+            scg::FastqStream fq2(paths2[f]);
+            reset_plan(P);
+            count_paired_files(P, paths1[f], paths2[f], fq1, fq2, nthreads);
+            read_counters(P, counts_out + stride * static_cast<size_t>(f));
+            totals_out[f] = narrow_total(P->total);
+        });
     });
 }
 

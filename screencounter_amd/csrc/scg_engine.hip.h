@@ -188,8 +188,14 @@ template<> struct KeyOps<uint64_t> {
 // Library index search.  Calls f(value, distance) for every entry within Hamming distance
 // <= cap of the query (an entry may be reported more than once); f returns true to stop.
 // ---------------------------------------------------------------------------------------------
+//
+// best (optional): the caller's running minimum distance (> cap while nothing is found).  When given, the walk is
+// ADAPTIVE: once an entry at distance b is known, every entry that can still matter (distance <= b: a closer one,
+// or a tie) is reachable through the first nwalk[b] tables, so the later tables are skipped -- a query one mismatch
+// away from its barcode looks into two tables of a budget-2 index, not six.
 template<class W, class F>
-__device__ __forceinline__ void index_search(const ScgIndex& X, const QueryT<W>& q, int cap, F f) {
+__device__ __forceinline__ void index_search(const ScgIndex& X, const QueryT<W>& q, int cap, F f,
+                                             const int* best = nullptr) {
     typedef KeyOps<W> K;
     if (q.n_other > cap) return;
     const W lm = low_mask_w<W>(X.len);
@@ -206,7 +212,8 @@ __device__ __forceinline__ void index_search(const ScgIndex& X, const QueryT<W>&
     // (selected from SGPR copies: indexing the kernel-argument array with a per-lane cap would be a vector load)
     const int w0 = __builtin_amdgcn_readfirstlane(X.nwalk[0]), w1 = __builtin_amdgcn_readfirstlane(X.nwalk[1]);
     const int w2 = __builtin_amdgcn_readfirstlane(X.nwalk[2]), w3 = __builtin_amdgcn_readfirstlane(X.nwalk[3]);
-    const int nwalk = cap <= 0 ? w0 : (cap == 1 ? w1 : (cap == 2 ? w2 : w3));
+    auto tables_for = [&](int c) { return c <= 0 ? w0 : (c == 1 ? w1 : (c == 2 ? w2 : w3)); };
+    int nwalk = tables_for(cap);
     const uint32_t nslots = X.slot_mask + 1u;
 #pragma unroll 1
     for (int s = 0; s < nwalk; ++s) {
@@ -234,6 +241,10 @@ __device__ __forceinline__ void index_search(const ScgIndex& X, const QueryT<W>&
             if (e < 0) break;
             ent = K::load(nodes, (size_t)e);
         }
+        if (best && *best < cap) {
+            const int t = tables_for(*best);
+            nwalk = t < nwalk ? t : nwalk;
+        }
     }
 }
 
@@ -252,7 +263,7 @@ __device__ __forceinline__ void index_match(const ScgIndex& X, const QueryT<W>& 
         if (d < best) { best = d; cur = v; }
         else if (d == best && cur != v) { cur = keep_first ? (v < cur ? v : cur) : SCG_AMBIGUOUS; }
         return d == 0;      // an exact entry is unique (one entry per concrete sequence)
-    });
+    }, &best);
     index = cur; mm = best;
 }
 

@@ -13,6 +13,7 @@
 // Unlike the reference's byte-at-a-time virtual-call loop this scanner works on large buffers
 // with memchr, and only the sequence bytes are kept (names and qualities never leave this file).
 #include "scg_host.h"
+#include "scg_ingest.h"
 
 #include <cctype>
 #include <cstdio>
@@ -216,26 +217,7 @@ struct ParallelFastq::Impl {
     // If a strict 4-line record starts at p, returns the offset just past it (== size for a final
     // record without trailing newline); otherwise 0.
     size_t record_end(size_t p, const char** seq_out = nullptr, size_t* seq_len_out = nullptr) const {
-        if (p >= size || data[p] != '@') return 0;
-        const char* e = data + size;
-        const char* l1 = static_cast<const char*>(std::memchr(data + p, '\n', size - p));
-        if (!l1) return 0;
-        const char* s0 = l1 + 1;
-        const char* l2 = s0 < e ? static_cast<const char*>(std::memchr(s0, '\n', e - s0)) : nullptr;
-        if (!l2) return 0;
-        if (std::memchr(s0, '+', l2 - s0)) return 0;            // '+' would end the sequence early
-        const char* p0 = l2 + 1;
-        if (p0 >= e || *p0 != '+') return 0;
-        const char* l3 = static_cast<const char*>(std::memchr(p0, '\n', e - p0));
-        if (!l3) return 0;
-        const char* q0 = l3 + 1;
-        size_t seq_len = static_cast<size_t>(l2 - s0);
-        const char* l4 = q0 < e ? static_cast<const char*>(std::memchr(q0, '\n', e - q0)) : nullptr;
-        size_t qual_len = l4 ? static_cast<size_t>(l4 - q0) : static_cast<size_t>(e - q0);
-        if (qual_len != seq_len) return 0;
-        if (seq_len == 0 && !l4) return 0;                      // leave EOF corner cases to the sequential parser
-        if (seq_out) { *seq_out = s0; *seq_len_out = seq_len; }
-        return l4 ? static_cast<size_t>(l4 + 1 - data) : size;
+        return strict_record_end(data, size, p, seq_out, seq_len_out);
     }
 
     // First position >= from that starts two consecutive strict records (or one ending at EOF).

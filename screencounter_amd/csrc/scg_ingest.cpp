@@ -1,0 +1,322 @@
+// scg_ingest.cpp -- sources of raw FASTQ text for the device-side record scan (see scg_ingest.h).
+#include "scg_ingest.h"
+#include "scg_host.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cstdio>
+#include <cstring>
+#include <exception>
+#include <fcntl.h>
+#include <mutex>
+#include <string>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <thread>
+#include <unistd.h>
+#include <vector>
+#include <zlib.h>
+
+namespace scg {
+
+void parallel_for(int n, int threads, const std::function<void(int)>& fn) {
+    if (n <= 0) return;
+    const int T = std::max(1, std::min(threads, n));
+    if (T == 1) {
+        for (int i = 0; i < n; ++i) fn(i);
+        return;
+    }
+    std::atomic<int> next(0);
+    std::exception_ptr err;
+    std::mutex mu;
+    auto work = [&] {
+        for (;;) {
+            const int i = next.fetch_add(1);
+            if (i >= n) return;
+            try {
+                fn(i);
+            } catch (...) {
+                std::lock_guard<std::mutex> g(mu);
+                if (!err) err = std::current_exception();
+                next.store(n);
+            }
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; ++t) th.emplace_back(work);
+    work();
+    for (auto& t : th) t.join();
+    if (err) std::rethrow_exception(err);
+}
+
+size_t strict_record_end(const char* data, size_t size, size_t p, const char** seq_out, size_t* seq_len_out) {
+    if (p >= size || data[p] != '@') return 0;
+    const char* e = data + size;
+    const char* l1 = static_cast<const char*>(std::memchr(data + p, '\n', size - p));
+    if (!l1) return 0;
+    const char* s0 = l1 + 1;
+    const char* l2 = s0 < e ? static_cast<const char*>(std::memchr(s0, '\n', e - s0)) : nullptr;
+    if (!l2) return 0;
+    if (std::memchr(s0, '+', l2 - s0)) return 0;            // '+' would end the sequence early
+    const char* p0 = l2 + 1;
+    if (p0 >= e || *p0 != '+') return 0;
+    const char* l3 = static_cast<const char*>(std::memchr(p0, '\n', e - p0));
+    if (!l3) return 0;
+    const char* q0 = l3 + 1;
+    const size_t seq_len = static_cast<size_t>(l2 - s0);
+    const char* l4 = q0 < e ? static_cast<const char*>(std::memchr(q0, '\n', e - q0)) : nullptr;
+    const size_t qual_len = l4 ? static_cast<size_t>(l4 - q0) : static_cast<size_t>(e - q0);
+    if (qual_len != seq_len) return 0;
+    if (seq_len == 0 && !l4) return 0;                      // leave EOF corner cases to the sequential parser
+    if (seq_out) { *seq_out = s0; *seq_len_out = seq_len; }
+    return l4 ? static_cast<size_t>(l4 + 1 - data) : size;
+}
+
+namespace {
+
+// The largest c <= len such that two consecutive ordinary records end exactly at c, searched among the line starts of
+// the last `slack` bytes; 0 if there is none.  data[0] is a record start, so c is then a record boundary as long as
+// the window holds ordinary records only -- which the device scan verifies for every window (scg_textscan.hip): a
+// wrong guess here surfaces there as a line count that is not a multiple of four.
+size_t find_cut(const char* data, size_t len, size_t slack = size_t(1) << 20) {
+    const size_t floor = len > slack ? len - slack : 0;
+    size_t pos = len;
+    while (pos > floor) {
+        // candidate: the line start that follows the last newline before pos - 1
+        const char* nl = pos >= 2 ? static_cast<const char*>(memrchr(data + floor, '\n', pos - 1 - floor)) : nullptr;
+        const size_t p = nl ? static_cast<size_t>(nl + 1 - data) : floor;
+        if (nl || floor == 0) {
+            const size_t e1 = strict_record_end(data, len, p);
+            if (e1 && e1 < len) {
+                const size_t e2 = strict_record_end(data, len, e1);
+                if (e2 && e2 <= len && data[e2 - 1] == '\n') return e2;
+            }
+        }
+        if (!nl) break;
+        pos = p;      // next candidate: the line before
+    }
+    return 0;
+}
+
+struct MappedFile {
+    int fd = -1;
+    const char* data = nullptr;
+    size_t size = 0;
+    explicit MappedFile(const char* path) {
+        fd = ::open(path, O_RDONLY);
+        if (fd < 0) throw Error(SCG_ERR_IO, std::string("failed to open file at '") + path + "'");
+        struct stat st;
+        if (::fstat(fd, &st) != 0) { ::close(fd); throw Error(SCG_ERR_IO, "failed to stat the FASTQ file"); }
+        size = static_cast<size_t>(st.st_size);
+        if (size) {
+            void* m = ::mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m == MAP_FAILED) { ::close(fd); throw Error(SCG_ERR_IO, "failed to map the FASTQ file"); }
+            ::madvise(m, size, MADV_SEQUENTIAL);
+            data = static_cast<const char*>(m);
+        }
+    }
+    ~MappedFile() {
+        if (data) ::munmap(const_cast<char*>(data), size);
+        if (fd >= 0) ::close(fd);
+    }
+    MappedFile(const MappedFile&) = delete;
+    MappedFile& operator=(const MappedFile&) = delete;
+};
+
+// ---- plain file: windows are copied out of the mapping by several threads ----
+class PlainSource : public TextSource {
+    MappedFile f;
+    size_t pos = 0;
+public:
+    PlainSource(const char* path, int nthreads) : f(path) { threads = nthreads; }
+    const char* kind() const override { return "plain"; }
+    uint64_t size_hint() const override { return f.size - pos; }
+    size_t next(char* dst, size_t cap) override {
+        if (odd || pos >= f.size) return 0;
+        const size_t left = f.size - pos;
+        size_t take;
+        bool pad = false;
+        if (left + 1 <= cap) {
+            take = left;
+            pad = f.data[f.size - 1] != '\n';
+        } else {
+            take = find_cut(f.data + pos, cap - 1);
+            if (!take) { odd = true; return 0; }
+        }
+        const int parts = static_cast<int>(std::min<size_t>(static_cast<size_t>(threads), (take >> 22) + 1));
+        const char* src = f.data + pos;
+        parallel_for(parts, threads, [&](int i) {
+            const size_t a = take * i / parts, b = take * (i + 1) / parts;
+            std::memcpy(dst + a, src + a, b - a);
+        });
+        pos += take;
+        if (pad) dst[take++] = '\n';
+        return take;
+    }
+};
+
+// Text that arrives as a stream (inflated gzip): the part of a window behind its last record boundary is carried over
+// to the front of the next one.
+class CarrySource : public TextSource {
+protected:
+    std::vector<char> carry;
+    bool exhausted = false;
+    // Appends up to cap - have fresh bytes at dst + have; returns the new fill level; sets exhausted at the end of the stream.
+    virtual size_t fill(char* dst, size_t have, size_t cap) = 0;
+public:
+    size_t next(char* dst, size_t cap) override {
+        if (odd) return 0;
+        size_t have = carry.size();
+        if (have >= cap) { odd = true; return 0; }
+        if (have) std::memcpy(dst, carry.data(), have);
+        carry.clear();
+        if (!exhausted) have = fill(dst, have, cap - 1);
+        if (have == 0) return 0;
+        if (exhausted) {
+            if (dst[have - 1] != '\n') dst[have++] = '\n';
+            return have;
+        }
+        const size_t cut = find_cut(dst, have);
+        if (!cut) { odd = true; return 0; }
+        carry.assign(dst + cut, dst + have);
+        return cut;
+    }
+};
+
+// ---- BGZF and other blocked gzip files whose members announce their size (the 'BC' extra subfield of the SAM/BAM
+//      specification, written by bgzip): members are located from their headers alone and inflated in parallel,
+//      each straight into its place in the window ----
+struct BgzfMember {
+    size_t off, csize;
+    uint32_t isize;
+};
+
+// Parses the member header at data[off]; false if it is not a BGZF member.
+bool bgzf_member(const char* data, size_t size, size_t off, BgzfMember& m) {
+    const unsigned char* p = reinterpret_cast<const unsigned char*>(data) + off;
+    if (size - off < 28) return false;
+    if (p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || !(p[3] & 4)) return false;
+    const size_t xlen = p[10] | (static_cast<size_t>(p[11]) << 8);
+    if (size - off < 12 + xlen + 8) return false;
+    size_t x = 12;
+    size_t bsize = 0;
+    while (x + 4 <= 12 + xlen) {
+        const size_t slen = p[x + 2] | (static_cast<size_t>(p[x + 3]) << 8);
+        if (p[x] == 'B' && p[x + 1] == 'C' && slen == 2 && x + 6 <= 12 + xlen) {
+            bsize = (p[x + 4] | (static_cast<size_t>(p[x + 5]) << 8)) + 1;
+            break;
+        }
+        x += 4 + slen;
+    }
+    if (!bsize || bsize < 12 + xlen + 8 || off + bsize > size) return false;
+    const unsigned char* t = p + bsize - 4;
+    m.off = off;
+    m.csize = bsize;
+    m.isize = t[0] | (static_cast<uint32_t>(t[1]) << 8) | (static_cast<uint32_t>(t[2]) << 16) | (static_cast<uint32_t>(t[3]) << 24);
+    return true;
+}
+
+void inflate_member(const char* src, size_t csize, char* dst, uint32_t isize) {
+    z_stream zs;
+    std::memset(&zs, 0, sizeof(zs));
+    if (inflateInit2(&zs, 15 + 16) != Z_OK) throw Error(SCG_ERR_IO, "failed to initialise zlib");
+    zs.next_in = reinterpret_cast<Bytef*>(const_cast<char*>(src));
+    zs.avail_in = static_cast<uInt>(csize);
+    zs.next_out = reinterpret_cast<Bytef*>(dst);
+    zs.avail_out = isize;
+    const int rc = inflate(&zs, Z_FINISH);
+    const bool ok = rc == Z_STREAM_END && zs.total_out == isize && zs.avail_in == 0;
+    std::string msg = zs.msg ? zs.msg : "corrupt gzip member";
+    inflateEnd(&zs);
+    if (!ok) throw Error(SCG_ERR_IO, msg);      // byteme/GzipFileReader.hpp:45-48 reports zlib's message as well
+}
+
+class BgzfSource : public CarrySource {
+    MappedFile f;
+    size_t off = 0;
+public:
+    BgzfSource(const char* path, int nthreads) : f(path) { threads = nthreads; }
+    const char* kind() const override { return "bgzf"; }
+    uint64_t size_hint() const override { return static_cast<uint64_t>(f.size - off) * 6 + carry.size(); }
+    static bool looks_like(const char* path) {
+        MappedFile g(path);
+        BgzfMember m;
+        return g.size && bgzf_member(g.data, g.size, 0, m);
+    }
+protected:
+    size_t fill(char* dst, size_t have, size_t cap) override {
+        std::vector<BgzfMember> batch;
+        std::vector<size_t> where;
+        size_t at = have;
+        while (off < f.size) {
+            BgzfMember m;
+            if (!bgzf_member(f.data, f.size, off, m)) {
+                // a member without the size subfield in the middle of the file: not a format this source understands
+                odd = true;
+                return have;
+            }
+            if (at + m.isize > cap) break;
+            batch.push_back(m);
+            where.push_back(at);
+            at += m.isize;
+            off += m.csize;
+        }
+        if (off >= f.size) exhausted = true;
+        if (batch.empty() && !exhausted) { odd = true; return have; }     // one member larger than a window
+        parallel_for(static_cast<int>(batch.size()), threads, [&](int i) {
+            if (batch[i].isize) inflate_member(f.data + batch[i].off, batch[i].csize, dst + where[i], batch[i].isize);
+        });
+        return at;
+    }
+};
+
+// ---- any other gzip file: one inflate stream (zlib's gzread handles concatenated members like the reference's
+//      byteme::GzipFileReader), bounded by that one thread ----
+class GzipSource : public CarrySource {
+    gzFile gz = nullptr;
+    uint64_t csize = 0;
+public:
+    explicit GzipSource(const char* path) {
+        struct stat st;
+        if (::stat(path, &st) == 0) csize = static_cast<uint64_t>(st.st_size);
+        gz = gzopen(path, "rb");
+        if (!gz) throw Error(SCG_ERR_IO, std::string("failed to open file at '") + path + "'");
+        gzbuffer(gz, 1 << 20);
+    }
+    ~GzipSource() override { if (gz) gzclose(gz); }
+    const char* kind() const override { return "gzip"; }
+    uint64_t size_hint() const override { return csize * 8; }
+protected:
+    size_t fill(char* dst, size_t have, size_t cap) override {
+        while (have < cap) {
+            const size_t want = std::min<size_t>(cap - have, size_t(1) << 30);
+            const int got = gzread(gz, dst + have, static_cast<unsigned>(want));
+            if (got < 0) {
+                int dummy;
+                throw Error(SCG_ERR_IO, gzerror(gz, &dummy));      // byteme/GzipFileReader.hpp:47
+            }
+            if (got == 0) { exhausted = true; break; }
+            have += static_cast<size_t>(got);
+        }
+        return have;
+    }
+};
+
+} // namespace
+
+std::unique_ptr<TextSource> TextSource::open(const char* path, int threads) {
+    unsigned char h[2] = {0, 0};
+    size_t got = 0;
+    {
+        FILE* fp = std::fopen(path, "rb");
+        if (!fp) throw Error(SCG_ERR_IO, std::string("failed to open file at '") + path + "'");
+        got = std::fread(h, 1, 2, fp);
+        std::fclose(fp);
+    }
+    const bool gz = got == 2 && h[0] == 0x1f && h[1] == 0x8b;      // byteme/magic_numbers.hpp:19-22
+    if (!gz) return std::unique_ptr<TextSource>(new PlainSource(path, threads));
+    if (BgzfSource::looks_like(path)) return std::unique_ptr<TextSource>(new BgzfSource(path, threads));
+    return std::unique_ptr<TextSource>(new GzipSource(path));
+}
+
+} // namespace scg

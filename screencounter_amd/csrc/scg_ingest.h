@@ -1,0 +1,50 @@
+// scg_ingest.h -- sources of raw FASTQ text for the device-side record scan (scg_textscan.hip).
+//
+// Replaces, for ordinary files, the byte-at-a-time reader stack of the reference (kaori::FastqReader over
+// byteme::PerByte over byteme::RawFileReader / GzipFileReader: inst/include/kaori/FastqReader.hpp:42-110,
+// inst/include/byteme/RawFileReader.hpp, GzipFileReader.hpp:39-51, SomeFileReader.hpp:31-44): the host only moves
+// bytes -- file pages or inflated blocks -- into pinned windows that start and end on record boundaries; the GPU
+// finds and validates the records.  Anything that is not a run of ordinary 4-line records makes the pipeline fall
+// back to the sequential reader of scg_fastq.cpp, which reproduces the reference exactly.
+#ifndef SCG_INGEST_H
+#define SCG_INGEST_H
+
+#include <cstddef>
+#include <cstdint>
+#include <functional>
+#include <memory>
+
+namespace scg {
+
+// fn(0) .. fn(n - 1) on up to `threads` host threads (the caller runs one share itself); exceptions are rethrown.
+void parallel_for(int n, int threads, const std::function<void(int)>& fn);
+
+// If an ordinary 4-line record starts at data[p], the offset just past it (== size for a final record without its
+// trailing newline); otherwise 0.  Optionally reports where its sequence line lies.
+size_t strict_record_end(const char* data, size_t size, size_t p, const char** seq = nullptr, size_t* seq_len = nullptr);
+
+class TextSource {
+public:
+    // plain file (mapped), BGZF / blocked gzip (members inflated in parallel) or any other gzip (one inflate stream)
+    static std::unique_ptr<TextSource> open(const char* path, int threads);
+    virtual ~TextSource() {}
+
+    // Writes the next window of text into dst[0 .. cap): whole records, starting where the previous window ended.
+    // Returns its size; 0 at the end of the input.  When the input ends without a newline one is appended (the
+    // reference accepts a final record without it).  cap must be at least min_capacity().
+    virtual size_t next(char* dst, size_t cap) = 0;
+    // The text could not be cut at a verified record boundary: the caller must redo the file sequentially.
+    bool unusual() const { return odd; }
+    // An upper estimate of the text bytes still to come (window sizing only).
+    virtual uint64_t size_hint() const = 0;
+    virtual const char* kind() const = 0;
+    static size_t min_capacity() { return size_t(4) << 20; }
+
+protected:
+    bool odd = false;
+    int threads = 1;
+};
+
+} // namespace scg
+
+#endif

@@ -25,6 +25,16 @@ namespace {
 
 constexpr int BLOCK = 256;
 
+// Occupancy of the staged kernels (A/B-measured, tools/abx.sh): left to itself the compiler takes 78 VGPRs for the
+// combination kernel = 6 waves per SIMD; asking for 8 (64 VGPRs, no spills) made it 11 % faster.  The dual kernel is
+// limited by its two 15 KB tiles (5 workgroups per CU), not by registers.
+#ifndef SCG_SINGLE_WAVES
+#define SCG_SINGLE_WAVES 8
+#endif
+#ifndef SCG_COMBO_WAVES
+#define SCG_COMBO_WAVES 8
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // single
 // ---------------------------------------------------------------------------------------------
@@ -413,7 +423,7 @@ __device__ __forceinline__ int single_read_staged(const ScgSingleParams& P, cons
 
 // NC < NW ("compact"): candidate positions fit 32*NC bits and the plan's seeds allow it (ScgScan::compact_ok).
 template<int NW, int NT, int NC, class W>
-__global__ __launch_bounds__(STAGE_BLOCK) __attribute__((amdgpu_num_sgpr(80))) void single_staged_kernel(ScgSingleParams P, ScgReads R, int64_t n_reads,
+__global__ __launch_bounds__(STAGE_BLOCK, SCG_SINGLE_WAVES) __attribute__((amdgpu_num_sgpr(80))) void single_staged_kernel(ScgSingleParams P, ScgReads R, int64_t n_reads,
                                                                    ScgCounters counts, int32_t* __restrict__ error_flag) {
     __shared__ Tile<NW> tile;
     __shared__ StrandTable<NT> strands;
@@ -513,7 +523,7 @@ __device__ __forceinline__ bool combo_candidate_staged(const ScgComboParams& P, 
 }
 
 template<int NW, int NT, int NC, bool SECOND>
-__global__ __launch_bounds__(STAGE_BLOCK) __attribute__((amdgpu_num_sgpr(80))) void combo_staged_kernel(ScgComboParams P, ScgReads R, int64_t n_reads,
+__global__ __launch_bounds__(STAGE_BLOCK, SCG_COMBO_WAVES) __attribute__((amdgpu_num_sgpr(80))) void combo_staged_kernel(ScgComboParams P, ScgReads R, int64_t n_reads,
                                                                   ScgCounters cells, int32_t* __restrict__ error_flag) {
     __shared__ Tile<NW> tile;
     __shared__ StrandTable<NT> strands;

@@ -50,8 +50,8 @@ struct Tile {
 
 // 16 ASCII bytes -> 16 bits of each plane.
 //
-// Per dword: code k = (byte >> 1) & 3; "ACTG"[k] is fetched with one byte permute and XORed with the
-// byte stripped of its case bit: the result z is zero exactly for ACGTacgt.  Plane bits are
+// Per dword: code k = (byte >> 1) & 3; "ACTG"[k] is fetched with one byte permute (selected by the code bits in
+// place) and XORed with the byte stripped of its case bit: the result z is zero exactly for ACGTacgt.  Plane bits are
 // gathered with v_dot4_u32_u8 against power-of-two weights, straight from ASCII bits 1 and 2 (so
 // scaled by 2 and 4).  When every lane of the wavefront holds only standard bases -- the rule in
 // real data, where N calls are rare -- the validity plane is all ones and its gather (a carry-free
@@ -63,8 +63,9 @@ __device__ __forceinline__ void transpose_chunk(const uint4& x, uint32_t& p0, ui
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const uint32_t w = (i & 1) ? 0x80402010u : 0x08040201u;     // bit weights of the 4 bytes
-        const uint32_t k = (d[i] >> 1) & 0x03030303u;               // codes
-        const uint32_t expect = __builtin_amdgcn_perm(0u, 0x47544341u, k);   // "ACTG"[code] per byte
+        // "ACTG"[code] per byte without shifting the code down: ASCII bits 1-2 in place (0, 2, 4, 6) select bytes
+        // 0 and 2 of each table word (a shift is a half-rate instruction on gfx950, the mask is not)
+        const uint32_t expect = __builtin_amdgcn_perm(0x00470054u, 0x00430041u, d[i] & 0x06060606u);
         z[i] = expect ^ (d[i] & 0xDFDFDFDFu);                       // zero byte <=> standard base
         a0[i >> 1] = __builtin_amdgcn_udot4(d[i] & 0x02020202u, w, a0[i >> 1], false);
         a1[i >> 1] = __builtin_amdgcn_udot4(d[i] & 0x04040404u, w, a1[i >> 1], false);
@@ -112,7 +113,11 @@ __device__ __forceinline__ bool stage_reads(const ScgReads& R, int64_t n_reads, 
     // All of a lane's loads are issued before any is consumed, so that it has 2*NW independent
     // 16-byte requests in flight instead of one HBM round trip per chunk.  Only the first and the
     // last workgroup of a buffer can touch bytes outside [0, total); they take the guarded loop.
+#ifdef SCG_STAGE_BATCH
+    constexpr int BATCH = SCG_STAGE_BATCH;
+#else
     constexpr int BATCH = NW;
+#endif
     const bool edge = span0 < 0 || (uint64_t)(span0 + 16 * (int64_t)nchunks) > total;
     for (int c0 = threadIdx.x; c0 < nchunks; c0 += STAGE_BLOCK * BATCH) {
         uint4 x[BATCH];

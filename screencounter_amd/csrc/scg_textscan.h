@@ -1,0 +1,45 @@
+// scg_textscan.h -- device-side FASTQ record scan (scg_textscan.hip): raw text window -> sequences + offsets.
+#ifndef SCG_TEXTSCAN_H
+#define SCG_TEXTSCAN_H
+
+#include <hip/hip_runtime_api.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace scg {
+
+enum : uint32_t {
+    TEXTSCAN_MALFORMED = 1,        // some record is not an ordinary 4-line record
+    TEXTSCAN_NOT_FOUR_LINES = 2,   // the window's line count is not a multiple of four
+    TEXTSCAN_CAPACITY = 4,         // more lines / records / sequence bytes than the slot's buffers hold (very short lines)
+};
+
+// Written by the device, copied back by the host before the counting kernels of the window are launched.
+struct TextScanResult {
+    uint32_t n_lines;
+    uint32_t n_records;
+    uint32_t max_len;      // longest sequence of the window
+    uint32_t flags;        // TEXTSCAN_*: non-zero => the host falls back to the sequential reference-exact reader
+    uint64_t seq_bytes;    // total sequence bytes (= offsets[n_records])
+};
+
+// Device scratch and outputs of one window.
+struct TextScanBuffers {
+    uint32_t* block_counts;   // [cap_blocks]: newline count per 4 KiB text tile, then their exclusive scan
+    uint32_t* nl;             // [cap_lines]: byte position of every newline
+    uint32_t* offsets;        // [cap_records + 1]: out, byte offset of every sequence in `seqs`
+    char* seqs;               // [cap_seq_bytes]: out, the sequences back to back
+    TextScanResult* result;
+    size_t cap_blocks, cap_lines, cap_records, cap_seq_bytes;
+};
+
+size_t text_scan_blocks(size_t n_bytes);    // text tiles of a window
+size_t text_scan_padded(size_t n_bytes);    // device text buffers must be readable up to this many bytes
+
+// Asynchronous on `stream`.  The text must start at a record start; the last byte of the final window of a file must be
+// a newline (the host appends one when the file lacks it, as the reference accepts a final record without it).
+hipError_t launch_text_scan(const char* d_text, size_t n_bytes, const TextScanBuffers& B, hipStream_t stream);
+
+} // namespace scg
+
+#endif

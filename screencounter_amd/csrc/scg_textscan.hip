@@ -1,0 +1,200 @@
+// scg_textscan.hip -- device-side FASTQ record scan: raw FASTQ text in HBM -> concatenated sequences + offsets.
+//
+// The host ships windows of raw text (plain file bytes, or the output of the inflate threads) across PCIe exactly once
+// and never looks at the records itself; these kernels find the line structure, check that every record of the window
+// is an ordinary 4-line record and cut the sequence lines out into the layout the counting kernels consume
+// (ScgReads: bytes back to back + uint32 offsets).  They implement the common case of kaori::FastqReader
+// (inst/include/kaori/FastqReader.hpp:42-110) -- '@' line, one sequence line without '+', '+' line, one quality line
+// as long as the sequence; '\r' stays a base like any other byte -- and REPORT everything else (multi-line records,
+// malformed input, stray blank lines, a line count that is not a multiple of four) through TextScanResult::flags, on
+// which the host redoes the whole file with the sequential reader that reproduces the reference's behaviour and error
+// messages exactly (scg_fastq.cpp).  A window always starts at a record start (scg_ingest.cpp), so the line grouping
+// found here is the sequential parser's grouping whenever no flag is raised.
+#include <hip/hip_runtime.h>
+
+#include "scg_textscan.h"
+
+namespace {
+
+constexpr int TS_BLOCK = 256;
+constexpr int TS_BYTES = 16;                       // text bytes per lane
+constexpr int TS_TILE = TS_BLOCK * TS_BYTES;       // text bytes per workgroup
+
+// Bit 7 of byte j set iff byte j of x is '\n' (exact: no borrow between bytes).
+__device__ __forceinline__ uint32_t newline_bytes(uint32_t x) {
+    const uint32_t y = x ^ 0x0A0A0A0Au;
+    return ~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y) & 0x80808080u;
+}
+
+// 16-bit mask of the newlines among the 16 text bytes at `pos` (bytes at or beyond n are ignored).
+__device__ __forceinline__ uint32_t newline_mask(const char* __restrict__ text, uint64_t pos, uint64_t n) {
+    if (pos >= n) return 0;
+    const uint4 x = *reinterpret_cast<const uint4*>(text + pos);      // the buffer is padded to a whole tile
+    const uint32_t d[4] = {x.x, x.y, x.z, x.w};
+    uint32_t m = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t t = newline_bytes(d[i]);
+        // bits 7, 15, 23, 31 -> bits 0..3
+        m |= (((t >> 7) & 1u) | ((t >> 14) & 2u) | ((t >> 21) & 4u) | ((t >> 28) & 8u)) << (4 * i);
+    }
+    const uint64_t left = n - pos;
+    if (left < 16) m &= (1u << left) - 1u;
+    return m;
+}
+
+__global__ __launch_bounds__(TS_BLOCK) void count_newlines_kernel(const char* __restrict__ text, uint64_t n, uint32_t* __restrict__ block_counts) {
+    __shared__ uint32_t part[TS_BLOCK / 64];
+    const uint64_t pos = ((uint64_t)blockIdx.x * TS_BLOCK + threadIdx.x) * TS_BYTES;
+    uint32_t c = __popc(newline_mask(text, pos, n));
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t s = 0;
+        for (int w = 0; w < TS_BLOCK / 64; ++w) s += part[w];
+        block_counts[blockIdx.x] = s;
+    }
+}
+
+// In-place exclusive scan of data[0 .. n) by ONE workgroup of 1024 lanes (n is a few hundred thousand at most);
+// data[n] receives the total.  n comes from *n_ptr when n_ptr is given (a count produced by an earlier kernel).
+constexpr int SCAN_BLOCK = 1024;
+__global__ __launch_bounds__(SCAN_BLOCK) void exclusive_scan_kernel(uint32_t* __restrict__ data, uint32_t n_fixed, const uint32_t* __restrict__ n_ptr,
+                                                                    uint32_t cap, uint32_t* __restrict__ total_out) {
+    __shared__ uint32_t sums[SCAN_BLOCK];
+    uint32_t n = n_ptr ? *n_ptr : n_fixed;
+    if (n > cap) n = cap;
+    const uint32_t per = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    const uint32_t lo = threadIdx.x * per, hi = (lo + per < n) ? lo + per : n;
+    uint32_t s = 0;
+    for (uint32_t i = lo; i < hi; ++i) s += data[i];
+    sums[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 1; off < SCAN_BLOCK; off <<= 1) {                 // Hillis-Steele over the 1024 partial sums
+        uint32_t v = threadIdx.x >= (unsigned)off ? sums[threadIdx.x - off] : 0;
+        __syncthreads();
+        sums[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = threadIdx.x ? sums[threadIdx.x - 1] : 0;
+    for (uint32_t i = lo; i < hi; ++i) {
+        const uint32_t v = data[i];
+        data[i] = run;
+        run += v;
+    }
+    if (threadIdx.x == SCAN_BLOCK - 1) {
+        data[n] = sums[SCAN_BLOCK - 1];
+        if (total_out) *total_out = sums[SCAN_BLOCK - 1];
+    }
+}
+
+// nl[k] = byte position of the k-th newline of the window.
+__global__ __launch_bounds__(TS_BLOCK) void newline_positions_kernel(const char* __restrict__ text, uint64_t n, const uint32_t* __restrict__ block_base,
+                                                                     uint32_t* __restrict__ nl, uint32_t cap_lines) {
+    __shared__ uint32_t wave_sum[TS_BLOCK / 64];
+    const uint64_t pos = ((uint64_t)blockIdx.x * TS_BLOCK + threadIdx.x) * TS_BYTES;
+    uint32_t m = newline_mask(text, pos, n);
+    const uint32_t c = __popc(m);
+    // exclusive scan of c over the workgroup
+    uint32_t incl = c;
+    const int lane = threadIdx.x & 63;
+    for (int off = 1; off < 64; off <<= 1) {
+        uint32_t v = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += v;
+    }
+    if (lane == 63) wave_sum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t base = block_base[blockIdx.x];
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) base += wave_sum[w];
+    uint32_t k = base + incl - c;
+    while (m) {
+        const int j = __ffs((int)m) - 1;
+        m &= m - 1;
+        if (k < cap_lines) nl[k] = (uint32_t)(pos + j);
+        ++k;
+    }
+}
+
+// One lane per record: structure checks, sequence length (written to lens[i], scanned into offsets afterwards).
+__global__ __launch_bounds__(TS_BLOCK) void records_kernel(const char* __restrict__ text, const uint32_t* __restrict__ nl, uint32_t cap_lines,
+                                                           uint32_t cap_records, uint32_t* __restrict__ lens, scg::TextScanResult* __restrict__ res) {
+    const uint32_t n_lines = res->n_lines;
+    const uint32_t n_rec = n_lines / 4;
+    const uint32_t i = blockIdx.x * TS_BLOCK + threadIdx.x;
+    if (i == 0) {
+        uint32_t f = 0;
+        if (n_lines % 4 != 0) f |= scg::TEXTSCAN_NOT_FOUR_LINES;
+        if (n_lines > cap_lines || n_rec > cap_records) f |= scg::TEXTSCAN_CAPACITY;
+        if (f) atomicOr(&res->flags, f);
+        res->n_records = n_rec;
+    }
+    uint32_t len = 0;
+    if (i < n_rec && n_lines <= cap_lines && n_rec <= cap_records) {
+        const uint32_t l0 = i ? nl[4 * i - 1] + 1 : 0;     // '@' line
+        const uint32_t e0 = nl[4 * i];
+        const uint32_t s = e0 + 1, e1 = nl[4 * i + 1];      // sequence line
+        const uint32_t p = e1 + 1, e2 = nl[4 * i + 2];      // '+' line
+        const uint32_t q = e2 + 1, e3 = nl[4 * i + 3];      // quality line
+        len = e1 - s;
+        const bool ok = text[l0] == '@' && text[p] == '+' && (e3 - q) == len;
+        lens[i] = len;
+        if (!ok) atomicOr(&res->flags, scg::TEXTSCAN_MALFORMED);
+    }
+    // longest read of the window (one atomic per wavefront; every lane takes part in the reduction)
+    uint32_t mx = len;
+    for (int off = 32; off > 0; off >>= 1) { const uint32_t o = __shfl_down(mx, off, 64); mx = o > mx ? o : mx; }
+    if ((threadIdx.x & 63) == 0 && mx) atomicMax(&res->max_len, mx);
+}
+
+// One wavefront per record: copies the sequence line to seqs[offsets[i] ...); a '+' inside it would have ended the
+// sequence early for the reference's reader (FastqReader.hpp:66-84), which is not an ordinary record.
+__global__ __launch_bounds__(TS_BLOCK) void compact_kernel(const char* __restrict__ text, const uint32_t* __restrict__ nl, const uint32_t* __restrict__ offsets,
+                                                           char* __restrict__ seqs, uint64_t cap_seq_bytes, scg::TextScanResult* __restrict__ res) {
+    if (res->flags & (scg::TEXTSCAN_CAPACITY | scg::TEXTSCAN_NOT_FOUR_LINES)) return;
+    const uint32_t n_rec = res->n_records;
+    const int lane = threadIdx.x & 63;
+    const uint32_t waves = gridDim.x * (TS_BLOCK / 64);
+    bool plus = false, over = false;
+    for (uint32_t i = blockIdx.x * (TS_BLOCK / 64) + (threadIdx.x >> 6); i < n_rec; i += waves) {
+        const uint32_t s = nl[4 * i] + 1, len = nl[4 * i + 1] - s;
+        const uint64_t dst = offsets[i];
+        if (dst + len > cap_seq_bytes) { over = true; continue; }
+        for (uint32_t j = lane; j < len; j += 64) {
+            const char c = text[s + j];
+            plus |= c == '+';
+            seqs[dst + j] = c;
+        }
+    }
+    if (__ballot(plus) && lane == 0) atomicOr(&res->flags, scg::TEXTSCAN_MALFORMED);
+    if (__ballot(over) && lane == 0) atomicOr(&res->flags, scg::TEXTSCAN_CAPACITY);
+    if (blockIdx.x == 0 && threadIdx.x == 0) res->seq_bytes = offsets[n_rec];
+}
+
+} // namespace
+
+namespace scg {
+
+size_t text_scan_blocks(size_t n_bytes) { return (n_bytes + TS_TILE - 1) / TS_TILE; }
+size_t text_scan_padded(size_t n_bytes) { return text_scan_blocks(n_bytes) * TS_TILE; }
+
+hipError_t launch_text_scan(const char* d_text, size_t n_bytes, const TextScanBuffers& B, hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(B.result, 0, sizeof(TextScanResult), stream);
+    if (e != hipSuccess) return e;
+    if (n_bytes == 0) return hipSuccess;
+    const unsigned blocks = (unsigned)text_scan_blocks(n_bytes);
+    if (blocks + 1 > B.cap_blocks) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(count_newlines_kernel, dim3(blocks), dim3(TS_BLOCK), 0, stream, d_text, (uint64_t)n_bytes, B.block_counts);
+    hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(SCAN_BLOCK), 0, stream, B.block_counts, blocks, (const uint32_t*)nullptr, blocks, &B.result->n_lines);
+    hipLaunchKernelGGL(newline_positions_kernel, dim3(blocks), dim3(TS_BLOCK), 0, stream, d_text, (uint64_t)n_bytes, B.block_counts, B.nl, (uint32_t)B.cap_lines);
+    const unsigned rec_blocks = (unsigned)((B.cap_records + TS_BLOCK - 1) / TS_BLOCK);
+    // a window holds at most n_bytes / 6 records (six bytes is the shortest 4-line record): never launch more lanes than that
+    const unsigned need = (unsigned)((n_bytes / 6 + TS_BLOCK) / TS_BLOCK);
+    hipLaunchKernelGGL(records_kernel, dim3(need < rec_blocks ? need : rec_blocks), dim3(TS_BLOCK), 0, stream, d_text, B.nl, (uint32_t)B.cap_lines,
+                       (uint32_t)B.cap_records, B.offsets, B.result);
+    hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(SCAN_BLOCK), 0, stream, B.offsets, 0u, &B.result->n_records, (uint32_t)B.cap_records, (uint32_t*)nullptr);
+    hipLaunchKernelGGL(compact_kernel, dim3(2048), dim3(TS_BLOCK), 0, stream, d_text, B.nl, B.offsets, B.seqs, (uint64_t)B.cap_seq_bytes, B.result);
+    return hipGetLastError();
+}
+
+} // namespace scg

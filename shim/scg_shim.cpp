@@ -156,3 +156,63 @@ Rcpp::List match_barcodes(Rcpp::CharacterVector sequences, Rcpp::CharacterVector
     }
     return Rcpp::List::create(id, mm);
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Many files in one native call: optional additions for the matrixOf* functions.  With these three exported, e.g.
+// matrixOfSingleBarcodes (R/countSingleBarcodes.R:112-126) replaces its
+//     out <- bplapply(files, FUN=countSingleBarcodes, ..., BPPARAM=BPPARAM)
+// by one call whose result it unpacks into the same per-file list; libscg schedules the files over the GPUs itself
+// (one file at a time per device, library compiled once), so no BiocParallel worker processes are needed.
+// ---------------------------------------------------------------------------------------------------------------
+
+//[[Rcpp::export(rng=false)]]
+Rcpp::List count_single_barcodes_files(Rcpp::CharacterVector paths, std::string constant, int strand, Rcpp::CharacterVector pool,
+                                       int mismatches, bool use_first, int nthreads) {
+    auto f = borrow(paths), p = borrow(pool);
+    Rcpp::IntegerMatrix counts((int)pool.size(), paths.size());     // column f = file f
+    Rcpp::IntegerVector totals(paths.size());
+    char err[1024];
+    check(scg_count_single_barcodes_files(f.data(), (int32_t)f.size(), constant.c_str(), strand, p.data(), (int32_t)p.size(),
+                                          mismatches, use_first, nthreads, counts.begin(), totals.begin(), err, sizeof(err)), err);
+    return Rcpp::List::create(counts, totals);
+}
+
+//[[Rcpp::export(rng=false)]]
+Rcpp::List count_combo_barcodes_single_files(Rcpp::CharacterVector paths, std::string constant, int strand, Rcpp::List pool,
+                                             int mismatches, bool use_first, int nthreads) {
+    if (pool.size() != 2) Rcpp::stop("currently expecting only 2 variable regions for single-end combinatorial barcodes");
+    Rcpp::CharacterVector c0(pool[0]), c1(pool[1]);
+    auto f = borrow(paths), p0 = borrow(c0), p1 = borrow(c1);
+    std::vector<int32_t*> idx(f.size(), nullptr), freq(f.size(), nullptr);
+    std::vector<int64_t> k(f.size(), 0);
+    Rcpp::IntegerVector totals(paths.size());
+    char err[1024];
+    check(scg_count_combo_barcodes_single_files(f.data(), (int32_t)f.size(), constant.c_str(), strand, p0.data(), (int32_t)p0.size(),
+                                                p1.data(), (int32_t)p1.size(), mismatches, use_first, nthreads,
+                                                idx.data(), freq.data(), k.data(), totals.begin(), err, sizeof(err)), err);
+    Rcpp::List out(paths.size());                        // one count_combo_barcodes_single() result per file
+    for (R_xlen_t i = 0; i < paths.size(); ++i) {
+        Rcpp::IntegerMatrix indices(2, k[i]);
+        std::copy(idx[i], idx[i] + 2 * k[i], indices.begin());
+        Rcpp::IntegerVector counts(freq[i], freq[i] + k[i]);
+        scg_free(idx[i]); scg_free(freq[i]);
+        out[i] = Rcpp::List::create(indices, counts, Rcpp::IntegerVector::create(totals[i]));
+    }
+    return out;
+}
+
+//[[Rcpp::export(rng=false)]]
+Rcpp::List count_dual_barcodes_files(Rcpp::CharacterVector paths1, std::string constant1, bool reverse1, int mismatches1, Rcpp::CharacterVector pool1,
+                                     Rcpp::CharacterVector paths2, std::string constant2, bool reverse2, int mismatches2, Rcpp::CharacterVector pool2,
+                                     bool randomized, bool use_first, int nthreads) {
+    if (pool1.size() != pool2.size()) Rcpp::stop("both barcode pools should be of the same length");
+    if (paths1.size() != paths2.size()) Rcpp::stop("'paths1' and 'paths2' should be of the same length");
+    auto f1 = borrow(paths1), f2 = borrow(paths2), p1 = borrow(pool1), p2 = borrow(pool2);
+    Rcpp::IntegerMatrix counts((int)pool1.size(), paths1.size());
+    Rcpp::IntegerVector totals(paths1.size());
+    char err[1024];
+    check(scg_count_dual_barcodes_files(f1.data(), constant1.c_str(), reverse1, mismatches1, p1.data(),
+                                        f2.data(), constant2.c_str(), reverse2, mismatches2, p2.data(), (int32_t)p1.size(), (int32_t)f1.size(),
+                                        randomized, use_first, nthreads, counts.begin(), totals.begin(), err, sizeof(err)), err);
+    return Rcpp::List::create(counts, totals);
+}

@@ -20,7 +20,7 @@ namespace Rcpp {
 [[noreturn]] void stop(const char* msg);
 [[noreturn]] void stop(const std::string& msg);
 
-struct ListProxy { operator SEXP() const; };
+struct ListProxy { operator SEXP() const; template<class T> ListProxy& operator=(const T&); };
 
 struct CharacterVector {
     struct Proxy { Proxy& operator=(const std::string&); Proxy& operator=(const char*); };

@@ -269,3 +269,30 @@ def random_match_case(rng: random.Random) -> dict:
     pool = make_pool(rng, rng.choice([1, 4, 30]), vlen, alphabet, iupac_rate=rng.choice([0, 0.1]))
     seqs = [mutate(rng, concrete(rng, rng.choice(pool)), 0.15, 0.03, 0.1) for _ in range(40)]
     return dict(kind="match", sequences=seqs, choices=pool, substitutions=rng.choice([0, 1, 2, 3]), reverse=rng.random() < 0.5)
+
+
+def write_bgzf(path: str, data: bytes, block: int = 60000, level: int = 6, eof_block: bool = True) -> None:
+    """BGZF ("blocked gzip", SAM/BAM specification section 4.1; what bgzip writes): a series of gzip members of at most
+    64 KiB, each carrying its own compressed size in a 'BC' extra subfield, optionally ended by the empty EOF member."""
+    import struct
+    import zlib
+
+    def member(chunk: bytes) -> bytes:
+        co = zlib.compressobj(level, zlib.DEFLATED, -15)
+        body = co.compress(chunk) + co.flush()
+        bsize = 12 + 6 + len(body) + 8
+        assert bsize <= 65536
+        head = b"\x1f\x8b\x08\x04" + b"\x00\x00\x00\x00" + b"\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, bsize - 1)
+        return head + body + struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk) & 0xFFFFFFFF)
+
+    with open(path, "wb") as f:
+        for a in range(0, len(data), block):
+            f.write(member(data[a:a + block]))
+        if eof_block:
+            f.write(member(b""))
+
+
+def fastq_text(reads, name_prefix: str = "r", trailing_newline: bool = True) -> bytes:
+    out = b"".join(b"@%s%d some comment\n" % (name_prefix.encode(), i) + (r.encode() if isinstance(r, str) else bytes(r)) + b"\n+\n" +
+                   b"I" * len(r) + b"\n" for i, r in enumerate(reads))
+    return out if trailing_newline else out[:-1]

@@ -40,7 +40,9 @@ def _reference(w, host, n, tmp_path, oracle):
             p = str(tmp_path / f"cfg{w.config_id}_{m}.fastq")
             synth.reads_to_fastq(p, arr[: n * L], L)
             paths.append(p)
-        threads = min(16, os.cpu_count() or 1)
+        # one thread: with more, the reference's reduce() merges its search cache while other workers read it
+        # ("latent race") -- it crashed once here at 16 threads
+        threads = 1
         if w.entry == "single":
             c, t = ref.count_single(paths[0], w.template, w.strand, w.pools[0], w.mismatches, w.use_first, threads)
         elif w.entry == "combo":

@@ -1,0 +1,130 @@
+"""Host side of the FASTQ staging (csrc/scg_ingest.cpp): the raw-text windows the file-level entry points ship to the GPU.
+Plain files, BGZF (members inflated in parallel) and ordinary gzip (one inflate stream, multi-member included) must all
+yield the decompressed text cut into windows of whole 4-line records; text that cannot be cut that way is declined
+(the counting calls then take the sequential reader).  No device needed."""
+import ctypes as C
+import gzip
+import os
+import random
+
+import pytest
+
+from tests import gen
+
+
+def text_windows(sc, path, window, threads=4):
+    from screencounter_amd import _lib
+    L = sc.load()
+    text, cuts = C.c_void_p(), C.c_void_p()
+    n, nw = C.c_int64(0), C.c_int64(0)
+    kind = C.create_string_buffer(16)
+    err = _lib.errbuf()
+    rc = L.scg_fastq_text_windows(os.fspath(path).encode(), int(window), int(threads), C.byref(text), C.byref(n), C.byref(cuts), C.byref(nw),
+                                  kind, err, _lib.ERRCAP)
+    if rc:
+        raise _lib.ScgError(rc, err.value.decode())
+    try:
+        data = C.string_at(text, n.value)
+        c = list((C.c_int64 * (nw.value + 1)).from_address(cuts.value))
+    finally:
+        L.scg_free(text)
+        L.scg_free(cuts)
+    return data, c, kind.value.decode()
+
+
+def strict_records(chunk: bytes):
+    """Parses whole ordinary 4-line records; returns the sequences (asserts the chunk holds nothing else)."""
+    lines = chunk.split(b"\n")
+    assert lines[-1] == b"", "window does not end with a newline"
+    lines = lines[:-1]
+    assert len(lines) % 4 == 0
+    seqs = []
+    for i in range(0, len(lines), 4):
+        assert lines[i].startswith(b"@") and lines[i + 2].startswith(b"+") and len(lines[i + 1]) == len(lines[i + 3])
+        seqs.append(lines[i + 1])
+    return seqs
+
+
+def random_reads(rng, n, lo=20, hi=160):
+    return ["".join(rng.choice("ACGTN") for _ in range(rng.randint(lo, hi))) for _ in range(n)]
+
+
+@pytest.mark.parametrize("form", ["plain", "bgzf", "bgzf_no_eof", "gzip", "gzip_multi"])
+@pytest.mark.parametrize("window", [4096, 70_001, 1 << 20])
+def test_windows_reassemble_the_text(sc, tmp_path, form, window):
+    rng = random.Random(hash((form, window)) & 0xFFFF)
+    reads = random_reads(rng, 3000)
+    text = gen.fastq_text(reads, trailing_newline=(window != 70_001))      # one size also covers "no final newline"
+    path = str(tmp_path / ("x.fastq" + ("" if form == "plain" else ".gz")))
+    if form == "plain":
+        open(path, "wb").write(text)
+    elif form.startswith("bgzf"):
+        gen.write_bgzf(path, text, block=(900 if window == 4096 else rng.choice([900, 5000, 60000])), eof_block=(form == "bgzf"))
+    elif form == "gzip":
+        with gzip.open(path, "wb") as f:
+            f.write(text)
+    else:
+        with open(path, "wb") as f:                                       # concatenated members without size fields
+            third = len(text) // 3
+            for part in (text[:third], text[third:2 * third], text[2 * third:]):
+                f.write(gzip.compress(part))
+    data, cuts, kind = text_windows(sc, path, window)
+    assert kind == {"plain": "plain", "bgzf": "bgzf", "bgzf_no_eof": "bgzf", "gzip": "gzip", "gzip_multi": "gzip"}[form]
+    assert data == (text if text.endswith(b"\n") else text + b"\n")
+    assert cuts[0] == 0 and cuts[-1] == len(data) and all(b > a for a, b in zip(cuts, cuts[1:]))
+    assert all(b - a <= window for a, b in zip(cuts, cuts[1:]))
+    got = []
+    for a, b in zip(cuts, cuts[1:]):
+        got += strict_records(data[a:b])
+    assert got == [r.encode() for r in reads]
+    if window == 4096:
+        assert len(cuts) > 50                                              # really cut into many windows
+
+
+def test_empty_inputs(sc, tmp_path):
+    p = tmp_path / "empty.fastq"
+    p.write_bytes(b"")
+    data, cuts, kind = text_windows(sc, p, 4096)
+    assert data == b"" and cuts == [0] and kind == "plain"
+    g = tmp_path / "empty.fastq.gz"
+    g.write_bytes(gzip.compress(b""))
+    data, cuts, kind = text_windows(sc, g, 4096)
+    assert data == b"" and cuts == [0]
+    b = tmp_path / "empty_bgzf.gz"
+    gen.write_bgzf(str(b), b"")
+    data, cuts, kind = text_windows(sc, b, 4096)
+    assert data == b"" and kind == "bgzf"
+
+
+def test_text_that_cannot_be_cut_is_declined(sc, tmp_path):
+    from screencounter_amd import _lib
+    # multi-line records (legal for the reference's reader, FastqReader.hpp:66-84): no window boundary can be verified
+    rec = b"@r\nACGT\nACGT\n+\nIIII\nIIII\n"
+    p = tmp_path / "multi.fastq"
+    p.write_bytes(rec * 2000)
+    with pytest.raises(_lib.ScgError) as e:
+        text_windows(sc, p, 4096)
+    assert e.value.code == _lib.SCG_ERR_UNSUPPORTED
+    # ... but a file that fits one window is handed over whole (the device scan then declines it)
+    data, cuts, _ = text_windows(sc, p, 1 << 20)
+    assert data == rec * 2000 and len(cuts) == 2
+
+
+def test_corrupt_gzip_member_is_an_io_error(sc, tmp_path):
+    from screencounter_amd import _lib
+    text = gen.fastq_text(random_reads(random.Random(5), 500))
+    p = str(tmp_path / "bad.gz")
+    gen.write_bgzf(p, text, block=5000)
+    raw = bytearray(open(p, "rb").read())
+    raw[len(raw) // 2] ^= 0x55
+    open(p, "wb").write(bytes(raw))
+    with pytest.raises(_lib.ScgError) as e:
+        text_windows(sc, p, 1 << 20)
+    assert e.value.code in (_lib.SCG_ERR_IO, _lib.SCG_ERR_UNSUPPORTED)
+
+
+def test_missing_file(sc, tmp_path):
+    from screencounter_amd import _lib
+    with pytest.raises(_lib.ScgError) as e:
+        text_windows(sc, tmp_path / "nope.fastq", 4096)
+    assert e.value.code == _lib.SCG_ERR_IO and "failed to open file" in str(e.value)

@@ -5,5 +5,5 @@
 set -e
 ROOT=$(cd $(dirname $0)/.. && pwd)
 mkdir -p $ROOT/tools/ablate
-make -s -C $ROOT/screencounter_amd/csrc OUT=$ROOT/tools/ablate/libscg_ablate.so EXTRA=-DSCG_ABLATE
+make -s -C $ROOT/screencounter_amd/csrc OUT=$ROOT/tools/ablate/libscg_ablate.so EXTRA=-DSCG_ABLATE OBJDIR=$ROOT/tools/ablate/build
 echo "built tools/ablate/libscg_ablate.so"
