@@ -202,6 +202,11 @@ int scg_match_barcodes(const char* const* sequences, int32_t n_sequences,
 
 void scg_free(void* p);
 
+/* The file-level entry points keep the pinned host windows and HBM scratch of their last run for the next call (at most
+ * three windows of <= 128 MB per device; counts never depend on it).  This releases them; SCG_BUFFER_CACHE=0 disables
+ * the cache altogether. */
+void scg_release_buffers(void);
+
 /* ---------------------------------------------------------------------------------------------
  * FASTQ staging (host).  Replaces kaori::FastqReader (inst/include/kaori/FastqReader.hpp:42-110)
  * over byteme::SomeFileReader (inst/include/byteme/SomeFileReader.hpp:31-44): gzip is detected by

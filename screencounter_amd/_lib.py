@@ -69,6 +69,7 @@ SIGNATURES = {
     "scg_fastq_text_windows": (C.c_int, [C.c_char_p, C.c_int64, C.c_int, C.POINTER(C.c_void_p), i64_p, C.POINTER(C.c_void_p), i64_p,
                                          C.c_char_p, C.c_char_p, C.c_size_t]),
     "scg_free": (None, [C.c_void_p]),
+    "scg_release_buffers": (None, []),
     "scg_parse_fastq": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), i64_p, C.c_char_p, C.c_size_t]),
     "scg_plan_single": (C.c_int, [C.POINTER(C.c_void_p), C.c_char_p, C.c_int, c_str_p, C.c_int32, C.c_int, C.c_int, C.c_int,
                                   C.c_char_p, C.c_size_t]),

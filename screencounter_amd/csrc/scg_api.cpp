@@ -8,6 +8,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <chrono>
 #include <climits>
 #include <cstdint>
 #include <cstdio>
@@ -68,6 +69,24 @@ int guarded(char* err, size_t cap, F f) {
         return SCG_ERR_INVALID;
     }
 }
+
+// Opt-in stage timings on stderr (SCG_TRACE=1): where a file-level call spends its wall time.
+struct Trace {
+    bool on;
+    std::chrono::steady_clock::time_point t0, last;
+    Trace() : on(false) {
+        const char* e = std::getenv("SCG_TRACE");
+        on = e && *e && *e != '0';
+        t0 = last = std::chrono::steady_clock::now();
+    }
+    void mark(const char* what) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[scg] %-28s %8.2f ms  (total %8.2f ms)\n", what,
+                     std::chrono::duration<double, std::milli>(now - last).count(), std::chrono::duration<double, std::milli>(now - t0).count());
+        last = now;
+    }
+};
 
 int resolve_device(int device) {
     int n = 0;
@@ -635,10 +654,28 @@ void launch_batch(scg_plan* P, const ScgReads& R, int64_t n, hipStream_t stream)
     P->total += n;
 }
 
+// Paired-end kernels search each template on ONE strand, fixed per plan: they get the scan description with that strand in
+// the forward fields, so that they neither carry both strands' seeds and planes in SGPRs nor select between them at run time.
+ScgScan searched_strand_first(const ScgScan& t, bool reverse) {
+    if (!reverse) return t;
+    ScgScan o = t;
+    o.fseeds = t.rseeds; o.rseeds = t.fseeds;
+    for (int r = 0; r < SCG_MAX_REGIONS; ++r) {
+        o.fstart[r] = t.rstart[r]; o.rstart[r] = t.fstart[r];
+        o.flen[r] = t.rlen[r]; o.rlen[r] = t.flen[r];
+    }
+    for (int w = 0; w < SCG_MAX_TEMPLATE / 32; ++w) {
+        o.fplane0[w] = t.rplane0[w]; o.rplane0[w] = t.fplane0[w];
+        o.fplane1[w] = t.rplane1[w]; o.rplane1[w] = t.fplane1[w];
+        o.fmask[w] = t.rmask[w]; o.rmask[w] = t.fmask[w];
+    }
+    return o;
+}
+
 void launch_batch_paired(scg_plan* P, const ScgReads& R1, const ScgReads& R2, int64_t n, hipStream_t stream) {
     scg_plan::Timer timer(P, stream);
     ScgDualParams dp;
-    dp.scan1 = P->scan1; dp.scan2 = P->scan2;
+    dp.scan1 = searched_strand_first(P->scan1, P->rev1); dp.scan2 = searched_strand_first(P->scan2, P->rev2);
     dp.tmpl1 = P->d_tmpl1.as<ScgTemplate>(); dp.tmpl2 = P->d_tmpl2.as<ScgTemplate>();
     dp.index1 = P->tab[0].view; dp.index2 = P->tab[1].view; dp.pairs = P->pairs.view;
     dp.rev1 = P->rev1; dp.rev2 = P->rev2; dp.max_mm1 = P->max_mm1; dp.max_mm2 = P->max_mm2;
@@ -817,6 +854,7 @@ struct UnusualInput {};
 
 struct ScanSlot {
     scg_plan* plan = nullptr;
+    int plan_device = -1;
     hipStream_t stream = nullptr;
     PinnedBuf text, h_result;
     DevBuf d_text, d_counts, d_nl, d_offsets, d_seqs, d_result;
@@ -827,6 +865,7 @@ struct ScanSlot {
 
     void init(scg_plan* P, size_t window) {
         plan = P;
+        plan_device = P->device;
         cap = window;
         DeviceGuard g(P->device);
         HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
@@ -851,7 +890,7 @@ struct ScanSlot {
     ~ScanSlot() {
         if (stream) {
             int prev = -1;
-            if (plan && hipGetDevice(&prev) == hipSuccess && prev != plan->device) (void)hipSetDevice(plan->device); else prev = -1;
+            if (plan_device >= 0 && hipGetDevice(&prev) == hipSuccess && prev != plan_device) (void)hipSetDevice(plan_device); else prev = -1;
             (void)hipStreamSynchronize(stream);
             (void)hipStreamDestroy(stream);
             if (prev >= 0) (void)hipSetDevice(prev);
@@ -871,16 +910,62 @@ size_t scan_window_bytes(uint64_t hint) {
     return std::max(w, floor);
 }
 
+// Idle scan slots are kept for the next call (pinning and unpinning 3 x 128 MB of host memory costs ~120 ms, a third
+// of the time a 10 GB file takes): at most three per device, released by scg_release_buffers() or with the process.
+struct SlotPool {
+    std::mutex mu;
+    std::vector<std::unique_ptr<ScanSlot> > idle;
+    std::unique_ptr<ScanSlot> take(scg_plan* P, size_t window) {
+        {
+            std::lock_guard<std::mutex> g(mu);
+            for (size_t i = 0; i < idle.size(); ++i) {
+                if (idle[i]->plan_device == P->device && idle[i]->cap >= window && idle[i]->cap <= 2 * window + (size_t(8) << 20)) {
+                    std::unique_ptr<ScanSlot> s = std::move(idle[i]);
+                    idle.erase(idle.begin() + static_cast<long>(i));
+                    s->plan = P;
+                    return s;
+                }
+            }
+        }
+        std::unique_ptr<ScanSlot> s(new ScanSlot);
+        s->init(P, window);
+        return s;
+    }
+    void give(std::unique_ptr<ScanSlot> s) {
+        const char* e = std::getenv("SCG_BUFFER_CACHE");
+        if (e && *e == '0') return;
+        s->plan = nullptr;
+        std::lock_guard<std::mutex> g(mu);
+        int same = 0;
+        for (auto& x : idle) same += x->plan_device == s->plan_device;
+        if (same < 3) idle.push_back(std::move(s));
+    }
+    void clear() {
+        std::lock_guard<std::mutex> g(mu);
+        idle.clear();
+    }
+};
+
+SlotPool& slot_pool() {
+    static SlotPool* pool = new SlotPool;      // deliberately never destroyed: the HIP runtime may be gone by then
+    return *pool;
+}
+
 void count_text_stream(const std::vector<scg_plan*>& plans, scg::TextSource& src) {
     const int slots_per_plan = 3;
     const size_t window = scan_window_bytes(src.size_hint());
+    Trace tr;
     std::vector<std::unique_ptr<ScanSlot> > slots;
+    struct Return {
+        std::vector<std::unique_ptr<ScanSlot> >& v;
+        bool ok = false;
+        ~Return() { if (ok) for (auto& s : v) if (s) slot_pool().give(std::move(s)); }
+    } ret{slots};
     for (int k = 0; k < slots_per_plan; ++k) {
-        for (scg_plan* P : plans) {
-            slots.emplace_back(new ScanSlot);
-            slots.back()->init(P, window);
-        }
+        for (scg_plan* P : plans) slots.push_back(slot_pool().take(P, window));
     }
+    tr.mark("  scan slots (pinned + HBM)");
+    double t_fill = 0, t_finish = 0;
     auto finish = [&](ScanSlot& s) {
         DeviceGuard g(s.plan->device);
         HIP_CHECK(hipStreamSynchronize(s.stream));                // copy + scan + result are in
@@ -893,27 +978,40 @@ void count_text_stream(const std::vector<scg_plan*>& plans, scg::TextSource& src
         }
         s.busy = true;
     };
-    ScanSlot* prev = nullptr;
-    for (size_t k = 0;; ++k) {
+    // Window k is filled and put on the wire; the counting kernels of window k - lag are launched afterwards, by which
+    // time its copy and scan have normally finished: the host thread does not wait on the link.
+    const size_t lag = plans.size() * 2 < slots.size() ? plans.size() * 2 : slots.size() - 1;
+    size_t k = 0;
+    for (;; ++k) {
         ScanSlot& s = *slots[k % slots.size()];
         DeviceGuard g(s.plan->device);
+        if (s.pending) finish(s);                                 // (never true with lag < slots.size(); kept for safety)
         if (s.busy) { HIP_CHECK(hipStreamSynchronize(s.stream)); s.busy = false; }
+        const auto f0 = std::chrono::steady_clock::now();
         const size_t bytes = src.next(s.text.as<char>(), s.cap);
+        t_fill += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - f0).count();
         if (src.unusual()) throw UnusualInput();
         if (bytes == 0) break;
         HIP_CHECK(hipMemcpyAsync(s.d_text.p, s.text.p, bytes, hipMemcpyHostToDevice, s.stream));
         HIP_CHECK(scg::launch_text_scan(s.d_text.as<char>(), bytes, s.B, s.stream));
         HIP_CHECK(hipMemcpyAsync(s.h_result.p, s.d_result.p, sizeof(scg::TextScanResult), hipMemcpyDeviceToHost, s.stream));
         s.pending = true;
-        if (prev) finish(*prev);
-        prev = &s;
+        const auto f1 = std::chrono::steady_clock::now();
+        if (k >= lag) finish(*slots[(k - lag) % slots.size()]);
+        t_finish += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - f1).count();
     }
-    if (prev && prev->pending) finish(*prev);
+    for (size_t j = k > lag ? k - lag : 0; j < k; ++j) {
+        ScanSlot& s = *slots[j % slots.size()];
+        if (s.pending) finish(s);
+    }
     for (auto& s : slots) {
         DeviceGuard g(s->plan->device);
         HIP_CHECK(hipStreamSynchronize(s->stream));
         s->busy = false;
     }
+    ret.ok = true;
+    if (tr.on) std::fprintf(stderr, "[scg]   windows of %zu MB: host fill %.2f ms, waiting for scans %.2f ms\n", window >> 20, t_fill, t_finish);
+    tr.mark("  windows");
 }
 
 void reset_plan(scg_plan* P) {
@@ -1271,6 +1369,8 @@ int scg_device_count(void) {
 
 void scg_free(void* p) { std::free(p); }
 
+void scg_release_buffers(void) { slot_pool().clear(); }
+
 int scg_parse_fastq(const char* path, char** seqs_out, uint64_t** offsets_out, int64_t* n_reads_out, char* err, size_t errcap) {
     return guarded(err, errcap, [&] {
         if (!path || !seqs_out || !offsets_out || !n_reads_out) throw Error(SCG_ERR_INVALID, "null argument");
@@ -1501,12 +1601,17 @@ int scg_count_single_barcodes(const char* path, const char* constant, int strand
                               char* err, size_t errcap) {
     return guarded(err, errcap, [&] {
         if (!path || !counts_out || !total_out) throw Error(SCG_ERR_INVALID, "null argument");
+        Trace tr;
         scg::FastqStream fq(path);                                           // src/count_single_barcodes.cpp:30
-        PlanSet set(compile_single(constant, strand, pool, n_pool, mismatches, use_first),   // :31-47
-                    devices_for_input(text_bytes_hint(path)));
+        auto compiled = compile_single(constant, strand, pool, n_pool, mismatches, use_first);   // :31-47
+        tr.mark("compile template + library");
+        PlanSet set(std::move(compiled), devices_for_input(text_bytes_hint(path)));
+        tr.mark("upload to device(s)");
         count_single_end(set.all(), path, fq, nthreads);
+        tr.mark("count file");
         set.read(counts_out);
         *total_out = narrow_total(set.total());
+        tr.mark("read counters");
     });
 }
 

@@ -583,13 +583,15 @@ __device__ __forceinline__ bool mate_search_staged(const Tile<NW>& tile, const S
     index = -1; mism = 0;
     int best = max_mm + 1;
     uint32_t cand[NC], unused[NC];
-    if (reverse) scan_read<NW, NC>(tile, sr, T, false, true, unused, cand); else scan_read<NW, NC>(tile, sr, T, true, false, cand, unused);
-    const int start = reverse ? T.rstart[0] : T.fstart[0];
+    // T carries the searched strand in its forward fields (searched_strand_first, scg_api.cpp); `reverse` only says how
+    // the extracted region is to be read
+    scan_read<NW, NC>(tile, sr, T, true, false, cand, unused);
+    const int start = T.fstart[0];
     for (;;) {
         int p = first_bit<NC>(cand);
         if (p >= (1 << 30)) break;
         clear_bit<NC>(cand, p);
-        int c = window_mismatches<NW, NT>(tile, sr.bit + p, T, reverse);
+        int c = window_mismatches<NW, NT>(tile, sr.bit + p, T, false);
         if (c > max_mm) continue;
         Query q = region_query<NW>(tile, sr.bit + p + start, X.len, reverse);
         int idx, d;
@@ -615,18 +617,19 @@ __device__ __forceinline__ void dual_orientation_staged(const ScgDualParams& P, 
     const ScgScan& T1 = P.scan1;
     const ScgScan& T2 = P.scan2;
     const bool rev1 = P.rev1 != 0, rev2 = P.rev2 != 0;
-    const int s1 = rev1 ? T1.rstart[0] : T1.fstart[0];
-    const int s2 = rev2 ? T2.rstart[0] : T2.fstart[0];
+    // both scans carry the searched strand in their forward fields (searched_strand_first, scg_api.cpp)
+    const int s1 = T1.fstart[0];
+    const int s2 = T2.fstart[0];
     chosen = -1;
     best = P.max_mm1 + P.max_mm2 + 1;
     uint32_t c1[NC], c2[NC], unused[NC];
-    if (rev1) scan_read<NW, NC>(ta, a, T1, false, true, unused, c1); else scan_read<NW, NC>(ta, a, T1, true, false, c1, unused);
-    if (rev2) scan_read<NW, NC>(tb, b, T2, false, true, unused, c2); else scan_read<NW, NC>(tb, b, T2, true, false, c2, unused);
+    scan_read<NW, NC>(ta, a, T1, true, false, c1, unused);
+    scan_read<NW, NC>(tb, b, T2, true, false, c2, unused);
     for (;;) {
         int p1 = first_bit<NC>(c1);
         if (p1 >= (1 << 30)) break;
         clear_bit<NC>(c1, p1);
-        int m1 = window_mismatches<NW, NT>(ta, a.bit + p1, T1, rev1);
+        int m1 = window_mismatches<NW, NT>(ta, a.bit + p1, T1, false);
         if (m1 > P.max_mm1) continue;
         Query q1 = region_query<NW>(ta, a.bit + p1 + s1, P.index1.len, rev1);
         uint32_t w2[NC];
@@ -636,7 +639,7 @@ __device__ __forceinline__ void dual_orientation_staged(const ScgDualParams& P, 
             int p2 = first_bit<NC>(w2);
             if (p2 >= (1 << 30)) break;
             clear_bit<NC>(w2, p2);
-            int m2 = window_mismatches<NW, NT>(tb, b.bit + p2, T2, rev2);
+            int m2 = window_mismatches<NW, NT>(tb, b.bit + p2, T2, false);
             if (m2 > P.max_mm2) {
                 clear_bit<NC>(c2, p2);      // never a hit of mate 2: drop it for later outer iterations
                 continue;

@@ -4,10 +4,23 @@
 #include "scg_host.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <unordered_map>
 
 namespace scg {
+
+// Slots per entry of the group tables.  A wavefront repeats a probe step as long as ANY of its 64 lanes has not found its
+// chain, so collisions cost far more than their per-lookup rate suggests: at 50 % load nearly every wavefront probed twice
+// or more.  Small libraries, whose tables stay cache-resident anyway, get very sparse tables; for 100 k barcodes a
+// quarter load is the measured optimum (MI355X: config 3 -13 % at 64 slots per entry, configs 2 and 5 -4 % at 4, +1 % at
+// 8 where the tables start missing the L2).  SCG_TABLE_FACTOR overrides (tuning aid).
+static uint32_t table_factor(size_t n) {
+    if (const char* e = std::getenv("SCG_TABLE_FACTOR")) { const int v = std::atoi(e); if (v >= 2) return static_cast<uint32_t>(v); }
+    if (n <= 4096) return 64;
+    if (n <= 32768) return 16;
+    return 4;
+}
 
 namespace {
 
@@ -277,9 +290,9 @@ void finish_index(HostIndex& X, const std::vector<uint64_t>& keys, const std::ve
             if (it->second == static_cast<int32_t>(i)) heads[sgm].push_back(static_cast<int32_t>(i));
         }
     }
-    // open addressing with linear probing at <= 50 % load, one slot count for all tables
+    // open addressing with linear probing, one slot count for all tables (load: table_factor)
     uint32_t cap = 16;
-    while (cap < n * 2) cap <<= 1;
+    while (cap < n * table_factor(n)) cap <<= 1;
     X.slot_mask = cap - 1;
     std::vector<std::vector<int32_t> > placed(nseg);
     for (int sgm = 0; sgm < nseg; ++sgm) {
@@ -434,7 +447,7 @@ HostIndex build_index_wide(const char* const* pool, int32_t n, int32_t len, int 
     }
     if (nseg == 0) return X;
     uint32_t cap = 16;
-    while (cap < cnt * 2) cap <<= 1;
+    while (cap < cnt * table_factor(cnt)) cap <<= 1;
     X.slot_mask = cap - 1;
     X.tables.assign(static_cast<size_t>(nseg) * cap * 8, 0);
     for (int sgm = 0; sgm < nseg; ++sgm) {

@@ -7,6 +7,7 @@ on the host with numpy from the same base seed.  Nothing here is part of the cou
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass, field
 from typing import List, Optional, Sequence, Tuple
 
@@ -306,8 +307,49 @@ def generate_host(w: Workload, n_reads: int, first_read: int = 0, mate: int = 0)
     return out.reshape(-1)
 
 
-def reads_to_fastq(path: str, seqs: np.ndarray, read_len: int, start_index: int = 0) -> int:
+def reads_to_fastq(path: str, seqs: np.ndarray, read_len: int, start_index: int = 0, chunk: int = 4_000_000) -> int:
     """Write fixed-length reads (uint8 array of n*read_len bytes) as a 4-line FASTQ; returns n."""
+    n = seqs.size // read_len
+    if n > chunk:                                   # bounded memory for multi-GB files
+        open(path, "wb").close()
+        for a in range(0, n, chunk):
+            b = min(a + chunk, n)
+            _reads_to_fastq(path, seqs[a * read_len: b * read_len], read_len, start_index + a, "ab")
+        return n
+    return _reads_to_fastq(path, seqs, read_len, start_index, "wb")
+
+
+def _bgzf_member(chunk: bytes) -> bytes:
+    import struct
+    import zlib
+    co = zlib.compressobj(1, zlib.DEFLATED, -15)
+    body = co.compress(chunk) + co.flush()
+    return (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, 12 + 6 + len(body) + 8 - 1) +
+            body + struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk)))
+
+
+def _bgzf_span(args) -> bytes:
+    path, a, b = args
+    with open(path, "rb") as f:
+        f.seek(a)
+        data = f.read(b - a)
+    return b"".join(_bgzf_member(data[i:i + 65280]) for i in range(0, len(data), 65280))
+
+
+def fastq_to_bgzf(src: str, dst: str, workers: int = 8) -> None:
+    """Compress a FASTQ file into BGZF (blocked gzip, what bgzip writes: 64 KiB members that carry their size) with a
+    pool of worker processes; bench / test infrastructure."""
+    import multiprocessing as mp
+    size = os.path.getsize(src)
+    span = 65280 * 256
+    jobs = [(src, a, min(a + span, size)) for a in range(0, size, span)]
+    with mp.get_context("fork").Pool(max(1, workers)) as pool, open(dst, "wb") as out:
+        for blob in pool.imap(_bgzf_span, jobs):
+            out.write(blob)
+        out.write(_bgzf_member(b""))
+
+
+def _reads_to_fastq(path: str, seqs: np.ndarray, read_len: int, start_index: int, mode: str) -> int:
     n = seqs.size // read_len
     width = 10
     rec = 2 + width + 1 + read_len + 1 + 2 + read_len + 1
@@ -326,6 +368,6 @@ def reads_to_fastq(path: str, seqs: np.ndarray, read_len: int, start_index: int 
     buf[:, p + 2] = ord("\n")
     buf[:, p + 3:p + 3 + read_len] = ord("I")
     buf[:, p + 3 + read_len] = ord("\n")
-    with open(path, "wb") as f:
+    with open(path, mode) as f:
         f.write(buf.tobytes())
     return n

@@ -101,12 +101,14 @@ def test_unordinary_files_fall_back_to_the_sequential_reader(sc, oracle, gpu, tm
     exp, total = oracle.count_single(reads, TEMPLATE, 2, pool, 1, True)
     monkeypatch.setenv("SCG_WINDOW_KB", "8")
     # multi-line sequences and qualities: legal for the reference (FastqReader.hpp:66-84), declined by the scan
-    multi = b"".join(b"@r%d\n" % i + r[:7].encode() + b"\n" + r[7:].encode() + b"\n+\n" + b"I" * 7 + b"\n" + b"I" * (len(r) - 7) + b"\n"
-                     for i, r in enumerate(reads))
+    multi = b"".join(b"@r%d\n" % i + r[:len(r) // 2].encode() + b"\n" + r[len(r) // 2:].encode() + b"\n+\n" +
+                     b"I" * (len(r) // 2) + b"\n" + b"I" * (len(r) - len(r) // 2) + b"\n" for i, r in enumerate(reads) if len(r) >= 2)
+    exp, total = oracle.count_single([r for r in reads if len(r) >= 2], TEMPLATE, 2, pool, 1, True)
     p = str(tmp_path / "multi.fastq")
     open(p, "wb").write(multi)
     got, n = sc.count_single_barcodes(p, TEMPLATE, 2, pool, 1, True, 4)
     assert n == total and np.array_equal(got, exp)
+    exp, total = oracle.count_single(reads, TEMPLATE, 2, pool, 1, True)
     # a '+' inside a sequence line ends the sequence there for the reference; here: the same counts via the fallback
     q = str(tmp_path / "crlf.fastq")
     open(q, "wb").write(gen.fastq_text(reads).replace(b"\n", b"\r\n"))     # '\r' stays a base on every line
