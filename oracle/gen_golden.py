@@ -305,6 +305,8 @@ def main() -> None:
             c = gen.random_dual_single_end_case(rng, sizes=small, wide=(i % 3 == 0), diag=True)
             c["kind"] = "dual_single_end_diag"
             rnd.append(run_case(ref, c, tmp))
+        for i in range(30):     # templates with 3 to 5 variable regions (DualBarcodesSingleEnd.hpp:144-163 takes any number)
+            rnd.append(run_case(ref, gen.random_dual_single_end_case(rng, sizes=small, nreg=3 + i % 3), tmp))
         with open(os.path.join(OUT, "kaori_random.json"), "w") as f:
             json.dump({"generator": "oracle/gen_golden.py", "reference": "kaori v1.1.1 (screenCounter 1.5.1)", "seed": 20261003, "cases": rnd}, f)
 

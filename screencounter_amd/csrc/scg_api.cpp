@@ -345,8 +345,8 @@ std::unique_ptr<scg_plan> compile_dual_single_end(const char* constant, int stra
     const ScgTemplate& t = P->ht1.t;
     if (t.nreg != n_regions) throw Error(SCG_ERR_INVALID, "length of 'barcode_pools' should equal the number of variable regions");   // :76-78
     if (n_regions < 1 || n_regions > SCG_MAX_REGIONS) {
-        throw Error(SCG_ERR_UNSUPPORTED, "this engine counts dual barcodes in single-end reads with 1 or 2 variable regions (got " +
-                    std::to_string(n_regions) + ")");
+        throw Error(SCG_ERR_UNSUPPORTED, "this engine counts dual barcodes in single-end reads with 1 to " + std::to_string(SCG_MAX_REGIONS) +
+                    " variable regions (got " + std::to_string(n_regions) + ")");
     }
     int total = 0;
     for (int r = 0; r < n_regions; ++r) {                         // :80-87
@@ -1715,7 +1715,7 @@ int scg_count_random_barcodes(const char* path, const char* constant, int strand
         P->ht1 = scg::parse_template(constant, strand);
         const ScgTemplate& t = P->ht1.t;
         if (t.nreg < 1) throw Error(SCG_ERR_INVALID, "expected one variable region in the constant template");
-        if (t.nreg > SCG_MAX_REGIONS) throw Error(SCG_ERR_UNSUPPORTED, "this engine handles templates with at most 2 variable regions");
+        if (t.nreg > SCG_MAX_REGIONS) throw Error(SCG_ERR_UNSUPPORTED, "this engine handles templates with at most " + std::to_string(SCG_MAX_REGIONS) + " variable regions");
         if (mismatches < 0) throw Error(SCG_ERR_INVALID, "negative number of mismatches");
         P->scan1 = scg::build_scan(t, mismatches);
         P->max_mm1 = mismatches;

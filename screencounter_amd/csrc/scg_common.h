@@ -16,7 +16,8 @@
 #include <hip/hip_vector_types.h>
 
 #define SCG_MAX_TEMPLATE 256   // reference: src/count_single_barcodes.cpp:37-47
-#define SCG_MAX_REGIONS 2      // reference: src/count_combo_barcodes_single.cpp:44-46
+#define SCG_MAX_REGIONS 8      // variable regions per template (countDualBarcodesSingleEnd concatenates them: DualBarcodesSingleEnd.hpp:144-163)
+#define SCG_COMBO_REGIONS 2    // pools of countComboBarcodes; reference: src/count_combo_barcodes_single.cpp:44-46
 #define SCG_MAX_BARCODE 32     // bases per key of the narrow (2 x 32-bit plane) engine
 #define SCG_MAX_WIDE_BARCODE 64   // bases per key of the wide (2 x 64-bit plane) single-end engine
 #define SCG_MAX_SEGMENTS 6     // hash tables ("segment groups") of the library index (mismatch budgets <= 3)
@@ -177,8 +178,8 @@ struct ScgSingleParams {
 struct ScgComboParams {
     ScgScan scan;
     const ScgTemplate* tmpl;
-    ScgIndex index[SCG_MAX_REGIONS];
-    int32_t n_pool[SCG_MAX_REGIONS];
+    ScgIndex index[SCG_COMBO_REGIONS];
+    int32_t n_pool[SCG_COMBO_REGIONS];
     int32_t max_mm;
     int32_t use_first;
     int32_t fwd, rev;

@@ -139,12 +139,12 @@ __global__ __launch_bounds__(BLOCK) void random_kernel(ScgSingleParams P, ScgRea
 // combo (two variable regions in one template)
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool combo_candidate(const ScgComboParams& P, const Read& rd, int p, bool reverse, int c,
-                                                int out[SCG_MAX_REGIONS], int& total) {
+                                                int out[SCG_COMBO_REGIONS], int& total) {
     const ScgTemplate* T = P.tmpl;
     int obs = c;
-    for (int r = 0; r < SCG_MAX_REGIONS; ++r) {
+    for (int r = 0; r < SCG_COMBO_REGIONS; ++r) {
         // reverse scan order meets the pools back to front (CombinatorialBarcodesSingleEnd.hpp:111-116)
-        int slot = reverse ? (SCG_MAX_REGIONS - 1 - r) : r;
+        int slot = reverse ? (SCG_COMBO_REGIONS - 1 - r) : r;
         int start = reverse ? T->rstart[r] : T->fstart[r];
         const ScgIndex& tab = P.index[slot];
         Query q = pack_region(rd.p + p + start, tab.len, reverse);
@@ -160,7 +160,7 @@ __device__ __forceinline__ bool combo_candidate(const ScgComboParams& P, const R
 }
 
 // Returns 1 and fills best_id when the read yields a combination.
-__device__ __forceinline__ int combo_read(const ScgComboParams& P, const Read& rd, int best_id[SCG_MAX_REGIONS]) {
+__device__ __forceinline__ int combo_read(const ScgComboParams& P, const Read& rd, int best_id[SCG_COMBO_REGIONS]) {
     const ScgTemplate* T = P.tmpl;
     const int len = T->len;
     int found = 0, best = P.max_mm + 1;
@@ -169,7 +169,7 @@ __device__ __forceinline__ int combo_read(const ScgComboParams& P, const Read& r
             if (s == 0 ? !P.fwd : !P.rev) continue;
             int c = const_mismatches(T, s != 0, rd.p, p, P.max_mm);
             if (c > P.max_mm) continue;
-            int cand[SCG_MAX_REGIONS], tot;
+            int cand[SCG_COMBO_REGIONS], tot;
             if (!combo_candidate(P, rd, p, s != 0, c, cand, tot)) continue;
             if (P.use_first) {                          // :197-217
                 found = 1; best_id[0] = cand[0]; best_id[1] = cand[1];
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(BLOCK) void combo_kernel(ScgComboParams P, ScgReads
     if (i >= n_reads) return;
     if (P.only_if_negative && P.only_if_negative[i] >= 0) return;      // second pass of the single-end dual diagnostics
     Read rd = get_read(R, i);
-    int best_id[SCG_MAX_REGIONS] = {0, 0};
+    int best_id[SCG_COMBO_REGIONS] = {0, 0};
     if (combo_read(P, rd, best_id)) count_one(cells, (int64_t)best_id[0] * P.n_pool[1] + best_id[1]);
 }
 
@@ -503,11 +503,11 @@ __global__ __launch_bounds__(STAGE_BLOCK) __attribute__((amdgpu_num_sgpr(80))) v
 // the ordinary combination kernel keeps its code (a run-time flag here cost it 9 %).
 template<int NW, int NT, bool SECOND>
 __device__ __forceinline__ bool combo_candidate_staged(const ScgComboParams& P, const Tile<NW>& tile, const StrandTable<NT>& st, const StagedRead& sr,
-                                                       int p, bool reverse, int c, int out[SCG_MAX_REGIONS], int& total) {
+                                                       int p, bool reverse, int c, int out[SCG_COMBO_REGIONS], int& total) {
     int obs = c;
 #pragma unroll
-    for (int r = 0; r < SCG_MAX_REGIONS; ++r) {
-        int slot = reverse ? (SCG_MAX_REGIONS - 1 - r) : r;
+    for (int r = 0; r < SCG_COMBO_REGIONS; ++r) {
+        int slot = reverse ? (SCG_COMBO_REGIONS - 1 - r) : r;
         const int start = region_start<NT>(st, r, reverse);
         const ScgIndex& tab = P.index[slot];
         Query q = region_query<NW>(tile, sr.bit + p + start, tab.len, reverse);
@@ -536,7 +536,7 @@ __global__ __launch_bounds__(STAGE_BLOCK, SCG_COMBO_WAVES) __attribute__((amdgpu
     if ((int)threadIdx.x >= nr) return;
     Read rd = get_read(R, r0 + threadIdx.x);
     int found = 0, best = P.max_mm + 1;
-    int best_id[SCG_MAX_REGIONS] = {0, 0};
+    int best_id[SCG_COMBO_REGIONS] = {0, 0};
     if (!staged || rd.n > 32 * NW) {
         *error_flag = 1;
         return;
@@ -557,7 +557,7 @@ __global__ __launch_bounds__(STAGE_BLOCK, SCG_COMBO_WAVES) __attribute__((amdgpu
             clear_bit<NC>(candR, rev ? p : -1);
             int c = window_mismatches<NW, NT>(tile, sr.bit + p, strands, rev);
             if (c > P.max_mm) continue;
-            int cand[SCG_MAX_REGIONS], tot;
+            int cand[SCG_COMBO_REGIONS], tot;
             if (!combo_candidate_staged<NW, NT, SECOND>(P, tile, strands, sr, p, rev, c, cand, tot)) continue;
             if (P.use_first) {
                 found = 1; best_id[0] = cand[0]; best_id[1] = cand[1];

@@ -568,6 +568,8 @@ ScgScan build_scan(const ScgTemplate& t, int max_mm) {
     // k + 1 disjoint groups of constant positions for a budget of k mismatches; with fewer than
     // k + 1 constant bases (or k + 1 > SCG_MAX_SEEDS) no filter is possible and every position is
     // a candidate.
+    int seed_max = SCG_SEED_LEN;
+    if (const char* e = std::getenv("SCG_SEED_MAX")) { const int v = std::atoi(e); if (v >= 4 && v <= SCG_SEED_LEN) seed_max = v; }   // tuning aid
     auto fill = [&](ScgSeeds& S, const uint8_t* pos, const uint8_t* code) {
         int want = max_mm + 1;
         if (want > SCG_MAX_SEEDS || t.nconst < want) {
@@ -578,11 +580,11 @@ ScgScan build_scan(const ScgTemplate& t, int max_mm) {
         // Seeds are the first `want` runs of m consecutive constant positions: any disjoint groups
         // satisfy the pigeonhole argument, and groups near the template start keep every shift of
         // the bit-parallel walk short.
-        const int per = std::min(SCG_SEED_LEN, t.nconst / want);
+        const int per = std::min(seed_max, t.nconst / want);
         for (int i = 0; i < want; ++i) {
             int a = i * per;
             int b = a + per;
-            int m = std::min(b - a, SCG_SEED_LEN);
+            int m = std::min(b - a, seed_max);
             // Shrink the seed until every per-code walk fits its 16 step bytes (long shifts are
             // split into <= 31-bit steps, so far-apart bases cost extra bytes).
             for (;; --m) {
@@ -617,7 +619,7 @@ ScgScan build_scan(const ScgTemplate& t, int max_mm) {
     // no walk has to move a plane by 32 bits or more in total.
     sc.compact_ok = 1;
     auto check = [&](const ScgSeeds& S, const uint8_t* pos) {
-        const int per = S.nseeds > 0 ? std::min(SCG_SEED_LEN, t.nconst / S.nseeds) : 0;
+        const int per = S.nseeds > 0 ? std::min(seed_max, t.nconst / S.nseeds) : 0;
         for (int i = 0; i < S.nseeds; ++i) {
             int m = S.seed[i].len;
             if (m <= 0) continue;

@@ -195,13 +195,17 @@ def random_paired_combo_case(rng: random.Random, sizes=(1, 30, 150), max_mm: int
                 randomized=c["randomized"], use_first=c["use_first"], reads1=c["reads1"], reads2=c["reads2"])
 
 
-def random_dual_single_end_case(rng: random.Random, sizes=(1, 30, 150), wide: bool = None, diag: bool = False) -> dict:
-    """countDualBarcodesSingleEnd: one or two variable regions in one read, pools aligned by row
-    (row c = valid combination c); `wide` forces a combined key longer than 32 bases."""
-    nreg = 2 if diag else rng.choice([1, 2, 2])
+def random_dual_single_end_case(rng: random.Random, sizes=(1, 30, 150), wide: bool = None, diag: bool = False, nreg: int = None) -> dict:
+    """countDualBarcodesSingleEnd: the variable regions of one read, pools aligned by row (row c = valid combination c);
+    `wide` forces a combined key longer than 32 bases; nreg >= 3 exercises templates with many regions."""
+    if nreg is None:
+        nreg = 2 if diag else rng.choice([1, 2, 2])
     if wide is None:
         wide = rng.random() < 0.4
-    if nreg == 1:
+    if nreg >= 3:
+        lens = rng.choice({3: [[4, 6, 5], [8, 8, 8], [12, 20, 10], [20, 20, 20], [3, 30, 7]], 4: [[4, 4, 4, 4], [10, 10, 10, 10], [16, 16, 16, 16]],
+                           5: [[3, 4, 5, 6, 7], [12, 12, 12, 12, 12]]}[nreg])
+    elif nreg == 1:
         lens = [rng.choice([33, 40, 64] if wide else [4, 9, 20])]
     else:
         # (include.invalid=TRUE searches each region on its own with the narrow index: regions <= 32 bases there)

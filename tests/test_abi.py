@@ -96,7 +96,9 @@ def test_plan_argument_checks_precede_device_errors(sc):
     expect_error(sc, INV, "length of variable region 2 \\(2\\) should be the same as its sequences \\(3\\)", P.dual_single_end, "ACGT----TG--CA", 2, [["AAAA"], ["CCC"]])
     expect_error(sc, INV, "all entries of 'barcode_pools' should have the same length", P.dual_single_end, "ACGT----TG--CA", 2, [["AAAA", "CCCC"], ["CC"]])
     expect_error(sc, INV, "duplicate sequences detected \\(1, 2\\)", P.dual_single_end, "ACGT----TG--CA", 2, [["AAAA", "AAAA"], ["CC", "CC"]])
-    expect_error(sc, UNS, "1 or 2 variable regions", P.dual_single_end, "AC--GT--AC--GT", 2, [["AA"], ["CC"], ["GG"]])
+    nine = "AC" + "--GT" * 9
+    expect_error(sc, UNS, "1 to 8 variable regions \\(got 9\\)", P.dual_single_end, nine, 2, [["AA"]] * 9)
+    expect_error(sc, UNS, "64", P.dual_single_end, "AC" + ("-" * 30 + "GT") * 3, 2, [["A" * 30]] * 3)      # combined key > 64 bases
     expect_error(sc, INV, "expected 2 variable regions", P.combo, "ACGT----TGCA", 2, ["AAAA"], ["CC"])
     expect_error(sc, INV, "length of variable region 2 \\(3\\) should be the same as its sequences \\(2\\)", P.combo, "ACGT----TG---CA", 2, ["AAAA"], ["CC"])
     expect_error(sc, INV, "both barcode pools should be of the same length", P.dual, "AC--GT", False, 0, ["AA", "CC"], "AC--GT", False, 0, ["AA"])
