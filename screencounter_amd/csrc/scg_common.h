@@ -36,9 +36,10 @@
 // ScanTemplate reports (kaori/ScanTemplate.hpp:233-252); every candidate is then verified exactly.
 // Packed into dwords so that the whole description travels in the kernel-argument segment and
 // lives in SGPRs (gfx950 has no scalar byte loads).
-// For one (seed, base code): the walk along plane E[code].  Step k shifts the running copy of
-// the plane right by (byte & 31) bits and then ANDs it into the seed's match mask unless bit 7 is
-// set (a pure shift, used to split distances > 31).  Bytes are consumed from byte 0 of w[0] up.
+// For one (seed, base code): the walk along plane E[code], starting at template position 32 * ScgSeed::blk.  Step k
+// shifts the running copy of the plane right by (byte & 31) bits and then ANDs it into the seed's match mask unless
+// bit 7 is set (a pure shift).  Bytes are consumed from byte 0 of w[0] up.  A seed never straddles a 32-position block,
+// so that the compact scanner can take a shifted plane word with one funnel shift from two adjacent words.
 #define SCG_SEED_STEPS 16
 struct ScgSeedWalk {
     uint32_t w[SCG_SEED_STEPS / 4];
@@ -47,7 +48,8 @@ struct ScgSeedWalk {
 struct ScgSeed {
     int32_t len;                             // bases in the seed (0 => matches everywhere)
     uint32_t nsteps;                         // byte c: number of steps of walk[c]
-    int32_t pad[2];
+    int32_t blk;                             // the seed's bases all lie in template positions [32 blk, 32 blk + 32); walks are relative to 32 blk
+    int32_t pad;
     ScgSeedWalk walk[4];                     // per base code
 };
 
@@ -66,7 +68,7 @@ struct ScgScan {
     int32_t flen[SCG_MAX_REGIONS];            // region lengths, forward order
     int32_t rlen[SCG_MAX_REGIONS];            // ... in the order they appear on the reverse-complemented template
     ScgSeeds fseeds, rseeds;
-    int32_t compact_ok;                       // every seed starts below bit 32 and spans < 32 positions
+    int32_t compact_ok;                       // every seed lies in block 0 or 1 (template positions < 64)
     int32_t pad[3];
     // bit planes of the constant bases (word w covers template positions 32w .. 32w+31)
     uint32_t fplane0[SCG_MAX_TEMPLATE / 32], fplane1[SCG_MAX_TEMPLATE / 32], fmask[SCG_MAX_TEMPLATE / 32];

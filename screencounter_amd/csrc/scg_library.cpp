@@ -576,60 +576,63 @@ ScgScan build_scan(const ScgTemplate& t, int max_mm) {
             S.nseeds = 0;
             return;
         }
-        S.nseeds = want;
-        // Seeds are the first `want` runs of m consecutive constant positions: any disjoint groups
-        // satisfy the pigeonhole argument, and groups near the template start keep every shift of
-        // the bit-parallel walk short.
-        const int per = std::min(seed_max, t.nconst / want);
-        for (int i = 0; i < want; ++i) {
-            int a = i * per;
-            int b = a + per;
-            int m = std::min(b - a, seed_max);
-            // Shrink the seed until every per-code walk fits its 16 step bytes (long shifts are
-            // split into <= 31-bit steps, so far-apart bases cost extra bytes).
-            for (;; --m) {
-                bool fits = true;
-                ScgSeed sd;
-                std::memset(&sd, 0, sizeof(sd));
-                sd.len = m;
-                for (int c = 0; c < 4 && fits; ++c) {
-                    uint8_t steps[64];
-                    int ns = 0, prev = 0;
-                    for (int j = 0; j < m; ++j) {
-                        if (code[a + j] != c) continue;
-                        int delta = pos[a + j] - prev;
-                        prev = pos[a + j];
-                        while (delta > 31) { steps[ns++] = 0x80 | 31; delta -= 31; }   // pure shifts
-                        steps[ns++] = static_cast<uint8_t>(delta);                     // shift (maybe 0) then AND
-                    }
-                    if (ns & 1) steps[ns++] = 0;      // even step count: the compact scanner folds bases in pairs (a repeated AND is a no-op)
-                    if (ns > SCG_SEED_STEPS) { fits = false; break; }
-                    for (int k = 0; k < ns; ++k) {
-                        sd.walk[c].w[k >> 2] |= static_cast<uint32_t>(steps[k]) << (8 * (k & 3));
-                    }
-                    sd.nsteps |= static_cast<uint32_t>(ns) << (8 * c);
-                }
-                if (fits || m == 0) { S.seed[i] = sd; break; }
+        // Any k + 1 disjoint groups of constant positions satisfy the pigeonhole argument.  Candidates: runs of up to
+        // seed_max constant positions (consecutive in the list of constant positions) that stay inside one block of 32
+        // template positions -- the scanners take a shifted plane word from two adjacent words, and blocks 0 and 1 keep
+        // the compact scanner applicable.  The longest runs win (fewest false candidates), earlier ones first.
+        struct Run { int first, n, blk; };
+        std::vector<Run> runs;
+        for (int k = 0; k < t.nconst;) {
+            const int blk = pos[k] >> 5;
+            int n = 1;
+            while (k + n < t.nconst && n < seed_max && (pos[k + n] >> 5) == blk) ++n;
+            runs.push_back(Run{k, n, blk});
+            k += n;
+        }
+        if (static_cast<int>(runs.size()) < want) {      // fewer runs than seeds: split the longest until there are enough
+            while (static_cast<int>(runs.size()) < want) {
+                size_t big = 0;
+                for (size_t i = 1; i < runs.size(); ++i) if (runs[i].n > runs[big].n) big = i;
+                if (runs[big].n < 2) break;
+                const Run r = runs[big];
+                runs[big] = Run{r.first, r.n / 2, r.blk};
+                runs.insert(runs.begin() + static_cast<long>(big) + 1, Run{r.first + r.n / 2, r.n - r.n / 2, r.blk});
             }
+        }
+        if (static_cast<int>(runs.size()) < want) { S.nseeds = 0; return; }
+        std::stable_sort(runs.begin(), runs.end(), [](const Run& x, const Run& y) { return x.n > y.n; });
+        runs.resize(static_cast<size_t>(want));
+        std::sort(runs.begin(), runs.end(), [](const Run& x, const Run& y) { return x.first < y.first; });
+        S.nseeds = want;
+        for (int i = 0; i < want; ++i) {
+            const int a = runs[static_cast<size_t>(i)].first;
+            ScgSeed sd;
+            std::memset(&sd, 0, sizeof(sd));
+            sd.len = runs[static_cast<size_t>(i)].n;
+            sd.blk = runs[static_cast<size_t>(i)].blk;
+            for (int c = 0; c < 4; ++c) {
+                uint8_t steps[64];
+                int ns = 0, prev = 32 * sd.blk;
+                for (int j = 0; j < sd.len; ++j) {
+                    if (code[a + j] != c) continue;
+                    steps[ns++] = static_cast<uint8_t>(pos[a + j] - prev);      // < 32: shift (maybe 0) then AND
+                    prev = pos[a + j];
+                }
+                if (ns & 1) steps[ns++] = 0;      // even step count: the compact scanner folds bases in pairs (a repeated AND is a no-op)
+                for (int k = 0; k < ns; ++k) sd.walk[c].w[k >> 2] |= static_cast<uint32_t>(steps[k]) << (8 * (k & 3));
+                sd.nsteps |= static_cast<uint32_t>(ns) << (8 * c);
+            }
+            S.seed[i] = sd;
         }
     };
     fill(sc.fseeds, t.fpos, t.fcode);
     fill(sc.rseeds, t.rpos, t.rcode);
-    // The compact kernels keep only the candidate words plus one of the running planes: valid when
-    // no walk has to move a plane by 32 bits or more in total.
+    // The compact kernels keep only the candidate words and read shifted plane words straight from the planes: valid
+    // while every seed lies in block 0 or 1.
     sc.compact_ok = 1;
-    auto check = [&](const ScgSeeds& S, const uint8_t* pos) {
-        const int per = S.nseeds > 0 ? std::min(seed_max, t.nconst / S.nseeds) : 0;
-        for (int i = 0; i < S.nseeds; ++i) {
-            int m = S.seed[i].len;
-            if (m <= 0) continue;
-            int first = pos[i * per], last = pos[i * per + m - 1];
-            if (last >= 32) sc.compact_ok = 0;     // total shift of any walk = offset of its last base
-            (void)first;
-        }
-    };
-    check(sc.fseeds, t.fpos);
-    check(sc.rseeds, t.rpos);
+    for (const ScgSeeds* S : {&sc.fseeds, &sc.rseeds}) {
+        for (int i = 0; i < S->nseeds; ++i) if (S->seed[i].blk > 1) sc.compact_ok = 0;
+    }
     return sc;
 }
 

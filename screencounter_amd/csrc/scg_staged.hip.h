@@ -25,6 +25,7 @@
 #define SCG_STAGED_HIP_H
 
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "scg_engine.hip.h"
 
 namespace scgdev {
@@ -241,42 +242,56 @@ __device__ __forceinline__ void seed_candidates(const BasePlanes<NW>& E, const S
         for (int i = 0; i < NC; ++i) g[i] = 0xFFFFFFFFu;
         const uint32_t counts = S.seed[s].nsteps;
         if constexpr (NC < NW) {
-            // Compact form: every seed offset is < 32, so the plane shifted to a seed base is one
-            // funnel shift per word straight from E (no running copy), and two bases are folded
-            // into g with a single 3-input AND.  The host pads every walk to an even step count.
+            // Compact form: a seed's bases all lie in one 32-position block (blk 0 or 1, guaranteed by the host), so the
+            // plane shifted to a seed base is one funnel shift per word straight from two adjacent words of E (no running
+            // copy), and two bases are folded into g with a single 3-input AND.  The host pads every walk to an even step count.
+            static_assert(NC + 2 <= NW, "compact scanner: candidate words + two plane words of look-ahead");
+            auto walk = [&](auto blk_tag) {
+                constexpr int B = decltype(blk_tag)::value;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                int left = (int)((counts >> (8 * c)) & 0xFFu);
-                int off = 0;
+                for (int c = 0; c < 4; ++c) {
+                    int left = (int)((counts >> (8 * c)) & 0xFFu);
+                    int off = 0;
 #pragma unroll
-                for (int wi = 0; wi < SCG_SEED_STEPS / 4; ++wi) {
-                    if (left <= 0) break;
-                    const uint32_t word = S.seed[s].walk[c].w[wi];
+                    for (int wi = 0; wi < SCG_SEED_STEPS / 4; ++wi) {
+                        if (left <= 0) break;
+                        const uint32_t word = S.seed[s].walk[c].w[wi];
 #pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        if (left <= 2 * h) break;
-                        const int o1 = off + (int)((word >> (16 * h)) & 31u);
-                        const int o2 = o1 + (int)((word >> (16 * h + 8)) & 31u);
-                        off = o2;
+                        for (int h = 0; h < 2; ++h) {
+                            if (left <= 2 * h) break;
+                            const int o1 = off + (int)((word >> (16 * h)) & 31u);
+                            const int o2 = o1 + (int)((word >> (16 * h + 8)) & 31u);
+                            off = o2;
 #pragma unroll
-                        for (int i = 0; i < NC; ++i) {
-                            const uint32_t a = __builtin_amdgcn_alignbit(E.e[c][i + 1], E.e[c][i], o1);
-                            const uint32_t b = __builtin_amdgcn_alignbit(E.e[c][i + 1], E.e[c][i], o2);
-                            g[i] &= a & b;
+                            for (int i = 0; i < NC; ++i) {
+                                const uint32_t a = __builtin_amdgcn_alignbit(E.e[c][i + B + 1], E.e[c][i + B], o1);
+                                const uint32_t b = __builtin_amdgcn_alignbit(E.e[c][i + B + 1], E.e[c][i + B], o2);
+                                g[i] &= a & b;
+                            }
                         }
+                        left -= 4;
                     }
-                    left -= 4;
                 }
-            }
+            };
+            if (uniform(S.seed[s].blk)) walk(std::integral_constant<int, 1>()); else walk(std::integral_constant<int, 0>());
 #pragma unroll
             for (int i = 0; i < NC; ++i) cand[i] |= g[i];
             continue;
         }
+        const int blk = uniform(S.seed[s].blk);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             int left = (int)((counts >> (8 * c)) & 0xFFu);
             if (left == 0) continue;
+            // running copy of plane c, moved down by the seed's block (whole words), then by the walk's steps
             uint32_t cur[NS];
+#pragma unroll
+            for (int i = 0; i < NS; ++i) cur[i] = E.e[c][i];
+            for (int b = 0; b < blk; ++b) {
+#pragma unroll
+                for (int i = 0; i + 1 < NS; ++i) cur[i] = cur[i + 1];
+                cur[NS - 1] = 0;
+            }
 #pragma unroll
             for (int wi = 0; wi < SCG_SEED_STEPS / 4; ++wi) {
                 if (left <= 0) break;
@@ -287,16 +302,7 @@ __device__ __forceinline__ void seed_candidates(const BasePlanes<NW>& E, const S
                     const int sh = (int)(word & 31u);
                     const uint32_t keep = (word & 0x80u) ? 0xFFFFFFFFu : 0u;   // pure shift: AND is a no-op
                     word >>= 8;
-                    if (wi == 0 && k == 0) {
-                        // first step reads the plane itself
-#pragma unroll
-                        for (int i = 0; i < NS; ++i) {
-                            cur[i] = (i + 1 < NW) ? __builtin_amdgcn_alignbit(E.e[c][i + 1 < NW ? i + 1 : i], E.e[c][i], sh)
-                                                  : (E.e[c][i] >> sh);
-                        }
-                    } else {
-                        shift_right_small<NS>(cur, sh);
-                    }
+                    shift_right_small<NS>(cur, sh);
 #pragma unroll
                     for (int i = 0; i < NC; ++i) g[i] &= (cur[i] | keep);
                 }
