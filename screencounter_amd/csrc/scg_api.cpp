@@ -1014,6 +1014,108 @@ void count_text_stream(const std::vector<scg_plan*>& plans, scg::TextSource& src
     tr.mark("  windows");
 }
 
+// -------------------------------------------------------------------------------------------------
+// Device-scan pipeline, paired-end: both files are shipped as raw text and scanned on the GPU like single-end input;
+// the two streams of sequences are brought into step there.  Windows of the two files hold different numbers of
+// records, so each mate has a queue in HBM to which its scanned sequences are appended; whenever both queues hold
+// reads, the common prefix is counted as pairs and the remainder of the longer queue moves to its front.
+// Replaces kaori::process_paired_end_data (process_data.hpp:224-340).  One device: pair i needs read i of both files.
+// -------------------------------------------------------------------------------------------------
+struct MateQueue {
+    DevBuf seqs, offs, tmp_seqs, tmp_offs;
+    uint32_t n = 0;           // reads queued
+    uint32_t bytes = 0;       // their sequence bytes
+    uint32_t max_len = 0;
+    size_t cap_bytes = 0, cap_reads = 0;
+    void init(size_t window) {
+        cap_bytes = 2 * (window / 2 + 64) + 64;
+        cap_reads = 2 * (window / 64 + 256) + 2;
+        seqs.alloc(cap_bytes + 64); offs.alloc((cap_reads + 1) * sizeof(uint32_t));
+        tmp_seqs.alloc(cap_bytes + 64); tmp_offs.alloc((cap_reads + 1) * sizeof(uint32_t));
+        HIP_CHECK(hipMemset(offs.p, 0, sizeof(uint32_t)));
+    }
+};
+
+void count_paired_text(scg_plan* P, scg::TextSource& src1, scg::TextSource& src2) {
+    DeviceGuard g(P->device);
+    scg::TextSource* src[2] = {&src1, &src2};
+    const size_t window = std::max(scan_window_bytes(src1.size_hint()), scan_window_bytes(src2.size_hint()));
+    std::unique_ptr<ScanSlot> slot[2][2];
+    for (int m = 0; m < 2; ++m) for (int k = 0; k < 2; ++k) slot[m][k] = slot_pool().take(P, window);
+    struct Return {
+        std::unique_ptr<ScanSlot> (&s)[2][2];
+        bool ok = false;
+        ~Return() { if (ok) for (auto& row : s) for (auto& x : row) if (x) slot_pool().give(std::move(x)); }
+    } ret{slot};
+    MateQueue q[2];
+    q[0].init(window); q[1].init(window);
+    hipStream_t compute = nullptr;
+    HIP_CHECK(hipStreamCreateWithFlags(&compute, hipStreamNonBlocking));
+    struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); } } sg{compute};
+    bool done[2] = {false, false};
+    for (size_t round = 0; !(done[0] && done[1]); ++round) {
+        // advance the mate(s) that are not ahead
+        bool fresh[2] = {false, false};
+        for (int m = 0; m < 2; ++m) {
+            if (done[m] || (q[m].n > q[1 - m].n && !done[1 - m])) continue;
+            ScanSlot& s = *slot[m][round & 1];
+            if (s.busy) { HIP_CHECK(hipStreamSynchronize(compute)); s.busy = false; }     // its sequences have been appended
+            const size_t bytes = src[m]->next(s.text.as<char>(), s.cap);
+            if (src[m]->unusual()) throw UnusualInput();
+            if (bytes == 0) { done[m] = true; continue; }
+            HIP_CHECK(hipMemcpyAsync(s.d_text.p, s.text.p, bytes, hipMemcpyHostToDevice, s.stream));
+            HIP_CHECK(scg::launch_text_scan(s.d_text.as<char>(), bytes, s.B, s.stream));
+            HIP_CHECK(hipMemcpyAsync(s.h_result.p, s.d_result.p, sizeof(scg::TextScanResult), hipMemcpyDeviceToHost, s.stream));
+            fresh[m] = true;
+        }
+        for (int m = 0; m < 2; ++m) {
+            if (!fresh[m]) continue;
+            ScanSlot& s = *slot[m][round & 1];
+            HIP_CHECK(hipStreamSynchronize(s.stream));
+            const scg::TextScanResult r = *s.h_result.as<scg::TextScanResult>();
+            if (r.flags) throw UnusualInput();
+            if (q[m].bytes + r.seq_bytes > q[m].cap_bytes || q[m].n + r.n_records > q[m].cap_reads) throw UnusualInput();   // very lopsided files: host readers
+            // append to the mate's queue (the queue's offsets carry on from its current end)
+            if (r.seq_bytes) HIP_CHECK(hipMemcpyAsync(q[m].seqs.as<char>() + q[m].bytes, s.B.seqs, r.seq_bytes, hipMemcpyDeviceToDevice, compute));
+            HIP_CHECK(scg::launch_rebase_offsets(q[m].offs.as<uint32_t>() + q[m].n, s.B.offsets, r.n_records + 1, q[m].bytes, 0, compute));
+            q[m].n += r.n_records;
+            q[m].bytes += static_cast<uint32_t>(r.seq_bytes);
+            q[m].max_len = std::max(q[m].max_len, r.max_len);
+            s.busy = true;
+        }
+        for (int m = 0; m < 2; ++m) {
+            // one file is exhausted and fully paired while the other still holds reads (process_data.hpp:284-285)
+            if (done[1 - m] && q[1 - m].n == 0 && q[m].n > 0) throw Error(SCG_ERR_IO, "different number of reads in paired FASTQ files");
+        }
+        const uint32_t np = std::min(q[0].n, q[1].n);
+        if (np) {
+            const int32_t max_len = static_cast<int32_t>(std::min<uint32_t>(std::max(q[0].max_len, q[1].max_len), 1u << 30));
+            launch_batch_paired(P, make_reads(q[0].seqs.as<char>(), q[0].offs.as<uint32_t>(), 0, max_len),
+                                make_reads(q[1].seqs.as<char>(), q[1].offs.as<uint32_t>(), 0, max_len), static_cast<int64_t>(np), compute);
+            for (int m = 0; m < 2; ++m) {
+                const uint32_t rest = q[m].n - np;
+                if (rest == 0) { q[m].n = 0; q[m].bytes = 0; continue; }
+                // the reads beyond the counted prefix move to the front (through a scratch copy: the ranges may overlap);
+                // the byte offset of read np is known on the device only, so the offsets are re-based there
+                HIP_CHECK(hipStreamSynchronize(compute));
+                uint32_t first = 0;
+                HIP_CHECK(hipMemcpy(&first, q[m].offs.as<uint32_t>() + np, sizeof(first), hipMemcpyDeviceToHost));
+                const uint32_t tail = q[m].bytes - first;
+                if (tail) HIP_CHECK(hipMemcpyAsync(q[m].tmp_seqs.p, q[m].seqs.as<char>() + first, tail, hipMemcpyDeviceToDevice, compute));
+                HIP_CHECK(scg::launch_rebase_offsets(q[m].tmp_offs.as<uint32_t>(), q[m].offs.as<uint32_t>() + np, rest + 1, 0, first, compute));
+                if (tail) HIP_CHECK(hipMemcpyAsync(q[m].seqs.p, q[m].tmp_seqs.p, tail, hipMemcpyDeviceToDevice, compute));
+                HIP_CHECK(hipMemcpyAsync(q[m].offs.p, q[m].tmp_offs.p, (rest + 1) * sizeof(uint32_t), hipMemcpyDeviceToDevice, compute));
+                q[m].n = rest;
+                q[m].bytes = tail;
+            }
+        }
+    }
+    HIP_CHECK(hipStreamSynchronize(compute));
+    for (auto& row : slot) for (auto& x : row) { HIP_CHECK(hipStreamSynchronize(x->stream)); x->busy = false; x->pending = false; }
+    ret.ok = true;
+    if (q[0].n != q[1].n) throw Error(SCG_ERR_IO, "different number of reads in paired FASTQ files");   // process_data.hpp:284-285
+}
+
 void reset_plan(scg_plan* P) {
     DeviceGuard g(P->device);
     if (P->n_counters) HIP_CHECK(hipMemset(P->counters, 0, static_cast<size_t>(P->n_counters) * sizeof(int32_t)));
@@ -1288,6 +1390,19 @@ void append_reads(scg::ReadBatch& dst, const scg::ReadBatch& src, int64_t from, 
 // equal read counts (pair i = read i of both files).  gzip input or anything unusual falls back to
 // the sequential readers in lock-step.  Unequal read counts => the reference's error.
 void count_paired_files(scg_plan* P, const char* path1, const char* path2, scg::FastqStream& fq1, scg::FastqStream& fq2, int nthreads) {
+    if (device_scan_enabled()) {
+        // ordinary files: raw text to the GPU, records found and paired there; anything else: the host readers below
+        bool done = false;
+        try {
+            const int threads = scg::default_host_threads(nthreads);
+            std::unique_ptr<scg::TextSource> s1 = scg::TextSource::open(path1, threads), s2 = scg::TextSource::open(path2, threads);
+            count_paired_text(P, *s1, *s2);
+            done = true;
+        } catch (const UnusualInput&) {
+            reset_plan(P);
+        }
+        if (done) return;
+    }
     Stager st;
     auto launch_pair = [&](const scg::ReadBatch& x, const scg::ReadBatch& y) {
         auto& s = st.acquire();

@@ -40,6 +40,10 @@ size_t text_scan_padded(size_t n_bytes);    // device text buffers must be reada
 // a newline (the host appends one when the file lacks it, as the reference accepts a final record without it).
 hipError_t launch_text_scan(const char* d_text, size_t n_bytes, const TextScanBuffers& B, hipStream_t stream);
 
+// dst[i] = src[i] + add - sub, i < n: byte offsets re-based when sequences are appended to / shifted within a buffer
+// (dst and src must not overlap).
+hipError_t launch_rebase_offsets(uint32_t* dst, const uint32_t* src, uint32_t n, uint32_t add, uint32_t sub, hipStream_t stream);
+
 } // namespace scg
 
 #endif

@@ -171,9 +171,21 @@ __global__ __launch_bounds__(TS_BLOCK) void compact_kernel(const char* __restric
     if (blockIdx.x == 0 && threadIdx.x == 0) res->seq_bytes = offsets[n_rec];
 }
 
+// dst[i] = src[i] + add - sub for i < n (re-basing byte offsets when sequences move between buffers).
+__global__ __launch_bounds__(TS_BLOCK) void rebase_kernel(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src, uint32_t n, uint32_t add, uint32_t sub) {
+    const uint32_t i = blockIdx.x * TS_BLOCK + threadIdx.x;
+    if (i < n) dst[i] = src[i] + add - sub;
+}
+
 } // namespace
 
 namespace scg {
+
+hipError_t launch_rebase_offsets(uint32_t* dst, const uint32_t* src, uint32_t n, uint32_t add, uint32_t sub, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(rebase_kernel, dim3((n + TS_BLOCK - 1) / TS_BLOCK), dim3(TS_BLOCK), 0, stream, dst, src, n, add, sub);
+    return hipGetLastError();
+}
 
 size_t text_scan_blocks(size_t n_bytes) { return (n_bytes + TS_TILE - 1) / TS_TILE; }
 size_t text_scan_padded(size_t n_bytes) { return text_scan_blocks(n_bytes) * TS_TILE; }

@@ -180,3 +180,59 @@ def test_multi_file_entries_equal_per_file_calls(sc, oracle, gpu, tmp_path, monk
     for c, f in enumerate(pairs1):
         cc, tt = sc.count_dual_barcodes(f, TEMPLATE, False, 1, pool, f, TEMPLATE, False, 1, pool, False, True, False, 2)
         assert tot[c] == tt and np.array_equal(mat[:, c], cc)
+
+
+def test_paired_files_through_the_scan(sc, oracle, gpu, tmp_path, monkeypatch):
+    """Both mates shipped as raw text; their windows hold different numbers of records (names and read lengths differ), so
+    the device-side queues that bring the two streams into step are exercised; one mate is BGZF, the other plain."""
+    from screencounter_amd import _lib
+    rng = random.Random(16)
+    t1, t2 = "ACGTAC" + "-" * 10 + "TGCATG", "GGATCC" + "-" * 8 + "AAGCTT"
+    u1, u2 = gen.make_pool(rng, 12, 10, "ACGT", min_dist=3), gen.make_pool(rng, 10, 8, "ACGT", min_dist=3)
+    pairs = [(a, b) for a in u1 for b in u2]
+    rng.shuffle(pairs)
+    pairs = pairs[:60]
+    pool1, pool2 = [a for a, _ in pairs], [b for _, b in pairs]
+    r1, r2 = [], []
+    for i in range(9000):
+        a, b = rng.choice(pairs) if rng.random() < 0.85 else (rng.choice(u1), rng.choice(u2))
+        x = gen.mutate(rng, gen.fill_template(t1, [a]), 0.02, 0.01, 0.02)
+        y = gen.mutate(rng, gen.fill_template(t2, [b]), 0.02, 0.01, 0.02)
+        r1.append(gen.rand_seq(rng, rng.randint(0, 60)) + x + gen.rand_seq(rng, rng.randint(0, 10)))     # mate 1 records are longer
+        r2.append(gen.rand_seq(rng, rng.randint(0, 5)) + y)
+    exp, total = oracle.count_dual(r1, r2, t1, False, 1, pool1, t2, False, 1, pool2, False, True)
+    p1 = str(tmp_path / "m1.fastq")
+    open(p1, "wb").write(gen.fastq_text(r1, name_prefix="a_rather_long_read_name_"))
+    p2 = str(tmp_path / "m2.fastq.gz")
+    gen.write_bgzf(p2, gen.fastq_text(r2, trailing_newline=False), block=2500)
+    for kb in (None, 16, 64):
+        if kb:
+            monkeypatch.setenv("SCG_WINDOW_KB", str(kb))
+        for first in (True, False):
+            e, t = (exp, total) if first else oracle.count_dual(r1, r2, t1, False, 1, pool1, t2, False, 1, pool2, False, False)
+            got, n = sc.count_dual_barcodes(p1, t1, False, 1, pool1, p2, t2, False, 1, pool2, False, first, False, 4)
+            assert n == t == len(r1) and np.array_equal(got, e), (kb, first)
+    # include.invalid = TRUE and randomized through the same pipeline
+    d = oracle.count_dual_diag(r1, r2, t1, False, 1, pool1, t2, False, 1, pool2, True, True)
+    counts, (idx, freq), tot, b1, b2 = sc.count_dual_barcodes(p1, t1, False, 1, pool1, p2, t2, False, 1, pool2, True, True, True, 4)
+    assert tot == d["total"] and np.array_equal(counts, d["counts"]) and np.array_equal(idx, d["indices"]) and np.array_equal(freq, d["freq"])
+    assert (b1, b2) == (d["barcode1_only"], d["barcode2_only"])
+    # host-parser path agrees
+    monkeypatch.setenv("SCG_DEVICE_SCAN", "0")
+    got, n = sc.count_dual_barcodes(p1, t1, False, 1, pool1, p2, t2, False, 1, pool2, False, True, False, 4)
+    assert n == total and np.array_equal(got, exp)
+    monkeypatch.delenv("SCG_DEVICE_SCAN")
+    # unequal numbers of reads: the reference's error
+    p3 = str(tmp_path / "short.fastq")
+    open(p3, "wb").write(gen.fastq_text(r2[:-7]))
+    for a, b in ((p1, p3), (p3, p1)):
+        with pytest.raises(_lib.ScgError) as e:
+            sc.count_dual_barcodes(a, t1, False, 1, pool1, b, t2, False, 1, pool2, False, True, False, 4)
+        assert e.value.code == _lib.SCG_ERR_IO and "different number of reads in paired FASTQ files" in str(e.value)
+    # one mate with multi-line records: both files go through the host readers
+    multi = b"".join(b"@r%d\n" % i + r[:len(r) // 2].encode() + b"\n" + r[len(r) // 2:].encode() + b"\n+\n" +
+                     b"I" * (len(r) // 2) + b"\n" + b"I" * (len(r) - len(r) // 2) + b"\n" for i, r in enumerate(r2))
+    p4 = str(tmp_path / "multi2.fastq")
+    open(p4, "wb").write(multi)
+    got, n = sc.count_dual_barcodes(p1, t1, False, 1, pool1, p4, t2, False, 1, pool2, False, True, False, 4)
+    assert n == total and np.array_equal(got, exp)
