@@ -307,6 +307,17 @@ def main() -> None:
             rnd.append(run_case(ref, c, tmp))
         for i in range(30):     # templates with 3 to 5 variable regions (DualBarcodesSingleEnd.hpp:144-163 takes any number)
             rnd.append(run_case(ref, gen.random_dual_single_end_case(rng, sizes=small, nreg=3 + i % 3), tmp))
+        for i in range(60):     # barcodes of 33..64 bases on the combinatorial and paired-end paths (wide keys)
+            if i % 4 == 0:
+                c = gen.random_combo_case(rng, sizes=small, wide=True)
+            elif i % 4 == 1:
+                c = gen.random_dual_case(rng, hazard_free=True, sizes=small, max_mm=3, wide=True)
+            elif i % 4 == 2:
+                c = gen.random_dual_case(rng, hazard_free=True, sizes=small, max_mm=2, wide=True)
+                c["kind"] = "dual_diag"
+            else:
+                c = gen.random_paired_combo_case(rng, sizes=small, max_mm=2, wide=True)
+            rnd.append(run_case(ref, c, tmp))
         with open(os.path.join(OUT, "kaori_random.json"), "w") as f:
             json.dump({"generator": "oracle/gen_golden.py", "reference": "kaori v1.1.1 (screenCounter 1.5.1)", "seed": 20261003, "cases": rnd}, f)
 

@@ -396,8 +396,10 @@ std::unique_ptr<scg_plan> compile_combo(const char* constant, int strand,
         }
     }
     if (mismatches < 0) throw Error(SCG_ERR_INVALID, "negative number of mismatches");
-    P->htab[0] = scg::build_index(pool0, n0, len0, mismatches);
-    P->htab[1] = scg::build_index(pool1, n1, len1, mismatches);
+    // pools of 33..64 bases take the wide (2 x 64-bit plane) index and kernels; both pools then, one key width per kernel
+    const bool wide = len0 > SCG_MAX_BARCODE || len1 > SCG_MAX_BARCODE;
+    P->htab[0] = wide ? scg::build_index_wide(pool0, n0, len0, mismatches) : scg::build_index(pool0, n0, len0, mismatches);
+    P->htab[1] = wide ? scg::build_index_wide(pool1, n1, len1, mismatches) : scg::build_index(pool1, n1, len1, mismatches);
     P->scan1 = scg::build_scan(P->ht1.t, mismatches);
     P->n_pool[0] = n0; P->n_pool[1] = n1;
     int64_t cells = static_cast<int64_t>(n0) * static_cast<int64_t>(n1);
@@ -433,8 +435,15 @@ std::unique_ptr<scg_plan> compile_dual(const char* constant1, int reverse1, int 
     if (mismatches1 < 0 || mismatches2 < 0) throw Error(SCG_ERR_INVALID, "negative number of mismatches");
     std::vector<std::vector<int32_t> > exp1, exp2;
     std::vector<uint64_t> uk1, uk2;
-    P->htab[0] = scg::build_uid_index(pool1, n_pool, len1, mismatches1, exp1, uk1);
-    P->htab[1] = scg::build_uid_index(pool2, n_pool, len2, mismatches2, exp2, uk2);
+    size_t n_uid1 = 0, n_uid2 = 0;
+    if (len1 > SCG_MAX_BARCODE || len2 > SCG_MAX_BARCODE) {     // barcodes of 33..64 bases on either mate: wide indexes and kernels for both
+        P->htab[0] = scg::build_uid_index_wide(pool1, n_pool, len1, mismatches1, exp1, n_uid1);
+        P->htab[1] = scg::build_uid_index_wide(pool2, n_pool, len2, mismatches2, exp2, n_uid2);
+    } else {
+        P->htab[0] = scg::build_uid_index(pool1, n_pool, len1, mismatches1, exp1, uk1);
+        P->htab[1] = scg::build_uid_index(pool2, n_pool, len2, mismatches2, exp2, uk2);
+        n_uid1 = uk1.size(); n_uid2 = uk2.size();
+    }
     P->scan1 = scg::build_scan(P->ht1.t, mismatches1);
     P->scan2 = scg::build_scan(P->ht2.t, mismatches2);
     P->hpairs = scg::build_pair_table(exp1, uk1, exp2, uk2);   // :138-178 (duplicate pairs => error)
@@ -449,9 +458,9 @@ std::unique_ptr<scg_plan> compile_dual(const char* constant1, int reverse1, int 
             }
             return f;
         };
-        P->first1 = firsts(exp1, uk1.size());
-        P->first2 = firsts(exp2, uk2.size());
-        int64_t cells = static_cast<int64_t>(uk1.size()) * static_cast<int64_t>(uk2.size());
+        P->first1 = firsts(exp1, n_uid1);
+        P->first2 = firsts(exp2, n_uid2);
+        int64_t cells = static_cast<int64_t>(n_uid1) * static_cast<int64_t>(n_uid2);
         if (cells > (int64_t(1) << 28)) {
             throw Error(SCG_ERR_UNSUPPORTED, "include.invalid=TRUE needs n_unique1 x n_unique2 <= 2^28 cells in this engine");
         }
@@ -477,8 +486,15 @@ std::unique_ptr<scg_plan> compile_dual_single_end_diag(const char* constant, int
     P->htab_combined = std::move(P->htab[0]);
     std::vector<std::vector<int32_t> > exp0, exp1;
     std::vector<uint64_t> uk0, uk1;
-    P->htab[0] = scg::build_uid_index(pools[0], n_pools[0], t.flen[0], mismatches, exp0, uk0);   // each region <= 32 bases here
-    P->htab[1] = scg::build_uid_index(pools[1], n_pools[1], t.flen[1], mismatches, exp1, uk1);
+    size_t n_uid0 = 0, n_uid1 = 0;
+    if (t.flen[0] > SCG_MAX_BARCODE || t.flen[1] > SCG_MAX_BARCODE) {
+        P->htab[0] = scg::build_uid_index_wide(pools[0], n_pools[0], t.flen[0], mismatches, exp0, n_uid0);
+        P->htab[1] = scg::build_uid_index_wide(pools[1], n_pools[1], t.flen[1], mismatches, exp1, n_uid1);
+    } else {
+        P->htab[0] = scg::build_uid_index(pools[0], n_pools[0], t.flen[0], mismatches, exp0, uk0);
+        P->htab[1] = scg::build_uid_index(pools[1], n_pools[1], t.flen[1], mismatches, exp1, uk1);
+        n_uid0 = uk0.size(); n_uid1 = uk1.size();
+    }
     auto firsts = [&](const std::vector<std::vector<int32_t> >& exp, size_t n_uid) {
         std::vector<int32_t> f(n_uid, -1);
         for (size_t i = 0; i < exp.size(); ++i) {
@@ -486,9 +502,9 @@ std::unique_ptr<scg_plan> compile_dual_single_end_diag(const char* constant, int
         }
         return f;
     };
-    P->first1 = firsts(exp0, uk0.size());
-    P->first2 = firsts(exp1, uk1.size());
-    int64_t cells = static_cast<int64_t>(uk0.size()) * static_cast<int64_t>(uk1.size());
+    P->first1 = firsts(exp0, n_uid0);
+    P->first2 = firsts(exp1, n_uid1);
+    int64_t cells = static_cast<int64_t>(n_uid0) * static_cast<int64_t>(n_uid1);
     if (cells > (int64_t(1) << 28)) {
         throw Error(SCG_ERR_UNSUPPORTED, "include.invalid=TRUE needs n_unique1 x n_unique2 <= 2^28 cells in this engine");
     }
@@ -518,8 +534,9 @@ std::unique_ptr<scg_plan> compile_paired_combo(const char* constant1, int revers
     check(P->ht1, len1);
     check(P->ht2, len2);
     if (mismatches1 < 0 || mismatches2 < 0) throw Error(SCG_ERR_INVALID, "negative number of mismatches");
-    P->htab[0] = scg::build_index(pool1, n1, len1, mismatches1);     // values = pool indices; duplicates => error
-    P->htab[1] = scg::build_index(pool2, n2, len2, mismatches2);
+    const bool wide = len1 > SCG_MAX_BARCODE || len2 > SCG_MAX_BARCODE;
+    P->htab[0] = wide ? scg::build_index_wide(pool1, n1, len1, mismatches1) : scg::build_index(pool1, n1, len1, mismatches1);     // values = pool indices; duplicates => error
+    P->htab[1] = wide ? scg::build_index_wide(pool2, n2, len2, mismatches2) : scg::build_index(pool2, n2, len2, mismatches2);
     P->scan1 = scg::build_scan(P->ht1.t, mismatches1);
     P->scan2 = scg::build_scan(P->ht2.t, mismatches2);
     int64_t cells = static_cast<int64_t>(n1) * static_cast<int64_t>(n2);

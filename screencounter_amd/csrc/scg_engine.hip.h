@@ -282,11 +282,11 @@ __device__ __forceinline__ int pair_probe(const ScgPairTable& t, int u1, int u2)
 }
 
 // Up to K distinct neighbours (value, distance) of a query within cap; returns false on overflow.
-template<int K>
-__device__ __forceinline__ bool index_neighbours(const ScgIndex& X, const Query& q, int cap, int val[K], int dist[K], int& n) {
+template<int K, class W>
+__device__ __forceinline__ bool index_neighbours(const ScgIndex& X, const QueryT<W>& q, int cap, int val[K], int dist[K], int& n) {
     n = 0;
     bool overflow = false;
-    index_search<uint32_t>(X, q, cap, [&](int v, int d) -> bool {
+    index_search<W>(X, q, cap, [&](int v, int d) -> bool {
         bool seen = false;
 #pragma unroll
         for (int i = 0; i < K; ++i) seen |= (i < n && val[i] == v);
@@ -305,8 +305,9 @@ __device__ __forceinline__ bool index_neighbours(const ScgIndex& X, const Query&
 
 // pair_match((q1,q2),(cap1,cap2)): among valid pairs whose two halves are within their own caps,
 // the unique one with the smallest total distance.
+template<class W>
 __device__ __forceinline__ void pair_match(const ScgIndex& X1, const ScgIndex& X2, const ScgPairTable& P,
-                                           const Query& q1, int cap1, const Query& q2, int cap2,
+                                           const QueryT<W>& q1, int cap1, const QueryT<W>& q2, int cap2,
                                            int& index, int& total) {
     index = SCG_MISSING; total = 0;
     if (q1.n_other > cap1 || q2.n_other > cap2) return;
@@ -320,15 +321,16 @@ __device__ __forceinline__ void pair_match(const ScgIndex& X1, const ScgIndex& X
             else if (cur != v) { cur = SCG_AMBIGUOUS; }
         }
     };
-    if (X1.nseg != 0 && X2.nseg != 0) {
+    // (wide keys have no dense pair list: their budgets beyond the tables fall through to index_search's dense scans)
+    if (sizeof(W) == 8 || (X1.nseg != 0 && X2.nseg != 0)) {
         // The neighbourhoods of the two halves are gathered once each (they hold one or two
         // sequences in practice) and crossed; only a pathological library overflows the small
         // arrays, in which case the halves are searched nested.
         constexpr int K = 4;
         int v1[K], d1[K], n1, v2[K], d2[K], n2;
-        const bool ok1 = index_neighbours<K>(X1, q1, cap1, v1, d1, n1);
+        const bool ok1 = index_neighbours<K, W>(X1, q1, cap1, v1, d1, n1);
         if (ok1 && n1 == 0) return;
-        const bool ok2 = index_neighbours<K>(X2, q2, cap2, v2, d2, n2);
+        const bool ok2 = index_neighbours<K, W>(X2, q2, cap2, v2, d2, n2);
         if (ok2 && n2 == 0) return;
         if (ok1 && ok2) {
 #pragma unroll
@@ -339,15 +341,15 @@ __device__ __forceinline__ void pair_match(const ScgIndex& X1, const ScgIndex& X
                 }
             }
         } else {
-            index_search<uint32_t>(X1, q1, cap1, [&](int u1, int e1) -> bool {
-                index_search<uint32_t>(X2, q2, cap2, [&](int u2, int e2) -> bool {
+            index_search<W>(X1, q1, cap1, [&](int u1, int e1) -> bool {
+                index_search<W>(X2, q2, cap2, [&](int u2, int e2) -> bool {
                     consider(u1, e1, u2, e2);
                     return false;
                 });
                 return false;
             });
         }
-    } else {
+    } else if constexpr (sizeof(W) == 4) {
         uint32_t lm1 = low_mask(X1.len), lm2 = low_mask(X2.len);
         for (int i = 0; i < P.n_entries; ++i) {
             uint64_t k1 = P.list_key1[i];

@@ -61,6 +61,10 @@ HostIndex build_uid_index(const char* const* pool, int32_t n, int32_t len, int m
                           std::vector<std::vector<int32_t> >& expansions,
                           std::vector<uint64_t>& uid_keys);
 
+// The same with wide keys (either pool of a pair longer than 32 bases); n_uid receives the number of distinct sequences.
+HostIndex build_uid_index_wide(const char* const* pool, int32_t n, int32_t len, int max_mm,
+                               std::vector<std::vector<int32_t> >& expansions, size_t& n_uid);
+
 struct HostPairTable {
     int32_t n_entries = 0;
     uint32_t mask = 0;

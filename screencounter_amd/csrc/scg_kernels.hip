@@ -138,6 +138,7 @@ __global__ __launch_bounds__(BLOCK) void random_kernel(ScgSingleParams P, ScgRea
 // ---------------------------------------------------------------------------------------------
 // combo (two variable regions in one template)
 // ---------------------------------------------------------------------------------------------
+template<class W>
 __device__ __forceinline__ bool combo_candidate(const ScgComboParams& P, const Read& rd, int p, bool reverse, int c,
                                                 int out[SCG_COMBO_REGIONS], int& total) {
     const ScgTemplate* T = P.tmpl;
@@ -147,9 +148,9 @@ __device__ __forceinline__ bool combo_candidate(const ScgComboParams& P, const R
         int slot = reverse ? (SCG_COMBO_REGIONS - 1 - r) : r;
         int start = reverse ? T->rstart[r] : T->fstart[r];
         const ScgIndex& tab = P.index[slot];
-        Query q = pack_region(rd.p + p + start, tab.len, reverse);
+        QueryT<W> q = pack_region<W>(rd.p + p + start, tab.len, reverse);
         int idx, d;
-        index_match(tab, q, P.max_mm - obs, idx, d, P.keep_first != 0);   // :168
+        index_match<W>(tab, q, P.max_mm - obs, idx, d, P.keep_first != 0);   // :168
         if (idx < 0) return false;
         obs += d;
         if (obs > P.max_mm) return false;               // :173-176
@@ -160,6 +161,7 @@ __device__ __forceinline__ bool combo_candidate(const ScgComboParams& P, const R
 }
 
 // Returns 1 and fills best_id when the read yields a combination.
+template<class W>
 __device__ __forceinline__ int combo_read(const ScgComboParams& P, const Read& rd, int best_id[SCG_COMBO_REGIONS]) {
     const ScgTemplate* T = P.tmpl;
     const int len = T->len;
@@ -170,7 +172,7 @@ __device__ __forceinline__ int combo_read(const ScgComboParams& P, const Read& r
             int c = const_mismatches(T, s != 0, rd.p, p, P.max_mm);
             if (c > P.max_mm) continue;
             int cand[SCG_COMBO_REGIONS], tot;
-            if (!combo_candidate(P, rd, p, s != 0, c, cand, tot)) continue;
+            if (!combo_candidate<W>(P, rd, p, s != 0, c, cand, tot)) continue;
             if (P.use_first) {                          // :197-217
                 found = 1; best_id[0] = cand[0]; best_id[1] = cand[1];
                 break;
@@ -186,6 +188,7 @@ __device__ __forceinline__ int combo_read(const ScgComboParams& P, const Read& r
     return found;
 }
 
+template<class W>
 __global__ __launch_bounds__(BLOCK) void combo_kernel(ScgComboParams P, ScgReads R, int64_t n_reads,
                                                        ScgCounters cells) {
     int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -193,7 +196,7 @@ __global__ __launch_bounds__(BLOCK) void combo_kernel(ScgComboParams P, ScgReads
     if (P.only_if_negative && P.only_if_negative[i] >= 0) return;      // second pass of the single-end dual diagnostics
     Read rd = get_read(R, i);
     int best_id[SCG_COMBO_REGIONS] = {0, 0};
-    if (combo_read(P, rd, best_id)) count_one(cells, (int64_t)best_id[0] * P.n_pool[1] + best_id[1]);
+    if (combo_read<W>(P, rd, best_id)) count_one(cells, (int64_t)best_id[0] * P.n_pool[1] + best_id[1]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -201,6 +204,7 @@ __global__ __launch_bounds__(BLOCK) void combo_kernel(ScgComboParams P, ScgReads
 // ---------------------------------------------------------------------------------------------
 // One orientation: template 1 on read a, template 2 on read b.
 // use_first: index of the first valid (hit1, hit2) combination or -1.
+template<class W>
 __device__ __forceinline__ int dual_first(const ScgDualParams& P, const Read& a, const Read& b) {
     const ScgTemplate* T1 = P.tmpl1;
     const ScgTemplate* T2 = P.tmpl2;
@@ -209,13 +213,13 @@ __device__ __forceinline__ int dual_first(const ScgDualParams& P, const Read& a,
     for (int p1 = 0; p1 + T1->len <= a.n; ++p1) {
         int c1 = const_mismatches(T1, P.rev1 != 0, a.p, p1, P.max_mm1);
         if (c1 > P.max_mm1) continue;
-        Query q1 = pack_region(a.p + p1 + s1, P.index1.len, P.rev1 != 0);
+        QueryT<W> q1 = pack_region<W>(a.p + p1 + s1, P.index1.len, P.rev1 != 0);
         for (int p2 = 0; p2 + T2->len <= b.n; ++p2) {
             int c2 = const_mismatches(T2, P.rev2 != 0, b.p, p2, P.max_mm2);
             if (c2 > P.max_mm2) continue;
-            Query q2 = pack_region(b.p + p2 + s2, P.index2.len, P.rev2 != 0);
+            QueryT<W> q2 = pack_region<W>(b.p + p2 + s2, P.index2.len, P.rev2 != 0);
             int idx, tot;
-            pair_match(P.index1, P.index2, P.pairs, q1, P.max_mm1 - c1, q2, P.max_mm2 - c2, idx, tot);
+            pair_match<W>(P.index1, P.index2, P.pairs, q1, P.max_mm1 - c1, q2, P.max_mm2 - c2, idx, tot);
             if (idx >= 0) return idx;                   // DualBarcodesPairedEnd.hpp:264-276
         }
     }
@@ -223,6 +227,7 @@ __device__ __forceinline__ int dual_first(const ScgDualParams& P, const Read& a,
 }
 
 // best: (chosen, best_mismatches) as DualBarcodesPairedEnd.hpp:310-347
+template<class W>
 __device__ __forceinline__ void dual_best(const ScgDualParams& P, const Read& a, const Read& b, int& chosen, int& best) {
     const ScgTemplate* T1 = P.tmpl1;
     const ScgTemplate* T2 = P.tmpl2;
@@ -233,13 +238,13 @@ __device__ __forceinline__ void dual_best(const ScgDualParams& P, const Read& a,
     for (int p1 = 0; p1 + T1->len <= a.n; ++p1) {
         int c1 = const_mismatches(T1, P.rev1 != 0, a.p, p1, P.max_mm1);
         if (c1 > P.max_mm1) continue;
-        Query q1 = pack_region(a.p + p1 + s1, P.index1.len, P.rev1 != 0);
+        QueryT<W> q1 = pack_region<W>(a.p + p1 + s1, P.index1.len, P.rev1 != 0);
         for (int p2 = 0; p2 + T2->len <= b.n; ++p2) {
             int c2 = const_mismatches(T2, P.rev2 != 0, b.p, p2, P.max_mm2);
             if (c2 > P.max_mm2) continue;
-            Query q2 = pack_region(b.p + p2 + s2, P.index2.len, P.rev2 != 0);
+            QueryT<W> q2 = pack_region<W>(b.p + p2 + s2, P.index2.len, P.rev2 != 0);
             int idx, tot;
-            pair_match(P.index1, P.index2, P.pairs, q1, P.max_mm1 - c1, q2, P.max_mm2 - c2, idx, tot);
+            pair_match<W>(P.index1, P.index2, P.pairs, q1, P.max_mm1 - c1, q2, P.max_mm2 - c2, idx, tot);
             if (idx >= 0) {                             // :333-341
                 int cur = tot + c1 + c2;
                 if (cur < best) { chosen = idx; best = cur; }
@@ -251,6 +256,7 @@ __device__ __forceinline__ void dual_best(const ScgDualParams& P, const Read& a,
 
 // SimpleSingleMatch::search_first / search_best of one mate on one strand (byte-wise), with the
 // FIRST duplicate policy of the diagnostics path.  Returns found; index = sequence uid.
+template<class W>
 __device__ __forceinline__ bool mate_search(const ScgTemplate* T, const ScgIndex& X, bool reverse, int max_mm, bool use_first,
                                             bool keep_first, const Read& rd, int& index, int& mism) {
     bool found = false;
@@ -260,9 +266,9 @@ __device__ __forceinline__ bool mate_search(const ScgTemplate* T, const ScgIndex
     for (int p = 0; p + T->len <= rd.n; ++p) {
         int c = const_mismatches(T, reverse, rd.p, p, max_mm);
         if (c > max_mm) continue;
-        Query q = pack_region(rd.p + p + start, X.len, reverse);
+        QueryT<W> q = pack_region<W>(rd.p + p + start, X.len, reverse);
         int idx, d;
-        index_match(X, q, max_mm - c, idx, d, keep_first);
+        index_match<W>(X, q, max_mm - c, idx, d, keep_first);
         if (idx < 0) continue;
         int tot = c + d;
         if (use_first) { index = idx; mism = tot; return true; }
@@ -333,17 +339,18 @@ __device__ __forceinline__ void diagnose_pair(const ScgDualParams& P, const M& m
     count_flagged(counters, 1, b2_only, what == 3);
 }
 
+template<class W>
 __device__ __forceinline__ int dual_pair(const ScgDualParams& P, const Read& a, const Read& b) {
     int idx;
     if (P.use_first) {                                  // :356-360
-        idx = dual_first(P, a, b);
-        if (idx < 0 && P.randomized) idx = dual_first(P, b, a);
+        idx = dual_first<W>(P, a, b);
+        if (idx < 0 && P.randomized) idx = dual_first<W>(P, b, a);
     } else {                                            // :362-376
         int best;
-        dual_best(P, a, b, idx, best);
+        dual_best<W>(P, a, b, idx, best);
         if (P.randomized) {
             int idx2, best2;
-            dual_best(P, b, a, idx2, best2);
+            dual_best<W>(P, b, a, idx2, best2);
             if (idx < 0 || best > best2) { idx = idx2; best = best2; }
             else if (best == best2 && idx != idx2) { idx = -1; }
         }
@@ -351,27 +358,29 @@ __device__ __forceinline__ int dual_pair(const ScgDualParams& P, const Read& a, 
     return idx;
 }
 
+template<class W>
 struct GeneralMates {
     Read a, b;
     __device__ __forceinline__ bool search1(const ScgDualParams& P, int which, int& index, int& mism) const {
-        return mate_search(P.tmpl1, P.index1, P.rev1 != 0, P.max_mm1, P.use_first != 0, P.keep_first != 0, which ? b : a, index, mism);
+        return mate_search<W>(P.tmpl1, P.index1, P.rev1 != 0, P.max_mm1, P.use_first != 0, P.keep_first != 0, which ? b : a, index, mism);
     }
     __device__ __forceinline__ bool search2(const ScgDualParams& P, int which, int& index, int& mism) const {
-        return mate_search(P.tmpl2, P.index2, P.rev2 != 0, P.max_mm2, P.use_first != 0, P.keep_first != 0, which ? b : a, index, mism);
+        return mate_search<W>(P.tmpl2, P.index2, P.rev2 != 0, P.max_mm2, P.use_first != 0, P.keep_first != 0, which ? b : a, index, mism);
     }
 };
 
+template<class W>
 __global__ __launch_bounds__(BLOCK) void dual_kernel(ScgDualParams P, ScgReads R1, ScgReads R2, int64_t n_pairs,
                                                       ScgCounters counts) {
     int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n_pairs) return;
     if (P.diagnostics == 2 && P.only_if_negative && P.only_if_negative[i] >= 0) return;   // second pass of include.invalid=TRUE
     Read a = get_read(R1, i), b = get_read(R2, i);
-    int idx = P.diagnostics == 2 ? -1 : dual_pair(P, a, b);
+    int idx = P.diagnostics == 2 ? -1 : dual_pair<W>(P, a, b);
     if (idx >= 0) {
         count_one(counts, idx);
     } else if (P.diagnostics) {
-        diagnose_pair(P, GeneralMates{a, b}, counts);
+        diagnose_pair(P, GeneralMates<W>{a, b}, counts);
     }
 }
 
@@ -501,7 +510,7 @@ __global__ __launch_bounds__(STAGE_BLOCK) __attribute__((amdgpu_num_sgpr(80))) v
 
 // SECOND: the masked DuplicateAction::FIRST pass of the single-end dual diagnostics -- a compile-time variant, so that
 // the ordinary combination kernel keeps its code (a run-time flag here cost it 9 %).
-template<int NW, int NT, bool SECOND>
+template<int NW, int NT, bool SECOND, class W>
 __device__ __forceinline__ bool combo_candidate_staged(const ScgComboParams& P, const Tile<NW>& tile, const StrandTable<NT>& st, const StagedRead& sr,
                                                        int p, bool reverse, int c, int out[SCG_COMBO_REGIONS], int& total) {
     int obs = c;
@@ -510,9 +519,9 @@ __device__ __forceinline__ bool combo_candidate_staged(const ScgComboParams& P, 
         int slot = reverse ? (SCG_COMBO_REGIONS - 1 - r) : r;
         const int start = region_start<NT>(st, r, reverse);
         const ScgIndex& tab = P.index[slot];
-        Query q = region_query<NW>(tile, sr.bit + p + start, tab.len, reverse);
+        QueryT<W> q = region_query<NW, W>(tile, sr.bit + p + start, tab.len, reverse);
         int idx, d;
-        index_match(tab, q, P.max_mm - obs, idx, d, SECOND);
+        index_match<W>(tab, q, P.max_mm - obs, idx, d, SECOND);
         if (idx < 0) return false;
         obs += d;
         if (obs > P.max_mm) return false;
@@ -522,7 +531,7 @@ __device__ __forceinline__ bool combo_candidate_staged(const ScgComboParams& P, 
     return true;
 }
 
-template<int NW, int NT, int NC, bool SECOND>
+template<int NW, int NT, int NC, bool SECOND, class W>
 __global__ __launch_bounds__(STAGE_BLOCK, SCG_COMBO_WAVES) __attribute__((amdgpu_num_sgpr(80))) void combo_staged_kernel(ScgComboParams P, ScgReads R, int64_t n_reads,
                                                                   ScgCounters cells, int32_t* __restrict__ error_flag) {
     __shared__ Tile<NW> tile;
@@ -558,7 +567,7 @@ __global__ __launch_bounds__(STAGE_BLOCK, SCG_COMBO_WAVES) __attribute__((amdgpu
             int c = window_mismatches<NW, NT>(tile, sr.bit + p, strands, rev);
             if (c > P.max_mm) continue;
             int cand[SCG_COMBO_REGIONS], tot;
-            if (!combo_candidate_staged<NW, NT, SECOND>(P, tile, strands, sr, p, rev, c, cand, tot)) continue;
+            if (!combo_candidate_staged<NW, NT, SECOND, W>(P, tile, strands, sr, p, rev, c, cand, tot)) continue;
             if (P.use_first) {
                 found = 1; best_id[0] = cand[0]; best_id[1] = cand[1];
                 break;
@@ -576,7 +585,7 @@ __global__ __launch_bounds__(STAGE_BLOCK, SCG_COMBO_WAVES) __attribute__((amdgpu
 }
 
 // Staged counterpart of mate_search.
-template<int NW, int NT, int NC>
+template<int NW, int NT, int NC, class W>
 __device__ __forceinline__ bool mate_search_staged(const Tile<NW>& tile, const StagedRead& sr, const ScgScan& T, const ScgIndex& X,
                                                    bool reverse, int max_mm, bool use_first, bool keep_first, int& index, int& mism) {
     bool found = false;
@@ -593,9 +602,9 @@ __device__ __forceinline__ bool mate_search_staged(const Tile<NW>& tile, const S
         clear_bit<NC>(cand, p);
         int c = window_mismatches<NW, NT>(tile, sr.bit + p, T, false);
         if (c > max_mm) continue;
-        Query q = region_query<NW>(tile, sr.bit + p + start, X.len, reverse);
+        QueryT<W> q = region_query<NW, W>(tile, sr.bit + p + start, X.len, reverse);
         int idx, d;
-        index_match(X, q, max_mm - c, idx, d, keep_first);
+        index_match<W>(X, q, max_mm - c, idx, d, keep_first);
         if (idx < 0) continue;
         int tot = c + d;
         if (use_first) { index = idx; mism = tot; return true; }
@@ -609,7 +618,7 @@ __device__ __forceinline__ bool mate_search_staged(const Tile<NW>& tile, const S
 }
 
 // One orientation of a staged pair: template 1 on (ta, a), template 2 on (tb, b).
-template<int NW, int NT, int NC>
+template<int NW, int NT, int NC, class W>
 __device__ __forceinline__ void dual_orientation_staged(const ScgDualParams& P, const bool BEST,
                                                         const Tile<NW>& ta, const StagedRead& a,
                                                         const Tile<NW>& tb, const StagedRead& b,
@@ -631,7 +640,7 @@ __device__ __forceinline__ void dual_orientation_staged(const ScgDualParams& P, 
         clear_bit<NC>(c1, p1);
         int m1 = window_mismatches<NW, NT>(ta, a.bit + p1, T1, false);
         if (m1 > P.max_mm1) continue;
-        Query q1 = region_query<NW>(ta, a.bit + p1 + s1, P.index1.len, rev1);
+        QueryT<W> q1 = region_query<NW, W>(ta, a.bit + p1 + s1, P.index1.len, rev1);
         uint32_t w2[NC];
 #pragma unroll
         for (int i = 0; i < NC; ++i) w2[i] = c2[i];
@@ -644,9 +653,9 @@ __device__ __forceinline__ void dual_orientation_staged(const ScgDualParams& P, 
                 clear_bit<NC>(c2, p2);      // never a hit of mate 2: drop it for later outer iterations
                 continue;
             }
-            Query q2 = region_query<NW>(tb, b.bit + p2 + s2, P.index2.len, rev2);
+            QueryT<W> q2 = region_query<NW, W>(tb, b.bit + p2 + s2, P.index2.len, rev2);
             int idx, tot;
-            pair_match(P.index1, P.index2, P.pairs, q1, P.max_mm1 - m1, q2, P.max_mm2 - m2, idx, tot);
+            pair_match<W>(P.index1, P.index2, P.pairs, q1, P.max_mm1 - m1, q2, P.max_mm2 - m2, idx, tot);
             if (idx >= 0) {
                 if (!BEST) { chosen = idx; return; }
                 int cur = tot + m1 + m2;
@@ -658,17 +667,17 @@ __device__ __forceinline__ void dual_orientation_staged(const ScgDualParams& P, 
 }
 
 // The two mate searches of diagnose_pair on staged tiles.
-template<int NW, int NT, int NC>
+template<int NW, int NT, int NC, class W>
 struct StagedMates {
     const Tile<NW>& tile1;
     const Tile<NW>& tile2;
     StagedRead sa, sb;
     __device__ __forceinline__ bool search1(const ScgDualParams& P, int which, int& index, int& mism) const {
-        return mate_search_staged<NW, NT, NC>(which ? tile2 : tile1, which ? sb : sa, P.scan1, P.index1, P.rev1 != 0,
+        return mate_search_staged<NW, NT, NC, W>(which ? tile2 : tile1, which ? sb : sa, P.scan1, P.index1, P.rev1 != 0,
                                               P.max_mm1, P.use_first != 0, P.keep_first != 0, index, mism);
     }
     __device__ __forceinline__ bool search2(const ScgDualParams& P, int which, int& index, int& mism) const {
-        return mate_search_staged<NW, NT, NC>(which ? tile2 : tile1, which ? sb : sa, P.scan2, P.index2, P.rev2 != 0,
+        return mate_search_staged<NW, NT, NC, W>(which ? tile2 : tile1, which ? sb : sa, P.scan2, P.index2, P.rev2 != 0,
                                               P.max_mm2, P.use_first != 0, P.keep_first != 0, index, mism);
     }
 };
@@ -677,7 +686,7 @@ struct StagedMates {
 // and the second pass of include.invalid=TRUE over the pairs the plain kernel rejected
 // (ScgDualParams::only_if_negative).  Two lean kernels instead of one: the nested pair search next to four
 // inlined mate searches needed 256 VGPRs plus a scratch copy of the arguments and ran 8 x slower.
-template<int NW, int NT, int NC, bool MATES_ONLY>
+template<int NW, int NT, int NC, bool MATES_ONLY, class W>
 __global__ __launch_bounds__(STAGE_BLOCK) void dual_staged_kernel(ScgDualParams P, ScgReads R1, ScgReads R2, int64_t n_pairs,
                                                                  ScgCounters counts, int32_t* __restrict__ error_flag) {
     __shared__ Tile<NW> tile1;
@@ -712,7 +721,7 @@ __global__ __launch_bounds__(STAGE_BLOCK) void dual_staged_kernel(ScgDualParams 
             const Tile<NW>* tb = o ? &tile1 : &tile2;
             const StagedRead ra = o ? sb : sa, rb = o ? sa : sb;
             int ci, cb;
-            dual_orientation_staged<NW, NT, NC>(P, best_mode, *ta, ra, *tb, rb, ci, cb);
+            dual_orientation_staged<NW, NT, NC, W>(P, best_mode, *ta, ra, *tb, rb, ci, cb);
             if (!best_mode) {
                 idx = ci;
                 if (ci >= 0) break;                      // :356-360
@@ -724,7 +733,7 @@ __global__ __launch_bounds__(STAGE_BLOCK) void dual_staged_kernel(ScgDualParams 
             }
         }
         if (MATES_ONLY) {
-            diagnose_pair(P, StagedMates<NW, NT, NC>{tile1, tile2, sa, sb}, counts);
+            diagnose_pair(P, StagedMates<NW, NT, NC, W>{tile1, tile2, sa, sb}, counts);
         }
     }
     if (!MATES_ONLY && counts.unit_index) counts.unit_index[r0 + threadIdx.x] = idx;       // index stream (ScgCounters::unit_index)
@@ -860,30 +869,35 @@ template<int NW, int NT> struct LaunchSingle {
     }
 };
 template<int NW, int NT> struct LaunchCombo {
+    template<int NC, class W>
+    static void run(const ScgComboParams& P, const ScgReads& R, int64_t n, const ScgCounters& cells, int32_t* flag, hipStream_t stream) {
+        if (P.only_if_negative) hipLaunchKernelGGL((combo_staged_kernel<NW, NT, NC, true, W>), dim3(staged_grid(n)), dim3(STAGE_BLOCK), 0, stream, P, R, n, cells, flag);
+        else hipLaunchKernelGGL((combo_staged_kernel<NW, NT, NC, false, W>), dim3(staged_grid(n)), dim3(STAGE_BLOCK), 0, stream, P, R, n, cells, flag);
+    }
     static hipError_t go(const ScgComboParams& P, const ScgReads& R, int64_t n, const ScgCounters& cells, int32_t* flag, hipStream_t stream) {
-        if (NW == 5 && P.scan.compact_ok && R.max_len - P.scan.len + 1 <= 96) {
-            if (P.only_if_negative) hipLaunchKernelGGL((combo_staged_kernel<NW, NT, (NW == 5 ? 3 : NW), true>), dim3(staged_grid(n)), dim3(STAGE_BLOCK), 0, stream, P, R, n, cells, flag);
-            else hipLaunchKernelGGL((combo_staged_kernel<NW, NT, (NW == 5 ? 3 : NW), false>), dim3(staged_grid(n)), dim3(STAGE_BLOCK), 0, stream, P, R, n, cells, flag);
-        } else {
-            if (P.only_if_negative) hipLaunchKernelGGL((combo_staged_kernel<NW, NT, NW, true>), dim3(staged_grid(n)), dim3(STAGE_BLOCK), 0, stream, P, R, n, cells, flag);
-            else hipLaunchKernelGGL((combo_staged_kernel<NW, NT, NW, false>), dim3(staged_grid(n)), dim3(STAGE_BLOCK), 0, stream, P, R, n, cells, flag);
-        }
+        const bool compact = NW == 5 && P.scan.compact_ok && R.max_len - P.scan.len + 1 <= 96;
+        constexpr int NCC = NW == 5 ? 3 : NW;
+        const bool wide = P.index[0].wide != 0;          // pools of 33..64 bases (both indexes are then built wide)
+        if (compact) { if (wide) run<NCC, uint64_t>(P, R, n, cells, flag, stream); else run<NCC, uint32_t>(P, R, n, cells, flag, stream); }
+        else { if (wide) run<NW, uint64_t>(P, R, n, cells, flag, stream); else run<NW, uint32_t>(P, R, n, cells, flag, stream); }
         return hipGetLastError();
     }
 };
 template<int NW, int NT> struct LaunchDual {
+    template<int NC, class W>
+    static void run(const ScgDualParams& P, const ScgReads& R1, const ScgReads& R2, int64_t n, const ScgCounters& counts, int32_t* flag, hipStream_t stream) {
+        if (P.diagnostics) hipLaunchKernelGGL((dual_staged_kernel<NW, NT, NC, true, W>), dim3(staged_grid(n)), dim3(STAGE_BLOCK), 0, stream, P, R1, R2, n, counts, flag);   // 2 (mates only)
+        else hipLaunchKernelGGL((dual_staged_kernel<NW, NT, NC, false, W>), dim3(staged_grid(n)), dim3(STAGE_BLOCK), 0, stream, P, R1, R2, n, counts, flag);
+    }
     static hipError_t go(const ScgDualParams& P, const ScgReads& R1, const ScgReads& R2, int64_t n, const ScgCounters& counts, int32_t* flag, hipStream_t stream) {
         const int max_len = R1.max_len > R2.max_len ? R1.max_len : R2.max_len;
         const int min_t = P.scan1.len < P.scan2.len ? P.scan1.len : P.scan2.len;
         const bool compact = NW == 5 && P.scan1.compact_ok && P.scan2.compact_ok && max_len - min_t + 1 <= 96;
+        constexpr int NCC = NW == 5 ? 3 : NW;
         if (P.diagnostics == 1) return hipErrorInvalidValue;   // the host runs include.invalid=TRUE as a plain pass followed by a masked pass of 2
-        if (P.diagnostics) {      // 2 (mates only)
-            if (compact) hipLaunchKernelGGL((dual_staged_kernel<NW, NT, (NW == 5 ? 3 : NW), true>), dim3(staged_grid(n)), dim3(STAGE_BLOCK), 0, stream, P, R1, R2, n, counts, flag);
-            else hipLaunchKernelGGL((dual_staged_kernel<NW, NT, NW, true>), dim3(staged_grid(n)), dim3(STAGE_BLOCK), 0, stream, P, R1, R2, n, counts, flag);
-        } else {
-            if (compact) hipLaunchKernelGGL((dual_staged_kernel<NW, NT, (NW == 5 ? 3 : NW), false>), dim3(staged_grid(n)), dim3(STAGE_BLOCK), 0, stream, P, R1, R2, n, counts, flag);
-            else hipLaunchKernelGGL((dual_staged_kernel<NW, NT, NW, false>), dim3(staged_grid(n)), dim3(STAGE_BLOCK), 0, stream, P, R1, R2, n, counts, flag);
-        }
+        const bool wide = P.index1.wide != 0;            // barcodes of 33..64 bases on either mate (both indexes are then built wide)
+        if (compact) { if (wide) run<NCC, uint64_t>(P, R1, R2, n, counts, flag, stream); else run<NCC, uint32_t>(P, R1, R2, n, counts, flag, stream); }
+        else { if (wide) run<NW, uint64_t>(P, R1, R2, n, counts, flag, stream); else run<NW, uint32_t>(P, R1, R2, n, counts, flag, stream); }
         return hipGetLastError();
     }
 };
@@ -927,7 +941,8 @@ hipError_t launch_random(const ScgSingleParams& P, int tmpl_len, const ScgReads&
 hipError_t launch_combo(const ScgComboParams& P, int tmpl_len, const ScgReads& R, int64_t n, const ScgCounters& cells, int32_t* flag, hipStream_t stream) {
     if (n <= 0) return hipSuccess;
     if (use_general(R.max_len)) {
-        hipLaunchKernelGGL(combo_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, stream, P, R, n, cells);
+        if (P.index[0].wide) hipLaunchKernelGGL(combo_kernel<uint64_t>, dim3(grid_for(n)), dim3(BLOCK), 0, stream, P, R, n, cells);
+        else hipLaunchKernelGGL(combo_kernel<uint32_t>, dim3(grid_for(n)), dim3(BLOCK), 0, stream, P, R, n, cells);
         return hipGetLastError();
     }
     return dispatch_shape<LaunchCombo>(R.max_len, tmpl_len, P, R, n, cells, flag, stream);
@@ -937,7 +952,8 @@ hipError_t launch_dual(const ScgDualParams& P, int tmpl_len, const ScgReads& R1,
     if (n <= 0) return hipSuccess;
     const int lo_len = R1.max_len < R2.max_len ? R1.max_len : R2.max_len;
     if (use_general(lo_len) || use_general(R1.max_len > R2.max_len ? R1.max_len : R2.max_len)) {
-        hipLaunchKernelGGL(dual_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, stream, P, R1, R2, n, counts);
+        if (P.index1.wide) hipLaunchKernelGGL(dual_kernel<uint64_t>, dim3(grid_for(n)), dim3(BLOCK), 0, stream, P, R1, R2, n, counts);
+        else hipLaunchKernelGGL(dual_kernel<uint32_t>, dim3(grid_for(n)), dim3(BLOCK), 0, stream, P, R1, R2, n, counts);
         return hipGetLastError();
     }
     const int max_len = R1.max_len > R2.max_len ? R1.max_len : R2.max_len;

@@ -395,23 +395,14 @@ void put_node(uint32_t* node, const WideKey& k, uint32_t val, uint32_t next) {
 
 } // namespace
 
-HostIndex build_index_wide(const char* const* pool, int32_t n, int32_t len, int max_mm) {
+static void check_wide_len(int len) {
     if (len > SCG_MAX_WIDE_BARCODE) {
         throw Error(SCG_ERR_UNSUPPORTED, "variable regions longer than 64 bp in total are not supported by this engine (got " + std::to_string(len) + ")");
     }
-    count_expansions(pool, n, len);
-    std::unordered_map<WideKey, int32_t, WideKeyHash> owner;
-    std::vector<WideKey> keys;
-    std::vector<int32_t> vals;
-    for (int32_t i = 0; i < n; ++i) {
-        for_each_expansion_wide(pool[i], len, [&](const WideKey& key) {
-            auto ins = owner.emplace(key, i);
-            if (!ins.second) throw_duplicate(ins.first->second, i);
-            keys.push_back(key);
-            vals.push_back(i);
-        });
-    }
-    HostIndex X;
+}
+
+// Tables and node copies of a wide (2 x 64-bit plane) index over concrete keys with their values.
+static void finish_index_wide(HostIndex& X, const std::vector<WideKey>& keys, const std::vector<int32_t>& vals, int32_t len, int max_mm) {
     X.wide = true;
     X.len = len;
     const size_t cnt = keys.size();
@@ -445,7 +436,7 @@ HostIndex build_index_wide(const char* const* pool, int32_t n, int32_t len, int 
         uint32_t* node = X.nodes.data() + static_cast<size_t>(c) * cnt * 8;
         for (size_t e = 0; e < cnt; ++e) put_node(node + 8 * e, keys[e], static_cast<uint32_t>(vals[e]), 0xFFFFFFFFu);
     }
-    if (nseg == 0) return X;
+    if (nseg == 0) return;
     uint32_t cap = 16;
     while (cap < cnt * table_factor(cnt)) cap <<= 1;
     X.slot_mask = cap - 1;
@@ -476,6 +467,47 @@ HostIndex build_index_wide(const char* const* pool, int32_t n, int32_t len, int 
             for (int w = 0; w < 8; ++w) table[8 * pos + w] = node[8 * i + w];
         }
     }
+}
+
+HostIndex build_index_wide(const char* const* pool, int32_t n, int32_t len, int max_mm) {
+    check_wide_len(len);
+    count_expansions(pool, n, len);
+    std::unordered_map<WideKey, int32_t, WideKeyHash> owner;
+    std::vector<WideKey> keys;
+    std::vector<int32_t> vals;
+    for (int32_t i = 0; i < n; ++i) {
+        for_each_expansion_wide(pool[i], len, [&](const WideKey& key) {
+            auto ins = owner.emplace(key, i);
+            if (!ins.second) throw_duplicate(ins.first->second, i);
+            keys.push_back(key);
+            vals.push_back(i);
+        });
+    }
+    HostIndex X;
+    finish_index_wide(X, keys, vals, len, max_mm);
+    return X;
+}
+
+// value = uid of the concrete sequence, wide keys (build_uid_index for pools of 33..64 bases, or paired with one).
+HostIndex build_uid_index_wide(const char* const* pool, int32_t n, int32_t len, int max_mm,
+                               std::vector<std::vector<int32_t> >& expansions, size_t& n_uid) {
+    check_wide_len(len);
+    count_expansions(pool, n, len);
+    std::unordered_map<WideKey, int32_t, WideKeyHash> uid_of;
+    std::vector<WideKey> keys;
+    expansions.assign(n, std::vector<int32_t>());
+    for (int32_t i = 0; i < n; ++i) {
+        for_each_expansion_wide(pool[i], len, [&](const WideKey& key) {
+            auto ins = uid_of.emplace(key, static_cast<int32_t>(keys.size()));
+            if (ins.second) keys.push_back(key);
+            expansions[i].push_back(ins.first->second);
+        });
+    }
+    std::vector<int32_t> vals(keys.size());
+    for (size_t u = 0; u < keys.size(); ++u) vals[u] = static_cast<int32_t>(u);
+    n_uid = keys.size();
+    HostIndex X;
+    finish_index_wide(X, keys, vals, len, max_mm);
     return X;
 }
 
@@ -535,8 +567,10 @@ HostPairTable build_pair_table(const std::vector<std::vector<int32_t> >& exp1, c
                 bool existed;
                 uint32_t slot = B.upsert(key, static_cast<int32_t>(i), &existed);
                 if (existed) throw_duplicate(P.vals[slot], static_cast<int32_t>(i));
-                P.list_key1.push_back(uid_keys1[u1]);
-                P.list_key2.push_back(uid_keys2[u2]);
+                if (!uid_keys1.empty() && !uid_keys2.empty()) {      // (wide pools pass none: they have no dense-scan fallback)
+                    P.list_key1.push_back(uid_keys1[u1]);
+                    P.list_key2.push_back(uid_keys2[u2]);
+                }
                 P.list_vals.push_back(static_cast<int32_t>(i));
             }
         }

@@ -118,8 +118,10 @@ def random_single_case(rng: random.Random, max_vlen: int = 33, sizes=(1, 30, 200
     return dict(kind="single", template=template, strand=strand, pool=pool, mismatches=mm, use_first=first, reads=reads)
 
 
-def random_combo_case(rng: random.Random, sizes=(1, 30, 200)) -> dict:
+def random_combo_case(rng: random.Random, sizes=(1, 30, 200), wide: bool = False) -> dict:
     v0, v1 = rng.choice([3, 5, 8, 14]), rng.choice([3, 6, 14])
+    if wide:          # a pool of 33..64 bases (wide keys), the other short or long
+        v0, v1 = rng.choice([(33, 6), (8, 40), (64, 64), (36, 33)])
     alphabet = rng.choice(["AC", BASES, BASES])
     p0 = make_pool(rng, rng.choice([1, 4, 30]), v0, alphabet, iupac_rate=rng.choice([0, 0, 0.05]))
     p1 = make_pool(rng, rng.choice([1, 4, 30]), v1, alphabet, iupac_rate=rng.choice([0, 0, 0.05]))
@@ -132,8 +134,10 @@ def random_combo_case(rng: random.Random, sizes=(1, 30, 200)) -> dict:
     return dict(kind="combo", template=template, strand=strand, pool0=p0, pool1=p1, mismatches=mm, use_first=first, reads=reads)
 
 
-def random_dual_case(rng: random.Random, hazard_free: bool = True, sizes=(1, 30, 150), max_mm: int = 2) -> dict:
+def random_dual_case(rng: random.Random, hazard_free: bool = True, sizes=(1, 30, 150), max_mm: int = 2, wide: bool = False) -> dict:
     l1, l2 = rng.choice([4, 6, 9, 12]), rng.choice([4, 7, 12])
+    if wide:          # a barcode of 33..64 bases on either mate (wide keys for both)
+        l1, l2 = rng.choice([(33, 7), (9, 40), (64, 64), (35, 34)])
     mm1, mm2 = rng.randint(0, max_mm), rng.randint(0, max_mm)
     # pools whose members are >= 2*cap+1 apart cannot trigger the reference's order-dependent
     # segmented-search cache
@@ -184,10 +188,10 @@ def random_dual_case(rng: random.Random, hazard_free: bool = True, sizes=(1, 30,
                 randomized=randomized, use_first=first, reads1=r1s, reads2=r2s)
 
 
-def random_paired_combo_case(rng: random.Random, sizes=(1, 30, 150), max_mm: int = 2) -> dict:
+def random_paired_combo_case(rng: random.Random, sizes=(1, 30, 150), max_mm: int = 2, wide: bool = False) -> dict:
     """countPairedComboBarcodes: the reads of a dual case against the two pools taken independently
     (distinct barcodes, no list of valid pairs; close barcodes allowed so that ties occur)."""
-    c = random_dual_case(rng, hazard_free=rng.random() < 0.5, sizes=sizes, max_mm=max_mm)
+    c = random_dual_case(rng, hazard_free=rng.random() < 0.5, sizes=sizes, max_mm=max_mm, wide=wide)
     pool1 = list(dict.fromkeys(c["pool1"]))
     pool2 = list(dict.fromkeys(c["pool2"]))
     return dict(kind="paired_combo", template1=c["template1"], reverse1=c["reverse1"], mismatches1=c["mismatches1"], pool1=pool1,

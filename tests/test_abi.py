@@ -91,7 +91,8 @@ def test_plan_argument_checks_precede_device_errors(sc):
     expect_error(sc, INV, "unknown base 'Z' detected when constructing the trie", P.single, "ACGT----TGCA", 2, ["AAZA"])
     expect_error(sc, INV, "longer than 256 bp", P.single, "A" * 250 + "----" + "C" * 10, 2, ["AAAA"])
     expect_error(sc, UNS, "longer than 64 bp", P.single, "ACGT" + "-" * 65 + "TGCA", 2, ["A" * 65])
-    expect_error(sc, UNS, "longer than 32 bp", P.combo, "ACGT" + "-" * 33 + "TG--CA", 2, ["A" * 33], ["CC"])
+    expect_error(sc, UNS, "longer than 64 bp", P.combo, "ACGT" + "-" * 65 + "TG--CA", 2, ["A" * 65], ["CC"])
+    expect_error(sc, UNS, "longer than 64 bp", P.dual, "ACGT" + "-" * 65 + "TG", False, 0, ["A" * 65], "AC--GT", False, 0, ["CC"])
     expect_error(sc, INV, "length of 'barcode_pools' should equal the number of variable regions", P.dual_single_end, "ACGT----TG--CA", 2, [["AAAA"]])
     expect_error(sc, INV, "length of variable region 2 \\(2\\) should be the same as its sequences \\(3\\)", P.dual_single_end, "ACGT----TG--CA", 2, [["AAAA"], ["CCC"]])
     expect_error(sc, INV, "all entries of 'barcode_pools' should have the same length", P.dual_single_end, "ACGT----TG--CA", 2, [["AAAA", "CCCC"], ["CC"]])

@@ -70,13 +70,14 @@ def test_single_random(sc, oracle, gpu, seed):
         done += 1
 
 
+@pytest.mark.parametrize("wide", [False, True], ids=["narrow", "wide"])      # wide: pools of 33..64 bases
 @pytest.mark.parametrize("seed", range(6))
-def test_combo_random(sc, oracle, gpu, seed):
+def test_combo_random(sc, oracle, gpu, seed, wide):
     from oracle.pyoracle import OracleError
     rng = random.Random(2000 + seed)
     done = 0
-    while done < 20:
-        case = gen.random_combo_case(rng)
+    while done < (8 if wide else 20):
+        case = gen.random_combo_case(rng, wide=wide)
         try:
             exp = oracle.count_combo(case["reads"], case["template"], case["strand"], case["pool0"], case["pool1"], case["mismatches"], case["use_first"])
         except OracleError:
@@ -89,14 +90,15 @@ def test_combo_random(sc, oracle, gpu, seed):
         done += 1
 
 
+@pytest.mark.parametrize("wide", [False, True], ids=["narrow", "wide"])      # wide: barcodes of 33..64 bases on a mate
 @pytest.mark.parametrize("seed", range(6))
 @pytest.mark.parametrize("hazard_free", [True, False])
-def test_dual_random(sc, oracle, gpu, seed, hazard_free):
+def test_dual_random(sc, oracle, gpu, seed, hazard_free, wide):
     # Both are compared with the cache-free oracle: hazard_free only matters when
     # comparing with the reference itself.
     rng = random.Random(3000 + seed)
-    for _ in range(20):
-        case = gen.random_dual_case(rng, hazard_free=hazard_free, max_mm=3)
+    for _ in range(6 if wide else 20):
+        case = gen.random_dual_case(rng, hazard_free=hazard_free, max_mm=3, wide=wide)
         exp = oracle.count_dual(case["reads1"], case["reads2"], case["template1"], case["reverse1"], case["mismatches1"], case["pool1"],
                                 case["template2"], case["reverse2"], case["mismatches2"], case["pool2"], case["randomized"], case["use_first"])
         got = run_dual(sc, case, gpu)
@@ -309,12 +311,13 @@ def test_wide_single_and_match_random(sc, oracle, gpu, seed):
         assert np.array_equal(got[0], exp[0]) and np.array_equal(got[1], exp[1]), (pool, seqs, subs, rev)
 
 
+@pytest.mark.parametrize("wide", [False, True], ids=["narrow", "wide"])
 @pytest.mark.parametrize("seed", range(5))
-def test_paired_combo_random(sc, oracle, gpu, seed):
+def test_paired_combo_random(sc, oracle, gpu, seed, wide):
     """countPairedComboBarcodes: combinations of independently matched mates, barcode1/2-only tallies."""
     rng = random.Random(6500 + seed)
-    for _ in range(20):
-        case = gen.random_paired_combo_case(rng)
+    for _ in range(6 if wide else 20):
+        case = gen.random_paired_combo_case(rng, wide=wide)
         exp = oracle.count_combo_paired(case["reads1"], case["reads2"], case["template1"], case["reverse1"], case["mismatches1"], case["pool1"],
                                         case["template2"], case["reverse2"], case["mismatches2"], case["pool2"], case["randomized"], case["use_first"])
         s1, o1 = sc.upload_reads(case["reads1"], gpu)
@@ -328,12 +331,13 @@ def test_paired_combo_random(sc, oracle, gpu, seed):
             assert np.array_equal(np.asarray(exp[key]), np.asarray(got[key])), (key, case, exp, got)
 
 
+@pytest.mark.parametrize("wide", [False, True], ids=["narrow", "wide"])
 @pytest.mark.parametrize("seed", range(5))
-def test_dual_diagnostics_random(sc, oracle, gpu, seed):
+def test_dual_diagnostics_random(sc, oracle, gpu, seed, wide):
     """include.invalid=TRUE: valid-pair counts, invalid combinations, barcode1/2-only tallies."""
     rng = random.Random(6000 + seed)
-    for _ in range(20):
-        case = gen.random_dual_case(rng, hazard_free=True, max_mm=2)
+    for _ in range(6 if wide else 20):
+        case = gen.random_dual_case(rng, hazard_free=True, max_mm=2, wide=wide)
         exp = oracle.count_dual_diag(case["reads1"], case["reads2"], case["template1"], case["reverse1"], case["mismatches1"], case["pool1"],
                                      case["template2"], case["reverse2"], case["mismatches2"], case["pool2"], case["randomized"], case["use_first"])
         s1, o1 = sc.upload_reads(case["reads1"], gpu)
