@@ -28,6 +28,9 @@
  *     size is known in advance, otherwise malloc'd by the library and released with scg_free.
  *   - barcode pools are arrays of NUL-terminated strings (R CHARSXPs are NUL-terminated); the
  *     library enforces "all the same length" itself like format_pointers() (src/utils.cpp:5-23).
+ *     Barcodes may be up to 64 bases long on every path (SCG_ERR_UNSUPPORTED beyond; the reference has no limit).
+ *   - FASTQ input may be plain, BGZF (bgzip) or any other gzip; it is detected by its magic bytes like
+ *     byteme::SomeFileReader (inst/include/byteme/SomeFileReader.hpp:31-44).
  *   - strand: 0 = forward, 1 = reverse, 2 = both (src/utils.cpp:33-41).
  *   - counters are 32-bit like the reference's (SingleBarcodeSingleEnd.hpp:132-133).
  *   - no CPU fallback exists: without a usable HIP device the counting functions fail with
@@ -55,10 +58,14 @@ const char* scg_version(void);
 /* Number of visible HIP devices (0 when there is none; never fails). */
 int scg_device_count(void);
 
-/* Makes `device` the calling thread's current HIP device.  The file-level entry points below run on
- * $SCG_DEVICE if set, else on the calling thread's current device, so a host that counts several
- * files at once (the matrixOf* functions: R/countSingleBarcodes.R:112-126 and siblings, BiocParallel
- * workers in the reference) gives each worker thread its own GPU with this call. */
+/* Makes `device` the calling thread's current HIP device.
+ *
+ * Devices of the file-level entry points below: $SCG_DEVICES ("all", or a comma list of device ids in which an id may
+ * repeat) if set; else $SCG_DEVICE alone if set; else the visible devices starting with the calling thread's current
+ * one -- as many of them as the input has groups of four 128 MB windows of FASTQ text, so that a small file stays on
+ * one GPU and a large one spreads its windows over all of them.  The single-end entry points shard one file over
+ * their devices (per-device counts are summed before the call returns); paired-end files run on the first device;
+ * the *_files entry points give every device one file at a time. */
 int scg_set_device(int device, char* err, size_t errcap);
 
 /* ---------------------------------------------------------------------------------------------
@@ -99,7 +106,7 @@ int scg_count_dual_barcodes(const char* path1, const char* constant1, int revers
 /* countDualBarcodesSingleEnd hot path: every variable region of the construct lies in
  * one read; pools[r][c] over the regions r spells valid combination c.  Replaces
  * src/count_dual_barcodes_single_end.cpp:53-87, non-diagnostic branch (:27-34, kaori::DualBarcodesSingleEnd).
- * pools: n_regions arrays of n_pools[r] strings; counts_out: n_pools[0] entries.  This engine handles 1 or 2
+ * pools: n_regions arrays of n_pools[r] strings; counts_out: n_pools[0] entries.  This engine handles 1 to 8
  * regions with at most 64 bases in total.  diagnostics must be 0 here: the include.invalid=TRUE branch returns
  * more outputs and is scg_count_dual_barcodes_single_end_diagnostics below. */
 int scg_count_dual_barcodes_single_end(const char* path, const char* constant,
