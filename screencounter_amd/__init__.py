@@ -8,7 +8,7 @@ Package contents (only what the path needs):
   synth.py   synthetic workloads of SURVEY.md section 8(d) (device-side generator)
   parallel.py  read-sharded multi-GPU driver (torch.distributed over RCCL)
 """
-from ._lib import ScgError, load  # noqa: F401
+from ._lib import ScgError, load, prepare_pool  # noqa: F401
 from .api import (  # noqa: F401
     count_single_barcodes, count_combo_barcodes_single, count_dual_barcodes, count_combo_barcodes_paired,
     count_single_barcodes_files, count_combo_barcodes_single_files, count_dual_barcodes_files, count_dual_barcodes_single_end, count_random_barcodes, match_barcodes, parse_fastq,

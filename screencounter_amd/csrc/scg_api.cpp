@@ -880,11 +880,10 @@ struct ScanSlot {
     bool pending = false;      // scan enqueued; the counting kernels still have to be launched
     bool busy = false;         // work of an earlier window may still be running on the stream
 
-    void init(scg_plan* P, size_t window) {
-        plan = P;
-        plan_device = P->device;
+    void init(int device, size_t window) {
+        plan_device = device;
         cap = window;
-        DeviceGuard g(P->device);
+        DeviceGuard g(device);
         HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         text.ensure(cap);
         h_result.ensure(sizeof(scg::TextScanResult));
@@ -932,20 +931,20 @@ size_t scan_window_bytes(uint64_t hint) {
 struct SlotPool {
     std::mutex mu;
     std::vector<std::unique_ptr<ScanSlot> > idle;
-    std::unique_ptr<ScanSlot> take(scg_plan* P, size_t window) {
+    std::unique_ptr<ScanSlot> take(int device, size_t window) {
         {
             std::lock_guard<std::mutex> g(mu);
             for (size_t i = 0; i < idle.size(); ++i) {
-                if (idle[i]->plan_device == P->device && idle[i]->cap >= window && idle[i]->cap <= 2 * window + (size_t(8) << 20)) {
+                if (idle[i]->plan_device == device && idle[i]->cap >= window && idle[i]->cap <= 2 * window + (size_t(8) << 20)) {
                     std::unique_ptr<ScanSlot> s = std::move(idle[i]);
                     idle.erase(idle.begin() + static_cast<long>(i));
-                    s->plan = P;
+                    s->plan = nullptr;
                     return s;
                 }
             }
         }
         std::unique_ptr<ScanSlot> s(new ScanSlot);
-        s->init(P, window);
+        s->init(device, window);
         return s;
     }
     void give(std::unique_ptr<ScanSlot> s) {
@@ -968,25 +967,80 @@ SlotPool& slot_pool() {
     return *pool;
 }
 
-void count_text_stream(const std::vector<scg_plan*>& plans, scg::TextSource& src) {
-    const int slots_per_plan = 3;
-    const size_t window = scan_window_bytes(src.size_hint());
-    Trace tr;
-    std::vector<std::unique_ptr<ScanSlot> > slots;
-    struct Return {
-        std::vector<std::unique_ptr<ScanSlot> >& v;
-        bool ok = false;
-        ~Return() { if (ok) for (auto& s : v) if (s) slot_pool().give(std::move(s)); }
-    } ret{slots};
-    for (int k = 0; k < slots_per_plan; ++k) {
-        for (scg_plan* P : plans) slots.push_back(slot_pool().take(P, window));
+// The single-end pipeline.  Slots belong to devices, not to plans, so the first window can be read, copied and
+// scanned (start) while the template and the library are still being compiled on another thread; run() then binds
+// device d's slots to plans[d] and carries on.
+class TextPipeline {
+public:
+    TextPipeline(scg::TextSource& source, const std::vector<int>& devs) : src(source), devices(devs), window(scan_window_bytes(source.size_hint())) {
+        const int slots_per_device = 3;
+        for (int k = 0; k < slots_per_device; ++k) {
+            for (int d : devices) slots.push_back(slot_pool().take(d, window));
+        }
+        tr.mark("  scan slots (pinned + HBM)");
     }
-    tr.mark("  scan slots (pinned + HBM)");
+    ~TextPipeline() {
+        if (ok) for (auto& s : slots) if (s) slot_pool().give(std::move(s));
+    }
+
+    // Window 0 on its way (no plan needed yet).
+    void start() { if (!ended && filled == 0) fill_next(); }
+
+    void run(const std::vector<scg_plan*>& plans) {
+        for (size_t i = 0; i < slots.size(); ++i) slots[i]->plan = plans[i % plans.size()];
+        // Window k is filled and put on the wire; the counting kernels of window k - lag are launched afterwards, by
+        // which time its copy and scan have normally finished: the host thread does not wait on the link.
+        const size_t lag = devices.size() * 2 < slots.size() ? devices.size() * 2 : slots.size() - 1;
+        while (!ended) {
+            fill_next();
+            if (filled > lag && finished < filled - lag) finish_next();
+        }
+        while (finished < filled) finish_next();
+        for (auto& s : slots) {
+            DeviceGuard g(s->plan_device);
+            HIP_CHECK(hipStreamSynchronize(s->stream));
+            s->busy = false;
+        }
+        ok = true;
+        if (tr.on) std::fprintf(stderr, "[scg]   windows of %zu MB: host fill %.2f ms, waiting for scans %.2f ms\n", window >> 20, t_fill, t_finish);
+        tr.mark("  windows");
+    }
+
+private:
+    scg::TextSource& src;
+    std::vector<int> devices;
+    size_t window;
+    std::vector<std::unique_ptr<ScanSlot> > slots;
+    size_t filled = 0, finished = 0;     // windows put on the wire / windows whose counting kernels have been launched
+    bool ended = false, ok = false;
+    Trace tr;
     double t_fill = 0, t_finish = 0;
-    auto finish = [&](ScanSlot& s) {
-        DeviceGuard g(s.plan->device);
+
+    void fill_next() {
+        ScanSlot& s = *slots[filled % slots.size()];
+        DeviceGuard g(s.plan_device);
+        if (s.pending) finish_next();                              // (only when there are fewer slots than the lag needs)
+        if (s.busy) { HIP_CHECK(hipStreamSynchronize(s.stream)); s.busy = false; }
+        const auto f0 = std::chrono::steady_clock::now();
+        const size_t bytes = src.next(s.text.as<char>(), s.cap);
+        t_fill += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - f0).count();
+        if (src.unusual()) throw UnusualInput();
+        if (bytes == 0) { ended = true; return; }
+        HIP_CHECK(hipMemcpyAsync(s.d_text.p, s.text.p, bytes, hipMemcpyHostToDevice, s.stream));
+        HIP_CHECK(scg::launch_text_scan(s.d_text.as<char>(), bytes, s.B, s.stream));
+        HIP_CHECK(hipMemcpyAsync(s.h_result.p, s.d_result.p, sizeof(scg::TextScanResult), hipMemcpyDeviceToHost, s.stream));
+        s.pending = true;
+        ++filled;
+    }
+
+    void finish_next() {
+        ScanSlot& s = *slots[finished % slots.size()];
+        const auto f1 = std::chrono::steady_clock::now();
+        DeviceGuard g(s.plan_device);
         HIP_CHECK(hipStreamSynchronize(s.stream));                // copy + scan + result are in
+        t_finish += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - f1).count();
         s.pending = false;
+        ++finished;
         const scg::TextScanResult r = *s.h_result.as<scg::TextScanResult>();
         if (r.flags) throw UnusualInput();
         if (r.n_records) {
@@ -994,41 +1048,14 @@ void count_text_stream(const std::vector<scg_plan*>& plans, scg::TextSource& src
                          static_cast<int64_t>(r.n_records), s.stream);
         }
         s.busy = true;
-    };
-    // Window k is filled and put on the wire; the counting kernels of window k - lag are launched afterwards, by which
-    // time its copy and scan have normally finished: the host thread does not wait on the link.
-    const size_t lag = plans.size() * 2 < slots.size() ? plans.size() * 2 : slots.size() - 1;
-    size_t k = 0;
-    for (;; ++k) {
-        ScanSlot& s = *slots[k % slots.size()];
-        DeviceGuard g(s.plan->device);
-        if (s.pending) finish(s);                                 // (never true with lag < slots.size(); kept for safety)
-        if (s.busy) { HIP_CHECK(hipStreamSynchronize(s.stream)); s.busy = false; }
-        const auto f0 = std::chrono::steady_clock::now();
-        const size_t bytes = src.next(s.text.as<char>(), s.cap);
-        t_fill += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - f0).count();
-        if (src.unusual()) throw UnusualInput();
-        if (bytes == 0) break;
-        HIP_CHECK(hipMemcpyAsync(s.d_text.p, s.text.p, bytes, hipMemcpyHostToDevice, s.stream));
-        HIP_CHECK(scg::launch_text_scan(s.d_text.as<char>(), bytes, s.B, s.stream));
-        HIP_CHECK(hipMemcpyAsync(s.h_result.p, s.d_result.p, sizeof(scg::TextScanResult), hipMemcpyDeviceToHost, s.stream));
-        s.pending = true;
-        const auto f1 = std::chrono::steady_clock::now();
-        if (k >= lag) finish(*slots[(k - lag) % slots.size()]);
-        t_finish += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - f1).count();
     }
-    for (size_t j = k > lag ? k - lag : 0; j < k; ++j) {
-        ScanSlot& s = *slots[j % slots.size()];
-        if (s.pending) finish(s);
-    }
-    for (auto& s : slots) {
-        DeviceGuard g(s->plan->device);
-        HIP_CHECK(hipStreamSynchronize(s->stream));
-        s->busy = false;
-    }
-    ret.ok = true;
-    if (tr.on) std::fprintf(stderr, "[scg]   windows of %zu MB: host fill %.2f ms, waiting for scans %.2f ms\n", window >> 20, t_fill, t_finish);
-    tr.mark("  windows");
+};
+
+void count_text_stream(const std::vector<scg_plan*>& plans, scg::TextSource& src) {
+    std::vector<int> devices;
+    for (scg_plan* P : plans) devices.push_back(P->device);
+    TextPipeline pipe(src, devices);
+    pipe.run(plans);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -1058,7 +1085,7 @@ void count_paired_text(scg_plan* P, scg::TextSource& src1, scg::TextSource& src2
     scg::TextSource* src[2] = {&src1, &src2};
     const size_t window = std::max(scan_window_bytes(src1.size_hint()), scan_window_bytes(src2.size_hint()));
     std::unique_ptr<ScanSlot> slot[2][2];
-    for (int m = 0; m < 2; ++m) for (int k = 0; k < 2; ++k) slot[m][k] = slot_pool().take(P, window);
+    for (int m = 0; m < 2; ++m) for (int k = 0; k < 2; ++k) { slot[m][k] = slot_pool().take(P->device, window); slot[m][k]->plan = P; }
     struct Return {
         std::unique_ptr<ScanSlot> (&s)[2][2];
         bool ok = false;
@@ -1336,6 +1363,58 @@ void schedule_files(int32_t n_files, const PlanSet& set, const std::function<voi
     worker(set.plans[0].get());
     for (auto& t : th) t.join();
     if (bad < n_files) throw Error(bad_code, bad_msg);
+}
+
+// One single-end file for a file-level entry point.  `compile` (template + pools -> plan: host work only) runs on a second
+// thread while the first window of text is read, copied to the first device and scanned; then the plans go to the devices
+// and the file is counted.  Errors keep the reference's order: the reader was opened by the caller, the handler's
+// constructor (compile) comes before anything met while reading.
+template<class Compile>
+std::unique_ptr<PlanSet> compile_and_count_single_end(const char* path, scg::FastqStream& fq, int nthreads, Compile compile) {
+    Trace tr;
+    std::unique_ptr<scg_plan> compiled;
+    std::exception_ptr compile_err, early;
+    std::thread th([&] {
+        try { compiled = compile(); } catch (...) { compile_err = std::current_exception(); }
+    });
+    std::vector<int> devices;
+    std::unique_ptr<scg::TextSource> src;
+    std::unique_ptr<TextPipeline> pipe;
+    try {
+        devices = devices_for_input(text_bytes_hint(path));
+        if (device_scan_enabled()) {
+            src = scg::TextSource::open(path, scg::default_host_threads(nthreads));
+            pipe.reset(new TextPipeline(*src, devices));
+            pipe->start();
+        }
+    } catch (const UnusualInput&) {
+        pipe.reset();
+    } catch (...) {
+        early = std::current_exception();
+        pipe.reset();
+    }
+    th.join();
+    if (compile_err) std::rethrow_exception(compile_err);
+    if (early) std::rethrow_exception(early);
+    tr.mark("compile + first window");
+    std::unique_ptr<PlanSet> set(new PlanSet(std::move(compiled), devices));
+    tr.mark("upload to device(s)");
+    bool done = false;
+    if (pipe) {
+        try {
+            pipe->run(set->all());
+            done = true;
+        } catch (const UnusualInput&) {
+            set->reset();
+        }
+        pipe.reset();
+    }
+    if (!done) {
+        DeviceGuard g(set->first()->device);
+        count_single_end_file(set->first(), path, fq, nthreads, nullptr, nullptr, nullptr);
+    }
+    tr.mark("count file");
+    return set;
 }
 
 void combo_compact(const int32_t* cells, int32_t n0, int32_t n1, int32_t** indices_out, int32_t** freq_out, int64_t* k_out) {
@@ -1733,17 +1812,12 @@ int scg_count_single_barcodes(const char* path, const char* constant, int strand
                               char* err, size_t errcap) {
     return guarded(err, errcap, [&] {
         if (!path || !counts_out || !total_out) throw Error(SCG_ERR_INVALID, "null argument");
-        Trace tr;
         scg::FastqStream fq(path);                                           // src/count_single_barcodes.cpp:30
-        auto compiled = compile_single(constant, strand, pool, n_pool, mismatches, use_first);   // :31-47
-        tr.mark("compile template + library");
-        PlanSet set(std::move(compiled), devices_for_input(text_bytes_hint(path)));
-        tr.mark("upload to device(s)");
-        count_single_end(set.all(), path, fq, nthreads);
-        tr.mark("count file");
-        set.read(counts_out);
-        *total_out = narrow_total(set.total());
-        tr.mark("read counters");
+        auto set = compile_and_count_single_end(path, fq, nthreads, [&] {
+            return compile_single(constant, strand, pool, n_pool, mismatches, use_first);   // :31-47
+        });
+        set->read(counts_out);
+        *total_out = narrow_total(set->total());
     });
 }
 
@@ -1755,12 +1829,12 @@ int scg_count_combo_barcodes_single(const char* path, const char* constant, int 
     return guarded(err, errcap, [&] {
         if (!path || !indices_out || !freq_out || !k_out || !total_out) throw Error(SCG_ERR_INVALID, "null argument");
         scg::FastqStream fq(path);
-        PlanSet set(compile_combo(constant, strand, pool0, n_pool0, pool1, n_pool1, mismatches, use_first),
-                    devices_for_input(text_bytes_hint(path)));
-        count_single_end(set.all(), path, fq, nthreads);
-        std::vector<int32_t> cells(static_cast<size_t>(set.first()->n_counters) + 1);
-        set.read(cells.data());
-        const int32_t total = narrow_total(set.total());
+        auto set = compile_and_count_single_end(path, fq, nthreads, [&] {
+            return compile_combo(constant, strand, pool0, n_pool0, pool1, n_pool1, mismatches, use_first);
+        });
+        std::vector<int32_t> cells(static_cast<size_t>(set->first()->n_counters) + 1);
+        set->read(cells.data());
+        const int32_t total = narrow_total(set->total());
         combo_compact(cells.data(), n_pool0, n_pool1, indices_out, freq_out, k_out);
         *total_out = total;
     });
@@ -1816,14 +1890,15 @@ int scg_count_dual_barcodes_single_end(const char* path, const char* constant, c
     return guarded(err, errcap, [&] {
         if (!path || !total_out || (n_regions > 0 && n_pools && n_pools[0] > 0 && !counts_out)) throw Error(SCG_ERR_INVALID, "null argument");
         scg::FastqStream fq(path);                             // src/count_dual_barcodes_single_end.cpp:64: reader first
-        auto P = compile_dual_single_end(constant, strand, pools, n_pools, n_regions, mismatches, use_first);
-        if (diagnostics) {
-            throw Error(SCG_ERR_INVALID, "diagnostics requested: call scg_count_dual_barcodes_single_end_diagnostics, which returns the extra outputs");
-        }
-        PlanSet set(std::move(P), devices_for_input(text_bytes_hint(path)));
-        count_single_end(set.all(), path, fq, nthreads);
-        set.read(counts_out);
-        *total_out = narrow_total(set.total());
+        auto set = compile_and_count_single_end(path, fq, nthreads, [&] {
+            auto P = compile_dual_single_end(constant, strand, pools, n_pools, n_regions, mismatches, use_first);
+            if (diagnostics) {
+                throw Error(SCG_ERR_INVALID, "diagnostics requested: call scg_count_dual_barcodes_single_end_diagnostics, which returns the extra outputs");
+            }
+            return P;
+        });
+        set->read(counts_out);
+        *total_out = narrow_total(set->total());
     });
 }
 
@@ -1924,14 +1999,14 @@ int scg_count_dual_barcodes_single_end_diagnostics(const char* path, const char*
     return guarded(err, errcap, [&] {
         if (!path || !invalid_indices_out || !invalid_freq_out || !k_out || !total_out) throw Error(SCG_ERR_INVALID, "null argument");
         scg::FastqStream fq(path);
-        PlanSet set(compile_dual_single_end_diag(constant, strand, pools, n_pools, n_regions, mismatches, use_first),
-                    devices_for_input(text_bytes_hint(path)));
-        count_single_end(set.all(), path, fq, nthreads);
-        std::vector<int32_t> all(static_cast<size_t>(set.first()->n_counters) + 1);
-        set.read(all.data());
-        const int32_t total = narrow_total(set.total());
+        auto set = compile_and_count_single_end(path, fq, nthreads, [&] {
+            return compile_dual_single_end_diag(constant, strand, pools, n_pools, n_regions, mismatches, use_first);
+        });
+        std::vector<int32_t> all(static_cast<size_t>(set->first()->n_counters) + 1);
+        set->read(all.data());
+        const int32_t total = narrow_total(set->total());
         int32_t b1 = 0, b2 = 0;
-        diagnostics_from_counters(set.first(), all, counts_out, invalid_indices_out, invalid_freq_out, k_out, &b1, &b2);
+        diagnostics_from_counters(set->first(), all, counts_out, invalid_indices_out, invalid_freq_out, k_out, &b1, &b2);
         *total_out = total;
     });
 }
