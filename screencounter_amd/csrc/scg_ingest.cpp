@@ -123,51 +123,44 @@ struct MappedFile {
     MappedFile& operator=(const MappedFile&) = delete;
 };
 
-// ---- plain file: windows are read straight into the (pinned) destination by several threads with pread().
-//      Copying out of a mapping of the file is faster per byte (tmpfs, 16 threads: 85-95 GB/s against 58 GB/s), but
-//      setting up and tearing down the page tables of a 10 GB mapping costs ~100 ms each -- and an unmapping left to a
-//      background thread holds the address-space lock against the next call's page faults.  58 GB/s is the speed of
-//      the PCIe link the windows go over next, so pread() it is: no mapping, no page-table work ----
+// ---- plain file: windows are copied out of a mapping of the file by several threads.  Copying from the mapping
+//      runs at 85-95 GB/s on tmpfs with 16 threads (pread() into the same pinned buffers: 50-58 GB/s, below the PCIe
+//      link the windows go over next), but a 10 GB mapping that has been touched takes ~100 ms to unmap, single-threaded
+//      and under the address-space write lock.  So every thread drops the page-table entries of the slice it has just
+//      copied with madvise(MADV_DONTNEED) -- a read-lock operation that runs in parallel and leaves the page cache
+//      alone -- and the final munmap finds nothing left to tear down ----
 class PlainSource : public TextSource {
-    int fd = -1;
-    size_t size = 0, pos = 0;
+    MappedFile f;
+    size_t pos = 0;
 public:
-    PlainSource(const char* path, int nthreads) {
-        threads = nthreads;
-        fd = ::open(path, O_RDONLY);
-        if (fd < 0) throw Error(SCG_ERR_IO, std::string("failed to open file at '") + path + "'");
-        struct stat st;
-        if (::fstat(fd, &st) != 0) { ::close(fd); throw Error(SCG_ERR_IO, "failed to stat the FASTQ file"); }
-        size = static_cast<size_t>(st.st_size);
-    }
-    ~PlainSource() override { if (fd >= 0) ::close(fd); }
+    PlainSource(const char* path, int nthreads) : f(path) { threads = nthreads; }
     const char* kind() const override { return "plain"; }
-    uint64_t size_hint() const override { return size - pos; }
+    uint64_t size_hint() const override { return f.size - pos; }
     size_t next(char* dst, size_t cap) override {
-        if (odd || pos >= size) return 0;
-        const size_t left = size - pos;
-        const bool final = left + 1 <= cap;
-        const size_t want = final ? left : cap - 1;
-        const int parts = static_cast<int>(std::min<size_t>(static_cast<size_t>(threads), (want >> 22) + 1));
-        const size_t base = pos;
-        parallel_for(parts, threads, [&](int i) {
-            size_t a = want * i / parts;
-            const size_t b = want * (i + 1) / parts;
-            while (a < b) {
-                const ssize_t got = ::pread(fd, dst + a, b - a, static_cast<off_t>(base + a));
-                if (got <= 0) throw Error(SCG_ERR_IO, "failed to read raw binary file");      // byteme/RawFileReader.hpp:60
-                a += static_cast<size_t>(got);
-            }
-        });
-        size_t take = want;
-        if (final) {
-            if (dst[take - 1] != '\n') dst[take++] = '\n';
-            pos = size;
-            return take;
+        if (odd || pos >= f.size) return 0;
+        const size_t left = f.size - pos;
+        size_t take;
+        bool pad = false;
+        if (left + 1 <= cap) {
+            take = left;
+            pad = f.data[f.size - 1] != '\n';
+        } else {
+            take = find_cut(f.data + pos, cap - 1);
+            if (!take) { odd = true; return 0; }
         }
-        take = find_cut(dst, want);
-        if (!take) { odd = true; return 0; }
+        const int parts = static_cast<int>(std::min<size_t>(static_cast<size_t>(threads), (take >> 22) + 1));
+        const char* src = f.data + pos;
+        const uintptr_t page = 4096;
+        parallel_for(parts, threads, [&](int i) {
+            const size_t a = take * i / parts, b = take * (i + 1) / parts;
+            std::memcpy(dst + a, src + a, b - a);
+            // whole pages inside the slice: their entries are not needed again
+            const uintptr_t lo = (reinterpret_cast<uintptr_t>(src + a) + page - 1) & ~(page - 1);
+            const uintptr_t hi = reinterpret_cast<uintptr_t>(src + b) & ~(page - 1);
+            if (hi > lo) (void)::madvise(reinterpret_cast<void*>(lo), hi - lo, MADV_DONTNEED);
+        });
         pos += take;
+        if (pad) dst[take++] = '\n';
         return take;
     }
 };

@@ -236,3 +236,34 @@ def test_paired_files_through_the_scan(sc, oracle, gpu, tmp_path, monkeypatch):
     open(p4, "wb").write(multi)
     got, n = sc.count_dual_barcodes(p1, t1, False, 1, pool1, p4, t2, False, 1, pool2, False, True, False, 4)
     assert n == total and np.array_equal(got, exp)
+
+
+def test_error_order_and_buffer_cache(sc, oracle, gpu, tmp_path, monkeypatch):
+    """The library is compiled while the first window is already on its way to the GPU; the reference's error order must
+    survive that: missing file, then the handler's argument errors, then whatever the file holds.  And the staging buffers
+    kept between calls never change results."""
+    from screencounter_amd import _lib
+    pool, reads = make_case(17, n=300)
+    good = str(tmp_path / "good.fastq")
+    open(good, "wb").write(gen.fastq_text(reads))
+    bad = str(tmp_path / "bad.fastq")
+    open(bad, "wb").write(b"@r0\nACGT\n+\nIII\n")
+    with pytest.raises(_lib.ScgError) as e:                       # file error first
+        sc.count_single_barcodes(str(tmp_path / "none.fastq"), "ACXT----TGCA", 2, ["AAAA"], 0, True, 1)
+    assert e.value.code == _lib.SCG_ERR_IO and "failed to open file" in str(e.value)
+    with pytest.raises(_lib.ScgError) as e:                       # argument error before the file's content is looked at
+        sc.count_single_barcodes(bad, "ACXT----TGCA", 2, ["AAAA"], 0, True, 1)
+    assert e.value.code == _lib.SCG_ERR_INVALID and "unknown base 'X'" in str(e.value)
+    with pytest.raises(_lib.ScgError) as e:
+        sc.count_single_barcodes(bad, TEMPLATE, 2, pool, 1, True, 1)
+    assert e.value.code == _lib.SCG_ERR_IO and "non-equal lengths" in str(e.value)
+    exp, total = oracle.count_single(reads, TEMPLATE, 2, pool, 1, True)
+    prepared = sc.prepare_pool(pool)
+    for cache in ("1", "0", "1"):
+        monkeypatch.setenv("SCG_BUFFER_CACHE", cache)
+        for p in (pool, prepared):
+            got, n = sc.count_single_barcodes(good, TEMPLATE, 2, p, 1, True, 2)
+            assert n == total and np.array_equal(got, exp)
+        sc.load().scg_release_buffers()
+    got, n = sc.count_single_barcodes(good, TEMPLATE, 2, prepared, 1, True, 2)
+    assert n == total and np.array_equal(got, exp)
