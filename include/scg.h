@@ -234,6 +234,14 @@ int scg_fastq_text_windows(const char* path, int64_t window_bytes, int nthreads,
                            char** text_out, int64_t* n_bytes_out, int64_t** cuts_out, int64_t* n_windows_out,
                            char* kind_out, char* err, size_t errcap);
 
+/* The other staging of plain files (host only, no device needed): the record scan done by the host threads, window by
+ * window, so that only sequences and offsets cross the PCIe link.  Output as scg_parse_fastq (release with scg_free);
+ * *n_windows_out windows of at most window_bytes of text were taken.  SCG_ERR_UNSUPPORTED for compressed input and for
+ * text that is not a run of ordinary 4-line records: such files take the device scan / the sequential reader. */
+int scg_fastq_scan_windows(const char* path, int64_t window_bytes, int nthreads,
+                           char** seqs_out, uint64_t** offsets_out, int64_t* n_reads_out, int64_t* n_windows_out,
+                           char* err, size_t errcap);
+
 /* ---------------------------------------------------------------------------------------------
  * Plans: a compiled (template, library, options) bound to one device, reusable across batches.
  * Replaces the construction of kaori::SingleBarcodeSingleEnd / CombinatorialBarcodesSingleEnd /

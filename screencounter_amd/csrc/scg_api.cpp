@@ -873,11 +873,13 @@ struct ScanSlot {
     scg_plan* plan = nullptr;
     int plan_device = -1;
     hipStream_t stream = nullptr;
-    PinnedBuf text, h_result;
+    PinnedBuf text, h_result, h_offsets;
     DevBuf d_text, d_counts, d_nl, d_offsets, d_seqs, d_result;
     scg::TextScanBuffers B;
     size_t cap = 0;
     bool pending = false;      // scan enqueued; the counting kernels still have to be launched
+    bool parsed = false;       // the host did the record scan of the pending window: `host_result` holds its outcome
+    scg::TextScanResult host_result{};
     bool busy = false;         // work of an earlier window may still be running on the stream
 
     void init(int device, size_t window) {
@@ -891,6 +893,7 @@ struct ScanSlot {
         B.cap_lines = cap / 16 + 1024;              // lines shorter than 16 bytes on average: left to the sequential reader
         B.cap_records = B.cap_lines / 4 + 1;
         B.cap_seq_bytes = cap / 2 + 64;
+        h_offsets.ensure((B.cap_records + 1) * sizeof(uint32_t));
         d_text.alloc(scg::text_scan_padded(cap) + 16);
         d_counts.alloc(B.cap_blocks * sizeof(uint32_t));
         d_nl.alloc(B.cap_lines * sizeof(uint32_t));
@@ -967,12 +970,18 @@ SlotPool& slot_pool() {
     return *pool;
 }
 
+bool host_scan_enabled() {
+    const char* e = std::getenv("SCG_HOST_SCAN");            // test hook: 0 ships the raw text of plain files too
+    return !(e && *e == '0');
+}
+
 // The single-end pipeline.  Slots belong to devices, not to plans, so the first window can be read, copied and
 // scanned (start) while the template and the library are still being compiled on another thread; run() then binds
 // device d's slots to plans[d] and carries on.
 class TextPipeline {
 public:
-    TextPipeline(scg::TextSource& source, const std::vector<int>& devs) : src(source), devices(devs), window(scan_window_bytes(source.size_hint())) {
+    TextPipeline(scg::TextSource& source, const std::vector<int>& devs)
+        : src(source), devices(devs), window(scan_window_bytes(source.size_hint())), host_scan(source.parses() && host_scan_enabled()) {
         const int slots_per_device = 3;
         for (int k = 0; k < slots_per_device; ++k) {
             for (int d : devices) slots.push_back(slot_pool().take(d, window));
@@ -990,7 +999,8 @@ public:
         for (size_t i = 0; i < slots.size(); ++i) slots[i]->plan = plans[i % plans.size()];
         // Window k is filled and put on the wire; the counting kernels of window k - lag are launched afterwards, by
         // which time its copy and scan have normally finished: the host thread does not wait on the link.
-        const size_t lag = devices.size() * 2 < slots.size() ? devices.size() * 2 : slots.size() - 1;
+        // (Windows scanned by the host need no such wait.)
+        const size_t lag = host_scan ? 0 : devices.size() * 2 < slots.size() ? devices.size() * 2 : slots.size() - 1;
         while (!ended) {
             fill_next();
             if (filled > lag && finished < filled - lag) finish_next();
@@ -1002,7 +1012,10 @@ public:
             s->busy = false;
         }
         ok = true;
-        if (tr.on) std::fprintf(stderr, "[scg]   windows of %zu MB: host fill %.2f ms, waiting for scans %.2f ms\n", window >> 20, t_fill, t_finish);
+        if (tr.on) {
+            std::fprintf(stderr, "[scg]   windows of %zu MB (%s scan): host fill %.2f ms, waiting for scans %.2f ms, for free slots %.2f ms\n", window >> 20,
+                         host_scan ? "host" : "device", t_fill, t_finish, t_busy);
+        }
         tr.mark("  windows");
     }
 
@@ -1010,22 +1023,52 @@ private:
     scg::TextSource& src;
     std::vector<int> devices;
     size_t window;
+    bool host_scan;
     std::vector<std::unique_ptr<ScanSlot> > slots;
     size_t filled = 0, finished = 0;     // windows put on the wire / windows whose counting kernels have been launched
     bool ended = false, ok = false;
     Trace tr;
-    double t_fill = 0, t_finish = 0;
+    double t_fill = 0, t_finish = 0, t_busy = 0;
 
     void fill_next() {
         ScanSlot& s = *slots[filled % slots.size()];
         DeviceGuard g(s.plan_device);
         if (s.pending) finish_next();                              // (only when there are fewer slots than the lag needs)
+        const auto b0 = std::chrono::steady_clock::now();
         if (s.busy) { HIP_CHECK(hipStreamSynchronize(s.stream)); s.busy = false; }
         const auto f0 = std::chrono::steady_clock::now();
-        const size_t bytes = src.next(s.text.as<char>(), s.cap);
+        t_busy += std::chrono::duration<double, std::milli>(f0 - b0).count();
+        scg::ParsedWindow w;
+        const size_t bytes = host_scan ? src.next_parsed(s.text.as<char>(), s.cap, s.h_offsets.as<uint32_t>(), s.B.cap_records + 1, w)
+                                       : src.next(s.text.as<char>(), s.cap);
         t_fill += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - f0).count();
         if (src.unusual()) throw UnusualInput();
         if (bytes == 0) { ended = true; return; }
+        if (host_scan) {
+            // one kernel pulls the segments over the link and lays them out back to back
+            if (w.seq_bytes > s.B.cap_seq_bytes || w.seq_bytes > 0xFFFFFFFFull || w.n_records > s.B.cap_records) throw UnusualInput();
+            scg::GatherSegments G;
+            G.n = static_cast<uint32_t>(w.n_segs);
+            uint32_t rec = 0, at = 0;
+            for (int i = 0; i < w.n_segs; ++i) {
+                const scg::ParsedSegment& g = w.seg[i];
+                G.seq_src[i] = s.text.as<char>() + g.seq_at;
+                G.off_src[i] = s.h_offsets.as<uint32_t>() + g.off_at;
+                G.seq_at[i] = at;
+                G.first[i] = rec;
+                rec += g.n_records;
+                at += g.seq_bytes;
+            }
+            G.seq_at[G.n] = at;
+            G.first[G.n] = rec;
+            HIP_CHECK(scg::launch_gather_segments(s.B.seqs, s.B.offsets, G, s.stream));
+            s.host_result = scg::TextScanResult{0, rec, w.max_len, 0, w.seq_bytes};
+            s.parsed = true;
+            s.pending = true;
+            ++filled;
+            return;
+        }
+        s.parsed = false;
         HIP_CHECK(hipMemcpyAsync(s.d_text.p, s.text.p, bytes, hipMemcpyHostToDevice, s.stream));
         HIP_CHECK(scg::launch_text_scan(s.d_text.as<char>(), bytes, s.B, s.stream));
         HIP_CHECK(hipMemcpyAsync(s.h_result.p, s.d_result.p, sizeof(scg::TextScanResult), hipMemcpyDeviceToHost, s.stream));
@@ -1037,11 +1080,11 @@ private:
         ScanSlot& s = *slots[finished % slots.size()];
         const auto f1 = std::chrono::steady_clock::now();
         DeviceGuard g(s.plan_device);
-        HIP_CHECK(hipStreamSynchronize(s.stream));                // copy + scan + result are in
+        if (!s.parsed) HIP_CHECK(hipStreamSynchronize(s.stream)); // copy + scan + result are in
         t_finish += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - f1).count();
         s.pending = false;
         ++finished;
-        const scg::TextScanResult r = *s.h_result.as<scg::TextScanResult>();
+        const scg::TextScanResult r = s.parsed ? s.host_result : *s.h_result.as<scg::TextScanResult>();
         if (r.flags) throw UnusualInput();
         if (r.n_records) {
             launch_batch(s.plan, make_reads(s.B.seqs, s.B.offsets, 0, static_cast<int32_t>(std::min<uint32_t>(r.max_len, 1u << 30))),
@@ -1639,6 +1682,41 @@ int scg_fastq_text_windows(const char* path, int64_t window_bytes, int nthreads,
         std::memcpy(c, cuts.data(), sizeof(int64_t) * cuts.size());
         *text_out = t; *n_bytes_out = static_cast<int64_t>(all.size());
         *cuts_out = c; *n_windows_out = static_cast<int64_t>(cuts.size()) - 1;
+    });
+}
+
+int scg_fastq_scan_windows(const char* path, int64_t window_bytes, int nthreads, char** seqs_out, uint64_t** offsets_out,
+                           int64_t* n_reads_out, int64_t* n_windows_out, char* err, size_t errcap) {
+    return guarded(err, errcap, [&] {
+        if (!path || !seqs_out || !offsets_out || !n_reads_out || !n_windows_out || window_bytes < 64) throw Error(SCG_ERR_INVALID, "null argument");
+        std::unique_ptr<scg::TextSource> src = scg::TextSource::open(path, scg::default_host_threads(nthreads));
+        if (!src->parses()) throw Error(SCG_ERR_UNSUPPORTED, std::string("no host-side record scan for ") + src->kind() + " input");
+        const size_t cap = static_cast<size_t>(window_bytes), cap_offsets = cap / 4 + 64;
+        std::vector<char> all, window(cap);
+        std::vector<uint32_t> offs(cap_offsets);
+        std::vector<uint64_t> offsets(1, 0);
+        int64_t n_windows = 0;
+        for (;;) {
+            scg::ParsedWindow w;
+            const size_t got = src->next_parsed(window.data(), cap, offs.data(), cap_offsets, w);
+            if (src->unusual()) throw Error(SCG_ERR_UNSUPPORTED, "the text is not a run of ordinary 4-line records");
+            if (!got) break;
+            ++n_windows;
+            for (int i = 0; i < w.n_segs; ++i) {
+                const scg::ParsedSegment& g = w.seg[i];
+                const uint64_t base = all.size();
+                all.insert(all.end(), window.begin() + static_cast<long>(g.seq_at), window.begin() + static_cast<long>(g.seq_at + g.seq_bytes));
+                for (uint32_t r = 0; r < g.n_records; ++r) offsets.push_back(base + offs[g.off_at + r + 1]);
+            }
+        }
+        char* t = static_cast<char*>(std::malloc(all.size() + 1));
+        uint64_t* o = static_cast<uint64_t*>(std::malloc(sizeof(uint64_t) * offsets.size()));
+        if (!t || !o) { std::free(t); std::free(o); throw std::bad_alloc(); }
+        if (!all.empty()) std::memcpy(t, all.data(), all.size());
+        std::memcpy(o, offsets.data(), sizeof(uint64_t) * offsets.size());
+        *seqs_out = t; *offsets_out = o;
+        *n_reads_out = static_cast<int64_t>(offsets.size()) - 1;
+        *n_windows_out = n_windows;
     });
 }
 

@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
 #include <cstdio>
 #include <cstring>
 #include <exception>
@@ -19,34 +20,80 @@
 
 namespace scg {
 
-void parallel_for(int n, int threads, const std::function<void(int)>& fn) {
-    if (n <= 0) return;
-    const int T = std::max(1, std::min(threads, n));
-    if (T == 1) {
-        for (int i = 0; i < n; ++i) fn(i);
-        return;
-    }
-    std::atomic<int> next(0);
-    std::exception_ptr err;
+struct WorkerPool::State {
     std::mutex mu;
-    auto work = [&] {
+    std::condition_variable wake, done;
+    std::vector<std::thread> th;
+    const std::function<void(int)>* fn = nullptr;
+    int n = 0;
+    std::atomic<int> next{0};
+    int running = 0;             // workers still inside the current job
+    uint64_t job = 0;
+    bool stop = false;
+    std::exception_ptr err;
+
+    void share() {
         for (;;) {
             const int i = next.fetch_add(1);
             if (i >= n) return;
             try {
-                fn(i);
+                (*fn)(i);
             } catch (...) {
                 std::lock_guard<std::mutex> g(mu);
                 if (!err) err = std::current_exception();
                 next.store(n);
             }
         }
-    };
-    std::vector<std::thread> th;
-    for (int t = 1; t < T; ++t) th.emplace_back(work);
-    work();
-    for (auto& t : th) t.join();
-    if (err) std::rethrow_exception(err);
+    }
+    void worker() {
+        uint64_t seen = 0;
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            wake.wait(lk, [&] { return stop || job != seen; });
+            if (stop) return;
+            seen = job;
+            lk.unlock();
+            share();
+            lk.lock();
+            if (--running == 0) done.notify_one();
+        }
+    }
+};
+
+WorkerPool::WorkerPool(int threads) : st(new State), n_threads(std::max(1, threads)) {
+    for (int t = 1; t < n_threads; ++t) st->th.emplace_back([this] { st->worker(); });
+}
+
+WorkerPool::~WorkerPool() {
+    {
+        std::lock_guard<std::mutex> g(st->mu);
+        st->stop = true;
+    }
+    st->wake.notify_all();
+    for (auto& t : st->th) t.join();
+    delete st;
+}
+
+void WorkerPool::run(int n, const std::function<void(int)>& fn) {
+    if (n <= 0) return;
+    if (n == 1 || st->th.empty()) {
+        for (int i = 0; i < n; ++i) fn(i);
+        return;
+    }
+    {
+        std::lock_guard<std::mutex> g(st->mu);
+        st->fn = &fn;
+        st->n = n;
+        st->next.store(0);
+        st->running = static_cast<int>(st->th.size());
+        st->err = nullptr;
+        ++st->job;
+    }
+    st->wake.notify_all();
+    st->share();
+    std::unique_lock<std::mutex> lk(st->mu);
+    st->done.wait(lk, [&] { return st->running == 0; });
+    if (st->err) std::rethrow_exception(st->err);
 }
 
 size_t strict_record_end(const char* data, size_t size, size_t p, const char** seq_out, size_t* seq_len_out) {
@@ -132,35 +179,116 @@ struct MappedFile {
 class PlainSource : public TextSource {
     MappedFile f;
     size_t pos = 0;
+    WorkerPool pool;
+
+    // The part of the mapping behind [a, b) is not needed again: whole pages inside it lose their entries.
+    static void drop(const char* a, const char* b) {
+        const uintptr_t page = 4096;
+        const uintptr_t lo = (reinterpret_cast<uintptr_t>(a) + page - 1) & ~(page - 1);
+        const uintptr_t hi = reinterpret_cast<uintptr_t>(b) & ~(page - 1);
+        if (hi > lo) (void)::madvise(reinterpret_cast<void*>(lo), hi - lo, MADV_DONTNEED);
+    }
+    // How much text the next window takes (0: none, or odd set) and whether the file ends in it without a newline.
+    size_t window(size_t cap, bool& pad) {
+        pad = false;
+        if (odd || pos >= f.size) return 0;
+        const size_t left = f.size - pos;
+        if (left + 1 <= cap) {
+            pad = f.data[f.size - 1] != '\n';
+            return left;
+        }
+        const size_t take = find_cut(f.data + pos, cap - 1);
+        if (!take) odd = true;
+        return take;
+    }
 public:
-    PlainSource(const char* path, int nthreads) : f(path) { threads = nthreads; }
+    PlainSource(const char* path, int nthreads) : f(path), pool(nthreads) { threads = nthreads; }
     const char* kind() const override { return "plain"; }
     uint64_t size_hint() const override { return f.size - pos; }
     size_t next(char* dst, size_t cap) override {
-        if (odd || pos >= f.size) return 0;
-        const size_t left = f.size - pos;
-        size_t take;
-        bool pad = false;
-        if (left + 1 <= cap) {
-            take = left;
-            pad = f.data[f.size - 1] != '\n';
-        } else {
-            take = find_cut(f.data + pos, cap - 1);
-            if (!take) { odd = true; return 0; }
-        }
+        bool pad;
+        size_t take = window(cap, pad);
+        if (!take) return 0;
         const int parts = static_cast<int>(std::min<size_t>(static_cast<size_t>(threads), (take >> 22) + 1));
         const char* src = f.data + pos;
-        const uintptr_t page = 4096;
-        parallel_for(parts, threads, [&](int i) {
+        pool.run(parts, [&](int i) {
             const size_t a = take * i / parts, b = take * (i + 1) / parts;
             std::memcpy(dst + a, src + a, b - a);
-            // whole pages inside the slice: their entries are not needed again
-            const uintptr_t lo = (reinterpret_cast<uintptr_t>(src + a) + page - 1) & ~(page - 1);
-            const uintptr_t hi = reinterpret_cast<uintptr_t>(src + b) & ~(page - 1);
-            if (hi > lo) (void)::madvise(reinterpret_cast<void*>(lo), hi - lo, MADV_DONTNEED);
+            drop(src + a, src + b);
         });
         pos += take;
         if (pad) dst[take++] = '\n';
+        return take;
+    }
+
+    // The record scan on the host: the window is split at record boundaries (guessed by find_cut, confirmed by the
+    // thread of the slice before, whose chain of records has to end exactly there); every thread walks the records of
+    // its slice with the same definition of an ordinary record as the device scan (strict_record_end) and copies the
+    // sequence lines out.  The threads read the mapping at the speed they would copy it, and write half as much.
+    bool parses() const override { return true; }
+    size_t next_parsed(char* seqs, size_t cap, uint32_t* offsets, size_t cap_offsets, ParsedWindow& out) override {
+        out = ParsedWindow();
+        bool pad;
+        const size_t take = window(cap, pad);       // a final record without its newline is an ordinary record here
+        if (!take) return 0;
+        const char* src = f.data + pos;
+        const size_t size = f.size - pos;           // records may be checked against text beyond the window
+        const int max_parts = static_cast<int>(sizeof(out.seg) / sizeof(out.seg[0]));
+        const size_t slice = std::min(size_t(4) << 20, std::max<size_t>(256, cap / 8));     // (small windows: tests)
+        int parts = static_cast<int>(std::min<size_t>(static_cast<size_t>(threads), take / slice + 1));
+        parts = std::max(1, std::min(parts, max_parts));
+        // Slice i runs from boundary(i) to boundary(i + 1): each thread works out both ends of its own slice (the
+        // guesses are deterministic, so neighbours agree); 0 means "no boundary found here, the slice before carries on".
+        auto boundary = [&](int i) -> size_t {
+            if (i <= 0) return 0;
+            if (i >= parts) return take;
+            return find_cut(src, take * i / parts, size_t(1) << 18);
+        };
+        const size_t per = cap_offsets / parts;
+        std::atomic<bool> bad(false);
+        pool.run(parts, [&](int i) {
+            ParsedSegment& g = out.seg[i];
+            g = ParsedSegment();
+            // where the slice really starts and ends: a missing boundary hands the stretch to the slice before
+            const size_t lo = boundary(i);
+            size_t hi = take;
+            if (i > 0 && lo == 0) { g.seq_at = take * i / parts; g.off_at = per * i; offsets[g.off_at] = 0; return; }
+            for (int k = i + 1; k < parts; ++k) {
+                const size_t c = boundary(k);
+                if (c) { hi = c; break; }
+            }
+            g.seq_at = lo;
+            g.off_at = per * i;
+            char* o = seqs + g.seq_at;
+            uint32_t* off = offsets + g.off_at;
+            size_t p = lo, n = 0, at = 0;
+            const size_t end = hi;
+            while (p < end) {
+                const char* s;
+                size_t len;
+                const size_t e = strict_record_end(src, size, p, &s, &len);
+                if (!e || n + 2 > per) { bad.store(true); return; }
+                std::memcpy(o + at, s, len);
+                off[n++] = static_cast<uint32_t>(at);
+                at += len;
+                if (len > g.max_len) g.max_len = static_cast<uint32_t>(len);
+                p = e;
+            }
+            if (p != end) { bad.store(true); return; }
+            off[n] = static_cast<uint32_t>(at);
+            g.n_records = static_cast<uint32_t>(n);
+            g.seq_bytes = static_cast<uint32_t>(at);
+            drop(src + lo, src + end);
+        });
+        if (bad.load()) { odd = true; return 0; }
+        out.n_segs = parts;
+        for (int i = 0; i < parts; ++i) {
+            ParsedSegment& g = out.seg[i];
+            out.max_len = std::max(out.max_len, g.max_len);
+            out.n_records += g.n_records;
+            out.seq_bytes += g.seq_bytes;
+        }
+        pos += take;
         return take;
     }
 };
@@ -244,8 +372,9 @@ void inflate_member(const char* src, size_t csize, char* dst, uint32_t isize) {
 class BgzfSource : public CarrySource {
     MappedFile f;
     size_t off = 0;
+    WorkerPool pool;
 public:
-    BgzfSource(const char* path, int nthreads) : f(path) { threads = nthreads; }
+    BgzfSource(const char* path, int nthreads) : f(path), pool(nthreads) { threads = nthreads; }
     const char* kind() const override { return "bgzf"; }
     uint64_t size_hint() const override { return static_cast<uint64_t>(f.size - off) * 6 + carry.size(); }
     static bool looks_like(const char* path) {
@@ -273,7 +402,7 @@ protected:
         }
         if (off >= f.size) exhausted = true;
         if (batch.empty() && !exhausted) { odd = true; return have; }     // one member larger than a window
-        parallel_for(static_cast<int>(batch.size()), threads, [&](int i) {
+        pool.run(static_cast<int>(batch.size()), [&](int i) {
             if (batch[i].isize) inflate_member(f.data + batch[i].off, batch[i].csize, dst + where[i], batch[i].isize);
         });
         return at;

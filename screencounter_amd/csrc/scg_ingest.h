@@ -16,12 +16,40 @@
 
 namespace scg {
 
-// fn(0) .. fn(n - 1) on up to `threads` host threads (the caller runs one share itself); exceptions are rethrown.
-void parallel_for(int n, int threads, const std::function<void(int)>& fn);
+// run(n, fn): fn(0) .. fn(n - 1) on a set of host threads that lives as long as the object (the caller runs one share
+// itself); exceptions are rethrown.  A window of text is a millisecond or two of work, of which starting sixteen
+// threads would be a third.
+class WorkerPool {
+public:
+    explicit WorkerPool(int threads);       // threads - 1 workers; the caller of run() takes a share
+    ~WorkerPool();
+    void run(int n, const std::function<void(int)>& fn);
+    int size() const { return n_threads; }
+    WorkerPool(const WorkerPool&) = delete;
+    WorkerPool& operator=(const WorkerPool&) = delete;
+private:
+    struct State;
+    State* st;
+    int n_threads;
+};
 
 // If an ordinary 4-line record starts at data[p], the offset just past it (== size for a final record without its
 // trailing newline); otherwise 0.  Optionally reports where its sequence line lies.
 size_t strict_record_end(const char* data, size_t size, size_t p, const char** seq = nullptr, size_t* seq_len = nullptr);
+
+// The sequences of one window, found by the host (TextSource::next_parsed): each segment is the work of one thread,
+// `seq_bytes` bytes of sequences back to back at seqs[seq_at ...) and n_records + 1 byte offsets, relative to the
+// segment's first sequence, at offsets[off_at ...).
+struct ParsedSegment {
+    size_t seq_at = 0, off_at = 0;
+    uint32_t n_records = 0, seq_bytes = 0, max_len = 0;
+};
+struct ParsedWindow {
+    ParsedSegment seg[64];
+    int n_segs = 0;
+    uint64_t n_records = 0, seq_bytes = 0;
+    uint32_t max_len = 0;
+};
 
 class TextSource {
 public:
@@ -33,6 +61,12 @@ public:
     // Returns its size; 0 at the end of the input.  When the input ends without a newline one is appended (the
     // reference accepts a final record without it).  cap must be at least min_capacity().
     virtual size_t next(char* dst, size_t cap) = 0;
+    // Sources whose text is addressable on the host (plain files) can do the record scan there instead, which halves
+    // what goes over the PCIe link: the sequences of the next window of (at most cap bytes of) text go to
+    // seqs[0 .. cap), sparsely (see ParsedSegment), their offsets to offsets[0 .. cap_offsets).  Returns the text
+    // bytes consumed, 0 at the end of the input; sets unusual() for anything but ordinary 4-line records.
+    virtual bool parses() const { return false; }
+    virtual size_t next_parsed(char*, size_t, uint32_t*, size_t, ParsedWindow&) { return 0; }
     // The text could not be cut at a verified record boundary: the caller must redo the file sequentially.
     bool unusual() const { return odd; }
     // An upper estimate of the text bytes still to come (window sizing only).

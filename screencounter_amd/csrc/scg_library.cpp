@@ -6,6 +6,11 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
+#include <cstdio>
+#include <exception>
+#include <mutex>
+#include <thread>
 #include <unordered_map>
 
 namespace scg {
@@ -37,29 +42,35 @@ inline int base_code(char c) {
 
 // Allowed codes of a library character in the reference's expansion order A, C, G, T
 // (kaori/MismatchTrie.hpp:163-188).  Returns the count, 0 for an unknown character.
-int iupac_codes(char c, int out[4]) {
-    const int A = 0, C = 1, T = 2, G = 3;
-    int n = 0;
-    auto put = [&](int x) { out[n++] = x; };
-    switch (c) {
-        case 'A': case 'a': put(A); break;
-        case 'C': case 'c': put(C); break;
-        case 'G': case 'g': put(G); break;
-        case 'T': case 't': put(T); break;
-        case 'R': case 'r': put(A); put(G); break;
-        case 'Y': case 'y': put(C); put(T); break;
-        case 'S': case 's': put(C); put(G); break;
-        case 'W': case 'w': put(A); put(T); break;
-        case 'K': case 'k': put(G); put(T); break;
-        case 'M': case 'm': put(A); put(C); break;
-        case 'B': case 'b': put(C); put(G); put(T); break;
-        case 'D': case 'd': put(A); put(G); put(T); break;
-        case 'H': case 'h': put(A); put(C); put(T); break;
-        case 'V': case 'v': put(A); put(C); put(G); break;
-        case 'N': case 'n': put(A); put(C); put(G); put(T); break;
-        default: break;
+struct IupacTable {
+    uint8_t n[256];
+    uint8_t code[256][4];
+    IupacTable() {
+        std::memset(n, 0, sizeof(n));
+        std::memset(code, 0, sizeof(code));
+        const int A = 0, C = 1, T = 2, G = 3;
+        auto def = [&](char c, std::initializer_list<int> codes) {
+            for (int ch : {static_cast<int>(c), static_cast<int>(c) + ('a' - 'A')}) {
+                int k = 0;
+                for (int x : codes) code[ch][k++] = static_cast<uint8_t>(x);
+                n[ch] = static_cast<uint8_t>(k);
+            }
+        };
+        def('A', {A}); def('C', {C}); def('G', {G}); def('T', {T});
+        def('R', {A, G}); def('Y', {C, T}); def('S', {C, G}); def('W', {A, T}); def('K', {G, T}); def('M', {A, C});
+        def('B', {C, G, T}); def('D', {A, G, T}); def('H', {A, C, T}); def('V', {A, C, G});
+        def('N', {A, C, G, T});
     }
-    return n;
+};
+const IupacTable& iupac() {
+    static const IupacTable t;
+    return t;
+}
+inline int iupac_codes(char c, int out[4]) {
+    const IupacTable& t = iupac();
+    const unsigned char u = static_cast<unsigned char>(c);
+    for (int k = 0; k < 4; ++k) out[k] = t.code[u][k];
+    return t.n[u];
 }
 
 const int64_t MAX_EXPANSIONS = int64_t(1) << 26;
@@ -68,9 +79,18 @@ const int64_t MAX_EXPANSIONS = int64_t(1) << 26;
 template<class F>
 void for_each_expansion(const char* s, int len, F f) {
     int cnt[SCG_MAX_BARCODE], codes[SCG_MAX_BARCODE][4], choice[SCG_MAX_BARCODE];
+    bool plain = true;
+    uint64_t only = 0;
     for (int p = 0; p < len; ++p) {
         cnt[p] = iupac_codes(s[p], codes[p]);
         choice[p] = 0;
+        plain &= cnt[p] == 1;
+        const uint64_t c = static_cast<uint64_t>(codes[p][0]);
+        only |= ((c & 1) << p) | ((c >> 1) << (32 + p));
+    }
+    if (plain) {            // the usual library: A, C, G, T only
+        f(only);
+        return;
     }
     for (;;) {
         uint64_t key = 0;
@@ -110,9 +130,9 @@ int64_t count_expansions(const char* const* pool, int32_t n, int32_t len) {
     return total;
 }
 
-uint32_t capacity_for(int64_t entries) {
+uint32_t capacity_for(int64_t entries, int slots_per_entry = 2) {
     uint64_t cap = 16;
-    while (cap < static_cast<uint64_t>(entries) * 4) cap <<= 1;
+    while (cap < static_cast<uint64_t>(entries) * static_cast<uint64_t>(slots_per_entry)) cap <<= 1;
     return static_cast<uint32_t>(cap);
 }
 
@@ -224,6 +244,26 @@ int pool_length(const char* const* pool, int32_t n) {
 
 namespace {
 
+// fn(0) .. fn(n - 1), each on its own thread (n <= 6 position groups).
+template<class F>
+void for_each_group(int n, F fn) {
+    std::exception_ptr err;
+    std::mutex mu;
+    auto guarded = [&](int i) {
+        try {
+            fn(i);
+        } catch (...) {
+            std::lock_guard<std::mutex> g(mu);
+            if (!err) err = std::current_exception();
+        }
+    };
+    std::vector<std::thread> th;
+    for (int i = 1; i < n; ++i) th.emplace_back(guarded, i);
+    if (n > 0) guarded(0);
+    for (auto& t : th) t.join();
+    if (err) std::rethrow_exception(err);
+}
+
 // Lays the concrete entries (key, value) out as a segment index (scg_common.h: ScgIndex).
 void finish_index(HostIndex& X, const std::vector<uint64_t>& keys, const std::vector<int32_t>& vals, int32_t len, int max_mm) {
     const size_t n = keys.size();
@@ -267,61 +307,52 @@ void finish_index(HostIndex& X, const std::vector<uint64_t>& keys, const std::ve
     }
     if (nseg == 0) return;
 
-    // chains: entries agreeing on group s, linked in ascending entry order; heads[s] = first of each chain
-    std::vector<std::vector<int32_t> > heads(nseg);
-    for (int sgm = 0; sgm < nseg; ++sgm) {
-        const uint64_t mask = groups[sgm];
-        X.segmask[sgm] = mask;
-        uint32_t* node = X.nodes.data() + static_cast<size_t>(sgm) * n * 4;
-        std::unordered_map<uint64_t, int32_t> head_of;
-        head_of.reserve(n * 2);
-        for (size_t i = n; i-- > 0;) {              // back to front: every chain ends up ascending
-            auto it = head_of.find(keys[i] & mask);
-            if (it == head_of.end()) {
-                head_of.emplace(keys[i] & mask, static_cast<int32_t>(i));
-            } else {
-                node[4 * i + 3] = static_cast<uint32_t>(it->second);
-                it->second = static_cast<int32_t>(i);
-            }
-        }
-        heads[sgm].reserve(head_of.size());
-        for (size_t i = 0; i < n; ++i) {            // deterministic insertion order
-            auto it = head_of.find(keys[i] & mask);
-            if (it->second == static_cast<int32_t>(i)) heads[sgm].push_back(static_cast<int32_t>(i));
-        }
-    }
-    // open addressing with linear probing, one slot count for all tables (load: table_factor)
+    // One table per group, open addressing with linear probing, one slot count for all (load: table_factor).  Entries
+    // agreeing on the group's positions form a chain in ascending entry order whose head sits in the slot itself: going
+    // through the entries back to front, each either claims a free slot or becomes the new head of the chain it finds.
+    // The groups are independent and are built side by side (the build overlaps the first window of a file only).
     uint32_t cap = 16;
     while (cap < n * table_factor(n)) cap <<= 1;
     X.slot_mask = cap - 1;
-    std::vector<std::vector<int32_t> > placed(nseg);
-    for (int sgm = 0; sgm < nseg; ++sgm) {
-        placed[sgm].assign(cap, -1);
-        for (int32_t e : heads[sgm]) {
-            uint32_t pos = scg_hash64(keys[e] & groups[sgm]) & X.slot_mask;
-            while (placed[sgm][pos] >= 0) pos = (pos + 1) & X.slot_mask;
-            placed[sgm][pos] = e;
-        }
-    }
-    X.tables.assign(static_cast<size_t>(nseg) * cap * 4, 0);
-    for (int sgm = 0; sgm < nseg; ++sgm) {
-        const uint32_t* node = X.nodes.data() + static_cast<size_t>(sgm) * n * 4;
+    X.tables.resize(static_cast<size_t>(nseg) * cap * 4);
+    for (int sgm = 0; sgm < nseg; ++sgm) X.segmask[sgm] = groups[sgm];
+    for_each_group(nseg, [&](int sgm) {
+        const uint64_t mask = groups[sgm];
+        const uint32_t slot_mask = X.slot_mask;
+        uint32_t* node = X.nodes.data() + static_cast<size_t>(sgm) * n * 4;
         uint32_t* table = X.tables.data() + static_cast<size_t>(sgm) * cap * 4;
+        std::vector<int32_t> placed(cap, -1);
+        for (size_t i = n; i-- > 0;) {
+            const uint64_t sk = keys[i] & mask;
+            uint32_t pos = scg_hash64(sk) & slot_mask;
+            for (;;) {
+                const int32_t e = placed[pos];
+                if (e < 0) { placed[pos] = static_cast<int32_t>(i); break; }
+                if ((keys[e] & mask) == sk) {
+                    node[4 * i + 3] = static_cast<uint32_t>(e);
+                    placed[pos] = static_cast<int32_t>(i);
+                    break;
+                }
+                pos = (pos + 1) & slot_mask;
+            }
+        }
         for (uint32_t pos = 0; pos < cap; ++pos) {
-            const int32_t e = placed[sgm][pos];
+            const int32_t e = placed[pos];
             if (e < 0) {
+                table[4 * pos] = table[4 * pos + 1] = table[4 * pos + 2] = 0;
                 table[4 * pos + 3] = SCG_SLOT_EMPTY;
             } else {
                 for (int w = 0; w < 4; ++w) table[4 * pos + w] = node[4 * static_cast<size_t>(e) + w];
             }
         }
-    }
+    });
 }
 
 } // namespace
 
 HostIndex build_index(const char* const* pool, int32_t n, int32_t len, int max_mm) {
     check_len(len);
+    auto T0 = std::chrono::steady_clock::now();
     int64_t total = count_expansions(pool, n, len);
     std::vector<uint64_t> hk;
     std::vector<int32_t> hv;
@@ -346,7 +377,10 @@ HostIndex build_index(const char* const* pool, int32_t n, int32_t len, int max_m
         });
     }
     HostIndex X;
+    auto T1 = std::chrono::steady_clock::now();
     finish_index(X, keys, vals, len, max_mm);
+    auto T2 = std::chrono::steady_clock::now();
+    if (std::getenv("SCG_TRACE_INDEX")) std::fprintf(stderr, "expansions %.2f ms, finish %.2f ms\n", std::chrono::duration<double, std::milli>(T1 - T0).count(), std::chrono::duration<double, std::milli>(T2 - T1).count());
     return X;
 }
 
@@ -440,33 +474,38 @@ static void finish_index_wide(HostIndex& X, const std::vector<WideKey>& keys, co
     uint32_t cap = 16;
     while (cap < cnt * table_factor(cnt)) cap <<= 1;
     X.slot_mask = cap - 1;
-    X.tables.assign(static_cast<size_t>(nseg) * cap * 8, 0);
-    for (int sgm = 0; sgm < nseg; ++sgm) {
+    X.tables.resize(static_cast<size_t>(nseg) * cap * 8);
+    for (int sgm = 0; sgm < nseg; ++sgm) X.segmask[sgm] = groups[sgm];
+    for_each_group(nseg, [&](int sgm) {             // as finish_index
         const uint64_t mask = groups[sgm];
-        X.segmask[sgm] = mask;
+        const uint32_t slot_mask = X.slot_mask;
         uint32_t* node = X.nodes.data() + static_cast<size_t>(sgm) * cnt * 8;
         uint32_t* table = X.tables.data() + static_cast<size_t>(sgm) * cap * 8;
-        for (uint32_t pos = 0; pos < cap; ++pos) table[8 * pos + 5] = SCG_SLOT_EMPTY;
-        std::unordered_map<WideKey, int32_t, WideKeyHash> head_of;
-        head_of.reserve(cnt * 2);
-        for (size_t i = cnt; i-- > 0;) {            // back to front: every chain ends up ascending
-            WideKey sk{keys[i].lo & mask, keys[i].hi & mask};
-            auto it = head_of.find(sk);
-            if (it == head_of.end()) {
-                head_of.emplace(sk, static_cast<int32_t>(i));
-            } else {
-                node[8 * i + 5] = static_cast<uint32_t>(it->second);
-                it->second = static_cast<int32_t>(i);
+        std::vector<int32_t> placed(cap, -1);
+        for (size_t i = cnt; i-- > 0;) {
+            const WideKey sk{keys[i].lo & mask, keys[i].hi & mask};
+            uint32_t pos = scg_hash128(sk.lo, sk.hi) & slot_mask;
+            for (;;) {
+                const int32_t e = placed[pos];
+                if (e < 0) { placed[pos] = static_cast<int32_t>(i); break; }
+                if ((keys[e].lo & mask) == sk.lo && (keys[e].hi & mask) == sk.hi) {
+                    node[8 * i + 5] = static_cast<uint32_t>(e);
+                    placed[pos] = static_cast<int32_t>(i);
+                    break;
+                }
+                pos = (pos + 1) & slot_mask;
             }
         }
-        for (size_t i = 0; i < cnt; ++i) {
-            WideKey sk{keys[i].lo & mask, keys[i].hi & mask};
-            if (head_of[sk] != static_cast<int32_t>(i)) continue;
-            uint32_t pos = scg_hash128(sk.lo, sk.hi) & X.slot_mask;
-            while (table[8 * pos + 5] != SCG_SLOT_EMPTY) pos = (pos + 1) & X.slot_mask;
-            for (int w = 0; w < 8; ++w) table[8 * pos + w] = node[8 * i + w];
+        for (uint32_t pos = 0; pos < cap; ++pos) {
+            const int32_t e = placed[pos];
+            if (e < 0) {
+                for (int w = 0; w < 8; ++w) table[8 * pos + w] = 0;
+                table[8 * pos + 5] = SCG_SLOT_EMPTY;
+            } else {
+                for (int w = 0; w < 8; ++w) table[8 * pos + w] = node[8 * static_cast<size_t>(e) + w];
+            }
         }
-    }
+    });
 }
 
 HostIndex build_index_wide(const char* const* pool, int32_t n, int32_t len, int max_mm) {
@@ -557,7 +596,7 @@ HostPairTable build_pair_table(const std::vector<std::vector<int32_t> >& exp1, c
             throw Error(SCG_ERR_UNSUPPORTED, "barcode pairs expand to more than 2^26 concrete sequences");
         }
     }
-    Builder B(P.keys, P.vals, capacity_for(total));
+    Builder B(P.keys, P.vals, capacity_for(total, 4));      // this one is probed by the device: a quarter full
     P.mask = B.mask;
     for (size_t i = 0; i < exp1.size(); ++i) {
         // concatenated expansions in lexicographic order: first barcode major

@@ -44,6 +44,21 @@ hipError_t launch_text_scan(const char* d_text, size_t n_bytes, const TextScanBu
 // (dst and src must not overlap).
 hipError_t launch_rebase_offsets(uint32_t* dst, const uint32_t* src, uint32_t n, uint32_t add, uint32_t sub, hipStream_t stream);
 
+// Host-side record scan (scg_ingest.h): the sequences and offsets of a window lie in pinned host memory in segments,
+// one per host thread, the offsets of each relative to its own first sequence.  One kernel pulls them over the link
+// (zero-copy reads run at link speed, 56 GB/s, where sixteen hipMemcpyAsync calls of 4 MB reach 32-37 GB/s and cost the
+// host 48 us each: tools/ubench/zero_copy.hip) and lays them out back to back:
+//   seqs[seq_at[s] ...) = seq_src[s][0 .. seq_at[s+1] - seq_at[s]),
+//   offsets[first[s] + j] = off_src[s][j] + seq_at[s] for j < first[s+1] - first[s],   offsets[first[n]] = seq_at[n].
+struct GatherSegments {
+    uint32_t n;                  // segments (<= 64)
+    const char* seq_src[64];     // device-visible host pointers
+    const uint32_t* off_src[64];
+    uint32_t seq_at[65];
+    uint32_t first[65];
+};
+hipError_t launch_gather_segments(char* seqs, uint32_t* offsets, const GatherSegments& G, hipStream_t stream);
+
 } // namespace scg
 
 #endif

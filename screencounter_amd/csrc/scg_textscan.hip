@@ -177,6 +177,51 @@ __global__ __launch_bounds__(TS_BLOCK) void rebase_kernel(uint32_t* __restrict__
     if (i < n) dst[i] = src[i] + add - sub;
 }
 
+// Tiles of 64 KB (sequence bytes) or 16 Ki offsets are dealt to the workgroups round-robin; the sources are pinned host
+// memory, read in 16-byte pieces whatever their alignment.
+constexpr uint32_t GATHER_TILE = 65536;
+
+__global__ __launch_bounds__(TS_BLOCK) void gather_segments_kernel(char* __restrict__ seqs, uint32_t* __restrict__ offsets, scg::GatherSegments G) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) offsets[G.first[G.n]] = G.seq_at[G.n];
+    for (uint32_t t = blockIdx.x;; t += gridDim.x) {
+        uint32_t k = t, s = 0;
+        bool seq_tile = true, found = false;
+        for (; s < G.n; ++s) {
+            const uint32_t nt = (G.seq_at[s + 1] - G.seq_at[s] + GATHER_TILE - 1) / GATHER_TILE;
+            if (k < nt) { found = true; break; }
+            k -= nt;
+        }
+        if (!found) {
+            seq_tile = false;
+            for (s = 0; s < G.n; ++s) {
+                const uint32_t nt = ((G.first[s + 1] - G.first[s]) * 4 + GATHER_TILE - 1) / GATHER_TILE;
+                if (k < nt) { found = true; break; }
+                k -= nt;
+            }
+            if (!found) return;
+        }
+        if (seq_tile) {
+            const uint32_t bytes = G.seq_at[s + 1] - G.seq_at[s];
+            const uint32_t lo = k * GATHER_TILE, n = min(GATHER_TILE, bytes - lo);
+            const char* src = G.seq_src[s] + lo;
+            char* dst = seqs + G.seq_at[s] + lo;
+            for (uint32_t j = threadIdx.x * 16; j + 16 <= n; j += TS_BLOCK * 16) {
+                uint4 v;
+                __builtin_memcpy(&v, src + j, 16);
+                __builtin_memcpy(dst + j, &v, 16);
+            }
+            if (threadIdx.x < (n & 15u)) dst[(n & ~15u) + threadIdx.x] = src[(n & ~15u) + threadIdx.x];
+        } else {
+            const uint32_t count = G.first[s + 1] - G.first[s];
+            const uint32_t lo = k * (GATHER_TILE / 4), n = min(GATHER_TILE / 4, count - lo);
+            const uint32_t* src = G.off_src[s] + lo;
+            uint32_t* dst = offsets + G.first[s] + lo;
+            const uint32_t add = G.seq_at[s];
+            for (uint32_t j = threadIdx.x; j < n; j += TS_BLOCK) dst[j] = src[j] + add;
+        }
+    }
+}
+
 } // namespace
 
 namespace scg {
@@ -184,6 +229,13 @@ namespace scg {
 hipError_t launch_rebase_offsets(uint32_t* dst, const uint32_t* src, uint32_t n, uint32_t add, uint32_t sub, hipStream_t stream) {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(rebase_kernel, dim3((n + TS_BLOCK - 1) / TS_BLOCK), dim3(TS_BLOCK), 0, stream, dst, src, n, add, sub);
+    return hipGetLastError();
+}
+
+hipError_t launch_gather_segments(char* seqs, uint32_t* offsets, const GatherSegments& G, hipStream_t stream) {
+    if (G.n == 0 || G.n > 64) return hipErrorInvalidValue;
+    // enough workgroups to keep the link busy, few enough to leave the counting kernels of earlier windows their CUs
+    hipLaunchKernelGGL(gather_segments_kernel, dim3(128), dim3(TS_BLOCK), 0, stream, seqs, offsets, G);
     return hipGetLastError();
 }
 

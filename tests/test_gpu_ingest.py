@@ -1,5 +1,6 @@
-"""The device-scan ingestion path (raw FASTQ text -> HBM -> record scan, csrc/scg_textscan.hip + scg_ingest.cpp) behind the
-file-level entry points: every input form (plain, BGZF, gzip), tiny windows that force many hand-overs and carries,
+"""The ingestion paths behind the file-level entry points -- plain files scanned for records by the host threads
+(sequences + offsets -> HBM) or, like BGZF and gzip always, shipped as raw text and scanned on the device
+(csrc/scg_textscan.hip + scg_ingest.cpp): every input form (plain, BGZF, gzip), tiny windows that force many hand-overs and carries,
 several pipelines (devices) sharing one file, the host-parser path as a cross-check, the multi-file entries against
 per-file calls, and the fall-back to the sequential reader for everything that is not a run of ordinary records."""
 import gzip
@@ -14,6 +15,14 @@ from tests import gen
 pytestmark = pytest.mark.gpu
 
 TEMPLATE = "ACGTACGA" + "-" * 12 + "TGCATGCA"
+
+
+@pytest.fixture(params=["host_scan", "device_scan"])
+def plain_scan(request, monkeypatch):
+    """Who scans plain files for records: the host threads (default) or the device (SCG_HOST_SCAN=0)."""
+    if request.param == "device_scan":
+        monkeypatch.setenv("SCG_HOST_SCAN", "0")
+    return request.param
 
 
 def make_case(seed, n=6000):
@@ -38,7 +47,7 @@ def write_forms(tmp_path, reads, trailing_newline=True):
 
 @pytest.mark.parametrize("window_kb", [None, 8])
 @pytest.mark.parametrize("trailing_newline", [True, False])
-def test_every_input_form_counts_like_the_oracle(sc, oracle, gpu, tmp_path, monkeypatch, window_kb, trailing_newline):
+def test_every_input_form_counts_like_the_oracle(sc, oracle, gpu, tmp_path, monkeypatch, plain_scan, window_kb, trailing_newline):
     pool, reads = make_case(11)
     exp, total = oracle.count_single(reads, TEMPLATE, 2, pool, 1, True)
     paths = write_forms(tmp_path, reads, trailing_newline)
@@ -56,7 +65,7 @@ def test_every_input_form_counts_like_the_oracle(sc, oracle, gpu, tmp_path, monk
     assert n == total and np.array_equal(got, exp)
 
 
-def test_several_pipelines_share_one_file(sc, oracle, gpu, tmp_path, monkeypatch):
+def test_several_pipelines_share_one_file(sc, oracle, gpu, tmp_path, monkeypatch, plain_scan):
     """$SCG_DEVICES lists the devices one call may use; an id may repeat.  Windows go round-robin over the plans and the
     per-device counters are summed at the end: the result must not depend on the list."""
     pool, reads = make_case(12, n=20000)
@@ -95,7 +104,7 @@ def test_combo_and_dual_single_end_through_the_scan(sc, oracle, gpu, tmp_path, m
     assert n == en and np.array_equal(c, ec)
 
 
-def test_unordinary_files_fall_back_to_the_sequential_reader(sc, oracle, gpu, tmp_path, monkeypatch):
+def test_unordinary_files_fall_back_to_the_sequential_reader(sc, oracle, gpu, tmp_path, monkeypatch, plain_scan):
     from screencounter_amd import _lib
     pool, reads = make_case(14, n=400)
     exp, total = oracle.count_single(reads, TEMPLATE, 2, pool, 1, True)
@@ -132,7 +141,7 @@ def test_unordinary_files_fall_back_to_the_sequential_reader(sc, oracle, gpu, tm
     assert "read name should start with '@'" in str(e.value)
 
 
-def test_multi_file_entries_equal_per_file_calls(sc, oracle, gpu, tmp_path, monkeypatch):
+def test_multi_file_entries_equal_per_file_calls(sc, oracle, gpu, tmp_path, monkeypatch, plain_scan):
     rng = random.Random(15)
     pool = gen.make_pool(rng, 40, 12, "ACGT")
     files, exp, totals = [], [], []
@@ -238,7 +247,7 @@ def test_paired_files_through_the_scan(sc, oracle, gpu, tmp_path, monkeypatch):
     assert n == total and np.array_equal(got, exp)
 
 
-def test_error_order_and_buffer_cache(sc, oracle, gpu, tmp_path, monkeypatch):
+def test_error_order_and_buffer_cache(sc, oracle, gpu, tmp_path, monkeypatch, plain_scan):
     """The library is compiled while the first window is already on its way to the GPU; the reference's error order must
     survive that: missing file, then the handler's argument errors, then whatever the file holds.  And the staging buffers
     kept between calls never change results."""

@@ -1,4 +1,5 @@
-"""Host side of the FASTQ staging (csrc/scg_ingest.cpp): the raw-text windows the file-level entry points ship to the GPU.
+"""Host side of the FASTQ staging (csrc/scg_ingest.cpp): the raw-text windows the file-level entry points ship to the GPU,
+and the host-side record scan of plain files (sequences + offsets only go over the link).
 Plain files, BGZF (members inflated in parallel) and ordinary gzip (one inflate stream, multi-member included) must all
 yield the decompressed text cut into windows of whole 4-line records; text that cannot be cut that way is declined
 (the counting calls then take the sequential reader).  No device needed."""
@@ -30,6 +31,27 @@ def text_windows(sc, path, window, threads=4):
         L.scg_free(text)
         L.scg_free(cuts)
     return data, c, kind.value.decode()
+
+
+def scan_windows(sc, path, window, threads=4):
+    """scg_fastq_scan_windows -> (list of sequences, number of windows)."""
+    from screencounter_amd import _lib
+    import numpy as np
+    L = sc.load()
+    seqs, offs = C.c_void_p(), C.c_void_p()
+    n, nw = C.c_int64(0), C.c_int64(0)
+    err = _lib.errbuf()
+    rc = L.scg_fastq_scan_windows(os.fspath(path).encode(), int(window), int(threads), C.byref(seqs), C.byref(offs), C.byref(n), C.byref(nw),
+                                  err, _lib.ERRCAP)
+    if rc:
+        raise _lib.ScgError(rc, err.value.decode())
+    try:
+        o = np.ctypeslib.as_array(C.cast(offs, C.POINTER(C.c_uint64)), shape=(n.value + 1,)).copy()
+        data = C.string_at(seqs, int(o[-1]))
+    finally:
+        L.scg_free(seqs)
+        L.scg_free(offs)
+    return [data[int(a):int(b)] for a, b in zip(o[:-1], o[1:])], nw.value
 
 
 def strict_records(chunk: bytes):
@@ -128,3 +150,51 @@ def test_missing_file(sc, tmp_path):
     with pytest.raises(_lib.ScgError) as e:
         text_windows(sc, tmp_path / "nope.fastq", 4096)
     assert e.value.code == _lib.SCG_ERR_IO and "failed to open file" in str(e.value)
+
+
+@pytest.mark.parametrize("window", [4096, 70_001, 1 << 20])
+@pytest.mark.parametrize("threads", [1, 4, 7])
+def test_host_record_scan_of_plain_files(sc, tmp_path, window, threads):
+    rng = random.Random(window * 31 + threads)
+    reads = random_reads(rng, 4000, lo=0 if window != 4096 else 1, hi=160)
+    text = gen.fastq_text(reads, trailing_newline=(window != 70_001))
+    p = tmp_path / "x.fastq"
+    p.write_bytes(text)
+    got, nw = scan_windows(sc, p, window, threads)
+    assert got == [r.encode() for r in reads]
+    assert nw >= len(text) // window
+    if window == 4096:
+        assert nw > 50
+
+
+def test_host_record_scan_declines_what_the_device_scan_declines(sc, tmp_path):
+    from screencounter_amd import _lib
+    good = gen.fastq_text(random_reads(random.Random(3), 50))
+    cases = {
+        "multi_line": b"@r\nACGT\nACGT\n+\nIIII\nIIII\n" * 50,
+        "plus_in_sequence": good + b"@r\nAC+GT\n+\nIIIII\n" + good,
+        "quality_length": good + b"@r\nACGT\n+\nIII\n" + good,
+        "no_at": good + b"r\nACGT\n+\nIIII\n" + good,
+        "blank_line": good + b"\n" + good,
+        "truncated": good + b"@r\nACGT\n+\n",
+        "crlf_quality_longer": good + b"@r\nACGT\n+\nIIII\r\n" + good,
+    }
+    for name, text in cases.items():
+        p = tmp_path / (name + ".fastq")
+        p.write_bytes(text)
+        for window in (1 << 20, 2048):
+            with pytest.raises(_lib.ScgError) as e:
+                scan_windows(sc, p, window)
+            assert e.value.code == _lib.SCG_ERR_UNSUPPORTED, name
+    g = tmp_path / "x.fastq.gz"
+    g.write_bytes(gzip.compress(good))
+    with pytest.raises(_lib.ScgError) as e:
+        scan_windows(sc, g, 1 << 20)
+    assert e.value.code == _lib.SCG_ERR_UNSUPPORTED and "gzip" in str(e.value)
+    e0 = tmp_path / "empty.fastq"
+    e0.write_bytes(b"")
+    assert scan_windows(sc, e0, 4096) == ([], 0)
+    # CRLF files whose lines all carry the '\r' are ordinary records for the reference too ('\r' is part of each line)
+    crlf = tmp_path / "crlf.fastq"
+    crlf.write_bytes(b"@r1\r\nACGT\r\n+\r\nIIII\r\n@r2\r\nGG\r\n+\r\nII\r\n")
+    assert scan_windows(sc, crlf, 4096)[0] == [b"ACGT\r", b"GG\r"]
