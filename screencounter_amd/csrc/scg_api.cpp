@@ -917,6 +917,28 @@ struct ScanSlot {
     }
 };
 
+// The sequences and offsets the host threads found in a window (pinned, in segments) go to the slot's HBM buffers,
+// back to back: one kernel pulls them over the link.  Returns the number of records.
+uint32_t enqueue_gather(ScanSlot& s, const scg::ParsedWindow& w) {
+    if (w.seq_bytes > s.B.cap_seq_bytes || w.seq_bytes > 0xFFFFFFFFull || w.n_records > s.B.cap_records) throw UnusualInput();
+    scg::GatherSegments G;
+    G.n = static_cast<uint32_t>(w.n_segs);
+    uint32_t rec = 0, at = 0;
+    for (int i = 0; i < w.n_segs; ++i) {
+        const scg::ParsedSegment& g = w.seg[i];
+        G.seq_src[i] = s.text.as<char>() + g.seq_at;
+        G.off_src[i] = s.h_offsets.as<uint32_t>() + g.off_at;
+        G.seq_at[i] = at;
+        G.first[i] = rec;
+        rec += g.n_records;
+        at += g.seq_bytes;
+    }
+    G.seq_at[G.n] = at;
+    G.first[G.n] = rec;
+    HIP_CHECK(scg::launch_gather_segments(s.B.seqs, s.B.offsets, G, s.stream));
+    return rec;
+}
+
 size_t scan_window_bytes(uint64_t hint) {
     size_t w = size_t(128) << 20;
     if (const char* e = std::getenv("SCG_WINDOW_KB")) {          // test hook: tiny windows force many hand-overs
@@ -930,7 +952,7 @@ size_t scan_window_bytes(uint64_t hint) {
 }
 
 // Idle scan slots are kept for the next call (pinning and unpinning 3 x 128 MB of host memory costs ~120 ms, a third
-// of the time a 10 GB file takes): at most three per device, released by scg_release_buffers() or with the process.
+// of the time a 10 GB file takes): at most four per device (the paired pipeline uses four), released by scg_release_buffers() or with the process.
 struct SlotPool {
     std::mutex mu;
     std::vector<std::unique_ptr<ScanSlot> > idle;
@@ -957,7 +979,7 @@ struct SlotPool {
         std::lock_guard<std::mutex> g(mu);
         int same = 0;
         for (auto& x : idle) same += x->plan_device == s->plan_device;
-        if (same < 3) idle.push_back(std::move(s));
+        if (same < 4) idle.push_back(std::move(s));
     }
     void clear() {
         std::lock_guard<std::mutex> g(mu);
@@ -1045,23 +1067,7 @@ private:
         if (src.unusual()) throw UnusualInput();
         if (bytes == 0) { ended = true; return; }
         if (host_scan) {
-            // one kernel pulls the segments over the link and lays them out back to back
-            if (w.seq_bytes > s.B.cap_seq_bytes || w.seq_bytes > 0xFFFFFFFFull || w.n_records > s.B.cap_records) throw UnusualInput();
-            scg::GatherSegments G;
-            G.n = static_cast<uint32_t>(w.n_segs);
-            uint32_t rec = 0, at = 0;
-            for (int i = 0; i < w.n_segs; ++i) {
-                const scg::ParsedSegment& g = w.seg[i];
-                G.seq_src[i] = s.text.as<char>() + g.seq_at;
-                G.off_src[i] = s.h_offsets.as<uint32_t>() + g.off_at;
-                G.seq_at[i] = at;
-                G.first[i] = rec;
-                rec += g.n_records;
-                at += g.seq_bytes;
-            }
-            G.seq_at[G.n] = at;
-            G.first[G.n] = rec;
-            HIP_CHECK(scg::launch_gather_segments(s.B.seqs, s.B.offsets, G, s.stream));
+            const uint32_t rec = enqueue_gather(s, w);
             s.host_result = scg::TextScanResult{0, rec, w.max_len, 0, w.seq_bytes};
             s.parsed = true;
             s.pending = true;
@@ -1102,106 +1108,150 @@ void count_text_stream(const std::vector<scg_plan*>& plans, scg::TextSource& src
 }
 
 // -------------------------------------------------------------------------------------------------
-// Device-scan pipeline, paired-end: both files are shipped as raw text and scanned on the GPU like single-end input;
-// the two streams of sequences are brought into step there.  Windows of the two files hold different numbers of
-// records, so each mate has a queue in HBM to which its scanned sequences are appended; whenever both queues hold
-// reads, the common prefix is counted as pairs and the remainder of the longer queue moves to its front.
+// The paired-end pipeline.  Each file is taken in windows like single-end input -- plain files scanned for records by
+// the host threads, compressed ones shipped as text and scanned on the device -- and the two streams of sequences are
+// brought into step on the device without moving them again: windows of the two files hold different numbers of
+// records, so each mate keeps a cursor into its current window (sequences + offsets in HBM); the kernels count
+// min(remaining, remaining) pairs from the two cursors, and the mate whose window is used up takes its next one.
 // Replaces kaori::process_paired_end_data (process_data.hpp:224-340).  One device: pair i needs read i of both files.
 // -------------------------------------------------------------------------------------------------
-struct MateQueue {
-    DevBuf seqs, offs, tmp_seqs, tmp_offs;
-    uint32_t n = 0;           // reads queued
-    uint32_t bytes = 0;       // their sequence bytes
-    uint32_t max_len = 0;
-    size_t cap_bytes = 0, cap_reads = 0;
-    void init(size_t window) {
-        cap_bytes = 2 * (window / 2 + 64) + 64;
-        cap_reads = 2 * (window / 64 + 256) + 2;
-        seqs.alloc(cap_bytes + 64); offs.alloc((cap_reads + 1) * sizeof(uint32_t));
-        tmp_seqs.alloc(cap_bytes + 64); tmp_offs.alloc((cap_reads + 1) * sizeof(uint32_t));
-        HIP_CHECK(hipMemset(offs.p, 0, sizeof(uint32_t)));
+struct MateWindows {
+    scg::TextSource* src = nullptr;
+    std::unique_ptr<ScanSlot> slot[2];      // double buffer: the host fills one while the kernels read the other
+    hipEvent_t used[2] = {nullptr, nullptr};// the last kernel reading slot k has been enqueued before this event
+    hipEvent_t ready = nullptr;             // the current window has arrived in HBM
+    bool host_scan = false, done = false, fresh = false;
+    int cur = 1;
+    uint32_t n = 0, k = 0, max_len = 0;     // records in the current window, of which k have been paired
+    uint32_t remaining() const { return n - k; }
+    ~MateWindows() {
+        for (hipEvent_t e : used) if (e) (void)hipEventDestroy(e);
+        if (ready) (void)hipEventDestroy(ready);
     }
 };
 
-void count_paired_text(scg_plan* P, scg::TextSource& src1, scg::TextSource& src2) {
-    DeviceGuard g(P->device);
-    scg::TextSource* src[2] = {&src1, &src2};
-    const size_t window = std::max(scan_window_bytes(src1.size_hint()), scan_window_bytes(src2.size_hint()));
-    std::unique_ptr<ScanSlot> slot[2][2];
-    for (int m = 0; m < 2; ++m) for (int k = 0; k < 2; ++k) { slot[m][k] = slot_pool().take(P->device, window); slot[m][k]->plan = P; }
-    struct Return {
-        std::unique_ptr<ScanSlot> (&s)[2][2];
-        bool ok = false;
-        ~Return() { if (ok) for (auto& row : s) for (auto& x : row) if (x) slot_pool().give(std::move(x)); }
-    } ret{slot};
-    MateQueue q[2];
-    q[0].init(window); q[1].init(window);
-    hipStream_t compute = nullptr;
-    HIP_CHECK(hipStreamCreateWithFlags(&compute, hipStreamNonBlocking));
-    struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); } } sg{compute};
-    bool done[2] = {false, false};
-    for (size_t round = 0; !(done[0] && done[1]); ++round) {
-        // advance the mate(s) that are not ahead
-        bool fresh[2] = {false, false};
-        for (int m = 0; m < 2; ++m) {
-            if (done[m] || (q[m].n > q[1 - m].n && !done[1 - m])) continue;
-            ScanSlot& s = *slot[m][round & 1];
-            if (s.busy) { HIP_CHECK(hipStreamSynchronize(compute)); s.busy = false; }     // its sequences have been appended
-            const size_t bytes = src[m]->next(s.text.as<char>(), s.cap);
-            if (src[m]->unusual()) throw UnusualInput();
-            if (bytes == 0) { done[m] = true; continue; }
-            HIP_CHECK(hipMemcpyAsync(s.d_text.p, s.text.p, bytes, hipMemcpyHostToDevice, s.stream));
-            HIP_CHECK(scg::launch_text_scan(s.d_text.as<char>(), bytes, s.B, s.stream));
-            HIP_CHECK(hipMemcpyAsync(s.h_result.p, s.d_result.p, sizeof(scg::TextScanResult), hipMemcpyDeviceToHost, s.stream));
-            fresh[m] = true;
+class PairedPipeline {
+public:
+    PairedPipeline(int dev, scg::TextSource& src1, scg::TextSource& src2)
+        : device(dev), window(std::max(scan_window_bytes(src1.size_hint()), scan_window_bytes(src2.size_hint()))) {
+        DeviceGuard g(device);
+        mate[0].src = &src1; mate[1].src = &src2;
+        HIP_CHECK(hipStreamCreateWithFlags(&compute, hipStreamNonBlocking));
+        for (auto& m : mate) {
+            m.host_scan = m.src->parses() && host_scan_enabled();
+            for (int k = 0; k < 2; ++k) {
+                m.slot[k] = slot_pool().take(device, window);
+                HIP_CHECK(hipEventCreateWithFlags(&m.used[k], hipEventDisableTiming));
+            }
+            HIP_CHECK(hipEventCreateWithFlags(&m.ready, hipEventDisableTiming));
         }
-        for (int m = 0; m < 2; ++m) {
-            if (!fresh[m]) continue;
-            ScanSlot& s = *slot[m][round & 1];
-            HIP_CHECK(hipStreamSynchronize(s.stream));
-            const scg::TextScanResult r = *s.h_result.as<scg::TextScanResult>();
-            if (r.flags) throw UnusualInput();
-            if (q[m].bytes + r.seq_bytes > q[m].cap_bytes || q[m].n + r.n_records > q[m].cap_reads) throw UnusualInput();   // very lopsided files: host readers
-            // append to the mate's queue (the queue's offsets carry on from its current end)
-            if (r.seq_bytes) HIP_CHECK(hipMemcpyAsync(q[m].seqs.as<char>() + q[m].bytes, s.B.seqs, r.seq_bytes, hipMemcpyDeviceToDevice, compute));
-            HIP_CHECK(scg::launch_rebase_offsets(q[m].offs.as<uint32_t>() + q[m].n, s.B.offsets, r.n_records + 1, q[m].bytes, 0, compute));
-            q[m].n += r.n_records;
-            q[m].bytes += static_cast<uint32_t>(r.seq_bytes);
-            q[m].max_len = std::max(q[m].max_len, r.max_len);
-            s.busy = true;
+        tr.mark("  scan slots (pinned + HBM)");
+    }
+    ~PairedPipeline() {
+        int prev = -1;
+        if (hipGetDevice(&prev) == hipSuccess && prev != device) (void)hipSetDevice(device); else prev = -1;
+        if (compute) { (void)hipStreamSynchronize(compute); (void)hipStreamDestroy(compute); }
+        for (auto& m : mate) for (auto& s : m.slot) {
+            if (!s) continue;
+            (void)hipStreamSynchronize(s->stream);
+            s->busy = false; s->pending = false;
+            if (ok) slot_pool().give(std::move(s));
         }
-        for (int m = 0; m < 2; ++m) {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+
+    // The first window of each file on its way (no plan needed yet).
+    void start() {
+        DeviceGuard g(device);
+        advance();
+        advanced = true;
+    }
+
+    void run(scg_plan* P) {
+        DeviceGuard g(device);
+        for (;;) {
+            if (advanced) advanced = false; else advance();
+            for (auto& m : mate) {
+                if (!m.fresh) continue;                               // device scan: the record count comes back from the card
+                m.fresh = false;
+                ScanSlot& s = *m.slot[m.cur];
+                const auto w0 = std::chrono::steady_clock::now();
+                HIP_CHECK(hipStreamSynchronize(s.stream));
+                t_wait += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
+                const scg::TextScanResult r = *s.h_result.as<scg::TextScanResult>();
+                if (r.flags) throw UnusualInput();
+                m.n = r.n_records;
+                m.max_len = r.max_len;
+            }
             // one file is exhausted and fully paired while the other still holds reads (process_data.hpp:284-285)
-            if (done[1 - m] && q[1 - m].n == 0 && q[m].n > 0) throw Error(SCG_ERR_IO, "different number of reads in paired FASTQ files");
-        }
-        const uint32_t np = std::min(q[0].n, q[1].n);
-        if (np) {
-            const int32_t max_len = static_cast<int32_t>(std::min<uint32_t>(std::max(q[0].max_len, q[1].max_len), 1u << 30));
-            launch_batch_paired(P, make_reads(q[0].seqs.as<char>(), q[0].offs.as<uint32_t>(), 0, max_len),
-                                make_reads(q[1].seqs.as<char>(), q[1].offs.as<uint32_t>(), 0, max_len), static_cast<int64_t>(np), compute);
-            for (int m = 0; m < 2; ++m) {
-                const uint32_t rest = q[m].n - np;
-                if (rest == 0) { q[m].n = 0; q[m].bytes = 0; continue; }
-                // the reads beyond the counted prefix move to the front (through a scratch copy: the ranges may overlap);
-                // the byte offset of read np is known on the device only, so the offsets are re-based there
-                HIP_CHECK(hipStreamSynchronize(compute));
-                uint32_t first = 0;
-                HIP_CHECK(hipMemcpy(&first, q[m].offs.as<uint32_t>() + np, sizeof(first), hipMemcpyDeviceToHost));
-                const uint32_t tail = q[m].bytes - first;
-                if (tail) HIP_CHECK(hipMemcpyAsync(q[m].tmp_seqs.p, q[m].seqs.as<char>() + first, tail, hipMemcpyDeviceToDevice, compute));
-                HIP_CHECK(scg::launch_rebase_offsets(q[m].tmp_offs.as<uint32_t>(), q[m].offs.as<uint32_t>() + np, rest + 1, 0, first, compute));
-                if (tail) HIP_CHECK(hipMemcpyAsync(q[m].seqs.p, q[m].tmp_seqs.p, tail, hipMemcpyDeviceToDevice, compute));
-                HIP_CHECK(hipMemcpyAsync(q[m].offs.p, q[m].tmp_offs.p, (rest + 1) * sizeof(uint32_t), hipMemcpyDeviceToDevice, compute));
-                q[m].n = rest;
-                q[m].bytes = tail;
+            for (int i = 0; i < 2; ++i) {
+                if (mate[i].done && mate[i].remaining() == 0 && mate[1 - i].remaining() > 0) {
+                    throw Error(SCG_ERR_IO, "different number of reads in paired FASTQ files");
+                }
+            }
+            if (mate[0].done && mate[1].done) break;
+            const uint32_t np = std::min(mate[0].remaining(), mate[1].remaining());
+            if (np == 0) continue;
+            const int32_t max_len = static_cast<int32_t>(std::min<uint32_t>(std::max(mate[0].max_len, mate[1].max_len), 1u << 30));
+            ScgReads R[2];
+            for (int i = 0; i < 2; ++i) {
+                MateWindows& m = mate[i];
+                const ScanSlot& s = *m.slot[m.cur];
+                HIP_CHECK(hipStreamWaitEvent(compute, m.ready, 0));
+                R[i] = make_reads(s.B.seqs, s.B.offsets + m.k, 0, max_len);
+            }
+            launch_batch_paired(P, R[0], R[1], static_cast<int64_t>(np), compute);
+            for (auto& m : mate) {
+                m.k += np;
+                HIP_CHECK(hipEventRecord(m.used[m.cur], compute));
             }
         }
+        HIP_CHECK(hipStreamSynchronize(compute));
+        ok = true;
+        if (tr.on) std::fprintf(stderr, "[scg]   paired windows of %zu MB: host fill %.2f ms, waiting for the device %.2f ms\n", window >> 20, t_fill, t_wait);
+        tr.mark("  windows");
     }
-    HIP_CHECK(hipStreamSynchronize(compute));
-    for (auto& row : slot) for (auto& x : row) { HIP_CHECK(hipStreamSynchronize(x->stream)); x->busy = false; x->pending = false; }
-    ret.ok = true;
-    if (q[0].n != q[1].n) throw Error(SCG_ERR_IO, "different number of reads in paired FASTQ files");   // process_data.hpp:284-285
-}
+
+private:
+    int device;
+    size_t window;
+    MateWindows mate[2];
+    hipStream_t compute = nullptr;
+    bool ok = false, advanced = false;
+    Trace tr;
+    double t_fill = 0, t_wait = 0;
+
+    // A mate whose window is used up takes its next one.
+    void advance() {
+        for (auto& m : mate) {
+            m.fresh = false;
+            if (m.done || m.remaining() > 0) continue;
+            m.cur ^= 1;
+            ScanSlot& s = *m.slot[m.cur];
+            const auto w0 = std::chrono::steady_clock::now();
+            HIP_CHECK(hipEventSynchronize(m.used[m.cur]));        // its previous content is no longer being read
+            const auto f0 = std::chrono::steady_clock::now();
+            t_wait += std::chrono::duration<double, std::milli>(f0 - w0).count();
+            scg::ParsedWindow w;
+            const size_t bytes = m.host_scan ? m.src->next_parsed(s.text.as<char>(), s.cap, s.h_offsets.as<uint32_t>(), s.B.cap_records + 1, w)
+                                             : m.src->next(s.text.as<char>(), s.cap);
+            t_fill += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - f0).count();
+            if (m.src->unusual()) throw UnusualInput();
+            m.n = m.k = 0;
+            if (bytes == 0) { m.done = true; continue; }
+            if (m.host_scan) {
+                m.n = enqueue_gather(s, w);
+                m.max_len = w.max_len;
+            } else {
+                HIP_CHECK(hipMemcpyAsync(s.d_text.p, s.text.p, bytes, hipMemcpyHostToDevice, s.stream));
+                HIP_CHECK(scg::launch_text_scan(s.d_text.as<char>(), bytes, s.B, s.stream));
+                HIP_CHECK(hipMemcpyAsync(s.h_result.p, s.d_result.p, sizeof(scg::TextScanResult), hipMemcpyDeviceToHost, s.stream));
+                m.fresh = true;
+            }
+            HIP_CHECK(hipEventRecord(m.ready, s.stream));
+        }
+    }
+};
 
 void reset_plan(scg_plan* P) {
     DeviceGuard g(P->device);
@@ -1528,20 +1578,7 @@ void append_reads(scg::ReadBatch& dst, const scg::ReadBatch& src, int64_t from, 
 // multi-threaded reader, each file on its own; the two read streams are re-cut into batches of
 // equal read counts (pair i = read i of both files).  gzip input or anything unusual falls back to
 // the sequential readers in lock-step.  Unequal read counts => the reference's error.
-void count_paired_files(scg_plan* P, const char* path1, const char* path2, scg::FastqStream& fq1, scg::FastqStream& fq2, int nthreads) {
-    if (device_scan_enabled()) {
-        // ordinary files: raw text to the GPU, records found and paired there; anything else: the host readers below
-        bool done = false;
-        try {
-            const int threads = scg::default_host_threads(nthreads);
-            std::unique_ptr<scg::TextSource> s1 = scg::TextSource::open(path1, threads), s2 = scg::TextSource::open(path2, threads);
-            count_paired_text(P, *s1, *s2);
-            done = true;
-        } catch (const UnusualInput&) {
-            reset_plan(P);
-        }
-        if (done) return;
-    }
+void count_paired_host(scg_plan* P, const char* path1, const char* path2, scg::FastqStream& fq1, scg::FastqStream& fq2, int nthreads) {
     Stager st;
     auto launch_pair = [&](const scg::ReadBatch& x, const scg::ReadBatch& y) {
         auto& s = st.acquire();
@@ -1603,6 +1640,75 @@ void count_paired_files(scg_plan* P, const char* path1, const char* path2, scg::
         launch_pair(b1, b2);
     }
     st.drain();
+}
+
+void count_paired_files(scg_plan* P, const char* path1, const char* path2, scg::FastqStream& fq1, scg::FastqStream& fq2, int nthreads) {
+    if (device_scan_enabled()) {
+        // ordinary files: windows of sequences paired on the device (PairedPipeline); anything else: the host readers
+        bool done = false;
+        try {
+            const int threads = scg::default_host_threads(nthreads);
+            std::unique_ptr<scg::TextSource> s1 = scg::TextSource::open(path1, threads), s2 = scg::TextSource::open(path2, threads);
+            PairedPipeline pipe(P->device, *s1, *s2);
+            pipe.run(P);
+            done = true;
+        } catch (const UnusualInput&) {
+            reset_plan(P);
+        }
+        if (done) return;
+    }
+    count_paired_host(P, path1, path2, fq1, fq2, nthreads);
+}
+
+// One pair of files, one call: as compile_and_count_single_end, the templates and libraries are compiled on a second
+// thread while the first window of each file is read and sent on its way.
+template<class Compile>
+std::unique_ptr<scg_plan> compile_and_count_paired(const char* path1, const char* path2, scg::FastqStream& fq1, scg::FastqStream& fq2, int nthreads,
+                                                   Compile compile) {
+    Trace tr;
+    std::unique_ptr<scg_plan> P;
+    std::exception_ptr compile_err, early;
+    std::thread th([&] {
+        try { P = compile(); } catch (...) { compile_err = std::current_exception(); }
+    });
+    int device = -1;
+    std::unique_ptr<scg::TextSource> s1, s2;
+    std::unique_ptr<PairedPipeline> pipe;
+    try {
+        device = resolve_device(-1);
+        if (device_scan_enabled()) {
+            const int threads = scg::default_host_threads(nthreads);
+            s1 = scg::TextSource::open(path1, threads);
+            s2 = scg::TextSource::open(path2, threads);
+            pipe.reset(new PairedPipeline(device, *s1, *s2));
+            pipe->start();
+        }
+    } catch (const UnusualInput&) {
+        pipe.reset();
+    } catch (...) {
+        early = std::current_exception();
+        pipe.reset();
+    }
+    th.join();
+    if (compile_err) std::rethrow_exception(compile_err);
+    if (early) std::rethrow_exception(early);
+    tr.mark("compile + first windows");
+    P->to_device(device);
+    DeviceGuard g(P->device);
+    tr.mark("upload to device");
+    bool done = false;
+    if (pipe) {
+        try {
+            pipe->run(P.get());
+            done = true;
+        } catch (const UnusualInput&) {
+            reset_plan(P.get());
+        }
+        pipe.reset();
+    }
+    if (!done) count_paired_host(P.get(), path1, path2, fq1, fq2, nthreads);
+    tr.mark("count files");
+    return P;
 }
 
 } // namespace
@@ -1929,10 +2035,10 @@ int scg_count_dual_barcodes(const char* path1, const char* constant1, int revers
         if (diagnostics) {
             throw Error(SCG_ERR_INVALID, "diagnostics requested: call scg_count_dual_barcodes_diagnostics, which returns the extra outputs");
         }
-        auto P = compile_dual(constant1, reverse1, mismatches1, pool1, constant2, reverse2, mismatches2, pool2, n_pool, randomized, use_first);
-        P->to_device(-1);
+        auto P = compile_and_count_paired(path1, path2, fq1, fq2, nthreads, [&] {
+            return compile_dual(constant1, reverse1, mismatches1, pool1, constant2, reverse2, mismatches2, pool2, n_pool, randomized, use_first);
+        });
         DeviceGuard g(P->device);
-        count_paired_files(P.get(), path1, path2, fq1, fq2, nthreads);
         read_counters(P.get(), counts_out);
         *total_out = narrow_total(P->total);
     });
@@ -1951,10 +2057,10 @@ int scg_count_dual_barcodes_diagnostics(const char* path1, const char* constant1
         }
         scg::FastqStream fq1(path1);
         scg::FastqStream fq2(path2);
-        auto P = compile_dual(constant1, reverse1, mismatches1, pool1, constant2, reverse2, mismatches2, pool2, n_pool, randomized, use_first, 1);
-        P->to_device(-1);
+        auto P = compile_and_count_paired(path1, path2, fq1, fq2, nthreads, [&] {
+            return compile_dual(constant1, reverse1, mismatches1, pool1, constant2, reverse2, mismatches2, pool2, n_pool, randomized, use_first, 1);
+        });
         DeviceGuard g(P->device);
-        count_paired_files(P.get(), path1, path2, fq1, fq2, nthreads);
         std::vector<int32_t> all(static_cast<size_t>(P->n_counters) + 1);
         read_counters(P.get(), all.data());
         diagnostics_from_counters(P.get(), all, counts_out, invalid_indices_out, invalid_freq_out, k_out, barcode1_only_out, barcode2_only_out);
@@ -2103,11 +2209,11 @@ int scg_count_combo_barcodes_paired(const char* path1, const char* constant1, in
         }
         scg::FastqStream fq1(path1);                           // src/count_combo_barcodes_paired.cpp:75-79: readers first
         scg::FastqStream fq2(path2);
-        auto P = compile_paired_combo(constant1, reverse1, mismatches1, pool1, n_pool1, constant2, reverse2, mismatches2, pool2, n_pool2,
-                                      randomized, use_first);
-        P->to_device(-1);
+        auto P = compile_and_count_paired(path1, path2, fq1, fq2, nthreads, [&] {
+            return compile_paired_combo(constant1, reverse1, mismatches1, pool1, n_pool1, constant2, reverse2, mismatches2, pool2, n_pool2,
+                                        randomized, use_first);
+        });
         DeviceGuard g(P->device);
-        count_paired_files(P.get(), path1, path2, fq1, fq2, nthreads);
         std::vector<int32_t> all(static_cast<size_t>(P->n_counters) + 1);
         read_counters(P.get(), all.data());
         diagnostics_from_counters(P.get(), all, nullptr, indices_out, freq_out, k_out, barcode1_only_out, barcode2_only_out);

@@ -6,8 +6,6 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
-#include <chrono>
-#include <cstdio>
 #include <exception>
 #include <mutex>
 #include <thread>
@@ -352,7 +350,6 @@ void finish_index(HostIndex& X, const std::vector<uint64_t>& keys, const std::ve
 
 HostIndex build_index(const char* const* pool, int32_t n, int32_t len, int max_mm) {
     check_len(len);
-    auto T0 = std::chrono::steady_clock::now();
     int64_t total = count_expansions(pool, n, len);
     std::vector<uint64_t> hk;
     std::vector<int32_t> hv;
@@ -377,10 +374,7 @@ HostIndex build_index(const char* const* pool, int32_t n, int32_t len, int max_m
         });
     }
     HostIndex X;
-    auto T1 = std::chrono::steady_clock::now();
     finish_index(X, keys, vals, len, max_mm);
-    auto T2 = std::chrono::steady_clock::now();
-    if (std::getenv("SCG_TRACE_INDEX")) std::fprintf(stderr, "expansions %.2f ms, finish %.2f ms\n", std::chrono::duration<double, std::milli>(T1 - T0).count(), std::chrono::duration<double, std::milli>(T2 - T1).count());
     return X;
 }
 

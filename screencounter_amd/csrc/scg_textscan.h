@@ -40,10 +40,6 @@ size_t text_scan_padded(size_t n_bytes);    // device text buffers must be reada
 // a newline (the host appends one when the file lacks it, as the reference accepts a final record without it).
 hipError_t launch_text_scan(const char* d_text, size_t n_bytes, const TextScanBuffers& B, hipStream_t stream);
 
-// dst[i] = src[i] + add - sub, i < n: byte offsets re-based when sequences are appended to / shifted within a buffer
-// (dst and src must not overlap).
-hipError_t launch_rebase_offsets(uint32_t* dst, const uint32_t* src, uint32_t n, uint32_t add, uint32_t sub, hipStream_t stream);
-
 // Host-side record scan (scg_ingest.h): the sequences and offsets of a window lie in pinned host memory in segments,
 // one per host thread, the offsets of each relative to its own first sequence.  One kernel pulls them over the link
 // (zero-copy reads run at link speed, 56 GB/s, where sixteen hipMemcpyAsync calls of 4 MB reach 32-37 GB/s and cost the

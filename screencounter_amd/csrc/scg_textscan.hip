@@ -171,12 +171,6 @@ __global__ __launch_bounds__(TS_BLOCK) void compact_kernel(const char* __restric
     if (blockIdx.x == 0 && threadIdx.x == 0) res->seq_bytes = offsets[n_rec];
 }
 
-// dst[i] = src[i] + add - sub for i < n (re-basing byte offsets when sequences move between buffers).
-__global__ __launch_bounds__(TS_BLOCK) void rebase_kernel(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src, uint32_t n, uint32_t add, uint32_t sub) {
-    const uint32_t i = blockIdx.x * TS_BLOCK + threadIdx.x;
-    if (i < n) dst[i] = src[i] + add - sub;
-}
-
 // Tiles of 64 KB (sequence bytes) or 16 Ki offsets are dealt to the workgroups round-robin; the sources are pinned host
 // memory, read in 16-byte pieces whatever their alignment.
 constexpr uint32_t GATHER_TILE = 65536;
@@ -225,12 +219,6 @@ __global__ __launch_bounds__(TS_BLOCK) void gather_segments_kernel(char* __restr
 } // namespace
 
 namespace scg {
-
-hipError_t launch_rebase_offsets(uint32_t* dst, const uint32_t* src, uint32_t n, uint32_t add, uint32_t sub, hipStream_t stream) {
-    if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(rebase_kernel, dim3((n + TS_BLOCK - 1) / TS_BLOCK), dim3(TS_BLOCK), 0, stream, dst, src, n, add, sub);
-    return hipGetLastError();
-}
 
 hipError_t launch_gather_segments(char* seqs, uint32_t* offsets, const GatherSegments& G, hipStream_t stream) {
     if (G.n == 0 || G.n > 64) return hipErrorInvalidValue;

@@ -191,9 +191,10 @@ def test_multi_file_entries_equal_per_file_calls(sc, oracle, gpu, tmp_path, monk
         assert tot[c] == tt and np.array_equal(mat[:, c], cc)
 
 
-def test_paired_files_through_the_scan(sc, oracle, gpu, tmp_path, monkeypatch):
-    """Both mates shipped as raw text; their windows hold different numbers of records (names and read lengths differ), so
-    the device-side queues that bring the two streams into step are exercised; one mate is BGZF, the other plain."""
+def test_paired_files_through_the_scan(sc, oracle, gpu, tmp_path, monkeypatch, plain_scan):
+    """The windows of the two mates hold different numbers of records (names and read lengths differ), so the cursors that
+    bring the two streams into step on the device are exercised; mate 1 is plain (scanned by the host threads or the
+    device), mate 2 BGZF (always the device) or plain."""
     from screencounter_amd import _lib
     rng = random.Random(16)
     t1, t2 = "ACGTAC" + "-" * 10 + "TGCATG", "GGATCC" + "-" * 8 + "AAGCTT"
@@ -214,13 +215,16 @@ def test_paired_files_through_the_scan(sc, oracle, gpu, tmp_path, monkeypatch):
     open(p1, "wb").write(gen.fastq_text(r1, name_prefix="a_rather_long_read_name_"))
     p2 = str(tmp_path / "m2.fastq.gz")
     gen.write_bgzf(p2, gen.fastq_text(r2, trailing_newline=False), block=2500)
+    p2_plain = str(tmp_path / "m2.fastq")
+    open(p2_plain, "wb").write(gen.fastq_text(r2, trailing_newline=False))
     for kb in (None, 16, 64):
         if kb:
             monkeypatch.setenv("SCG_WINDOW_KB", str(kb))
         for first in (True, False):
             e, t = (exp, total) if first else oracle.count_dual(r1, r2, t1, False, 1, pool1, t2, False, 1, pool2, False, False)
-            got, n = sc.count_dual_barcodes(p1, t1, False, 1, pool1, p2, t2, False, 1, pool2, False, first, False, 4)
-            assert n == t == len(r1) and np.array_equal(got, e), (kb, first)
+            for second in (p2, p2_plain):
+                got, n = sc.count_dual_barcodes(p1, t1, False, 1, pool1, second, t2, False, 1, pool2, False, first, False, 4)
+                assert n == t == len(r1) and np.array_equal(got, e), (kb, first, second)
     # include.invalid = TRUE and randomized through the same pipeline
     d = oracle.count_dual_diag(r1, r2, t1, False, 1, pool1, t2, False, 1, pool2, True, True)
     counts, (idx, freq), tot, b1, b2 = sc.count_dual_barcodes(p1, t1, False, 1, pool1, p2, t2, False, 1, pool2, True, True, True, 4)
