@@ -882,12 +882,21 @@ struct ScanSlot {
     scg::TextScanResult host_result{};
     bool busy = false;         // work of an earlier window may still be running on the stream
 
-    void init(int device, size_t window) {
+    // device-side inflate (InflatePipeline) only:
+    DevBuf d_in, d_status;     // compressed members + their table; failure flags of the inflate / carry kernels
+    PinnedBuf h_status;
+    hipEvent_t scanned = nullptr, carried = nullptr;
+    size_t pinned_cap = 0;     // bytes of `text` (the pinned staging buffer): the window, or less when only compressed bytes pass through
+    uint32_t text_bytes = 0;   // text in d_text for the pending window
+    bool last = false;         // the pending window is the input's last
+
+    void init(int device, size_t window, size_t pinned_bytes) {
         plan_device = device;
         cap = window;
+        pinned_cap = pinned_bytes;
         DeviceGuard g(device);
         HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-        text.ensure(cap);
+        text.ensure(pinned_cap);
         h_result.ensure(sizeof(scg::TextScanResult));
         B.cap_blocks = scg::text_scan_blocks(cap) + 1;
         B.cap_lines = cap / 16 + 1024;              // lines shorter than 16 bytes on average: left to the sequential reader
@@ -906,11 +915,23 @@ struct ScanSlot {
         B.seqs = d_seqs.as<char>();
         B.result = d_result.as<scg::TextScanResult>();
     }
+    // The extras of the inflate pipeline, on first use.
+    void ensure_inflate() {
+        if (scanned) return;
+        DeviceGuard g(plan_device);
+        d_in.alloc(pinned_cap);
+        d_status.alloc(sizeof(uint32_t));
+        h_status.ensure(sizeof(uint32_t));
+        HIP_CHECK(hipEventCreateWithFlags(&scanned, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&carried, hipEventDisableTiming));
+    }
     ~ScanSlot() {
         if (stream) {
             int prev = -1;
             if (plan_device >= 0 && hipGetDevice(&prev) == hipSuccess && prev != plan_device) (void)hipSetDevice(plan_device); else prev = -1;
             (void)hipStreamSynchronize(stream);
+            if (scanned) (void)hipEventDestroy(scanned);
+            if (carried) (void)hipEventDestroy(carried);
             (void)hipStreamDestroy(stream);
             if (prev >= 0) (void)hipSetDevice(prev);
         }
@@ -956,11 +977,14 @@ size_t scan_window_bytes(uint64_t hint) {
 struct SlotPool {
     std::mutex mu;
     std::vector<std::unique_ptr<ScanSlot> > idle;
-    std::unique_ptr<ScanSlot> take(int device, size_t window) {
+    // pinned_bytes = 0: as much pinned staging as text (the raw-text and host-scan pipelines)
+    std::unique_ptr<ScanSlot> take(int device, size_t window, size_t pinned_bytes = 0) {
+        if (pinned_bytes == 0) pinned_bytes = window;
         {
             std::lock_guard<std::mutex> g(mu);
             for (size_t i = 0; i < idle.size(); ++i) {
-                if (idle[i]->plan_device == device && idle[i]->cap >= window && idle[i]->cap <= 2 * window + (size_t(8) << 20)) {
+                if (idle[i]->plan_device == device && idle[i]->cap >= window && idle[i]->cap <= 2 * window + (size_t(8) << 20) &&
+                    idle[i]->pinned_cap >= pinned_bytes) {
                     std::unique_ptr<ScanSlot> s = std::move(idle[i]);
                     idle.erase(idle.begin() + static_cast<long>(i));
                     s->plan = nullptr;
@@ -969,7 +993,7 @@ struct SlotPool {
             }
         }
         std::unique_ptr<ScanSlot> s(new ScanSlot);
-        s->init(device, window);
+        s->init(device, window, pinned_bytes);
         return s;
     }
     void give(std::unique_ptr<ScanSlot> s) {
@@ -1068,7 +1092,7 @@ private:
         if (bytes == 0) { ended = true; return; }
         if (host_scan) {
             const uint32_t rec = enqueue_gather(s, w);
-            s.host_result = scg::TextScanResult{0, rec, w.max_len, 0, w.seq_bytes};
+            s.host_result = scg::TextScanResult{0, rec, w.max_len, 0, w.seq_bytes, 0, 0};
             s.parsed = true;
             s.pending = true;
             ++filled;
@@ -1095,6 +1119,162 @@ private:
         if (r.n_records) {
             launch_batch(s.plan, make_reads(s.B.seqs, s.B.offsets, 0, static_cast<int32_t>(std::min<uint32_t>(r.max_len, 1u << 30))),
                          static_cast<int64_t>(r.n_records), s.stream);
+        }
+        s.busy = true;
+    }
+};
+
+bool device_inflate_enabled() {
+    const char* e = std::getenv("SCG_DEVICE_INFLATE");       // test hook: 0 inflates BGZF members on the host threads
+    return !(e && *e == '0');
+}
+
+// The single-end pipeline for BGZF input with the members inflated on the device (scg_inflate.hip).  Per window, on
+// the slot's stream: compressed members + their table -> HBM; inflate + CRC check into the text buffer behind a gap of
+// GAP bytes; then -- once the previous window has been scanned -- the gap receives that window's partial last record
+// (launch_carry_tail), the text is scanned for records (allow_tail) and the result comes back.  The inflate kernels of
+// up to three windows overlap; only the carry chains the windows.  One device.
+class InflatePipeline {
+public:
+    static constexpr size_t GAP = size_t(1) << 20;
+    InflatePipeline(scg::TextSource& source, int dev) : src(source), device(dev) {
+        // windows of 256 MB of text (4 000 members in flight per window), less for small inputs
+        size_t w = size_t(256) << 20;
+        if (const char* e = std::getenv("SCG_WINDOW_KB")) { const long kb = std::atol(e); if (kb > 0) w = static_cast<size_t>(kb) << 10; }
+        const uint64_t need = source.size_hint() + (source.size_hint() >> 4) + 4096;
+        if (need < w) w = static_cast<size_t>(need);
+        w = std::max<size_t>(w, std::getenv("SCG_WINDOW_KB") ? size_t(4) << 10 : scg::TextSource::min_capacity());
+        cap_text = w;
+        window = GAP + cap_text + 64;
+        cap_in = cap_text / 2 + (size_t(1) << 20);          // compressed bytes + member table of a window
+        for (int k = 0; k < 3; ++k) {
+            slots.push_back(slot_pool().take(device, window, cap_in));
+            slots.back()->ensure_inflate();
+        }
+        tr.mark("  scan slots (pinned + HBM)");
+    }
+    ~InflatePipeline() {
+        for (auto& s : slots) {
+            if (!s) continue;
+            DeviceGuard g(s->plan_device);
+            (void)hipStreamSynchronize(s->stream);
+            s->busy = false; s->pending = false;
+            if (ok) slot_pool().give(std::move(s));
+        }
+    }
+
+    void start() { if (!ended && filled == 0) fill_next(); }
+
+    void run(scg_plan* plan) {
+        for (auto& s : slots) s->plan = plan;
+        const size_t lag = 2;
+        while (!ended) {
+            fill_next();
+            if (filled > lag && finished < filled - lag) finish_next();
+        }
+        while (finished < filled) finish_next();
+        for (auto& s : slots) {
+            DeviceGuard g(s->plan_device);
+            HIP_CHECK(hipStreamSynchronize(s->stream));
+            s->busy = false;
+        }
+        ok = true;
+        if (tr.on) {
+            std::fprintf(stderr, "[scg]   windows of %zu MB (device inflate): host fill %.2f ms, waiting for the device %.2f ms, for free slots %.2f ms\n",
+                         cap_text >> 20, t_fill, t_finish, t_busy);
+        }
+        tr.mark("  windows");
+    }
+
+private:
+    scg::TextSource& src;
+    int device;
+    size_t cap_text = 0, window = 0, cap_in = 0;
+    std::vector<std::unique_ptr<ScanSlot> > slots;
+    std::vector<scg::CompressedMember> members;
+    size_t filled = 0, finished = 0;
+    bool ended = false, ok = false;
+    Trace tr;
+    double t_fill = 0, t_finish = 0, t_busy = 0;
+
+    void fill_next() {
+        ScanSlot& s = *slots[filled % slots.size()];
+        DeviceGuard g(device);
+        if (s.pending) finish_next();
+        const auto b0 = std::chrono::steady_clock::now();
+        if (s.busy) { HIP_CHECK(hipStreamSynchronize(s.stream)); s.busy = false; }
+        const auto f0 = std::chrono::steady_clock::now();
+        t_busy += std::chrono::duration<double, std::milli>(f0 - b0).count();
+        // staging: [member table | payloads]; the table's size is not known before the members are, so it takes the
+        // end of the buffer's first part: room for one member per 32 bytes of compressed input is never short
+        const size_t slack = scg::inflate_input_slack();
+        const size_t table_cap = (cap_in / 32 / sizeof(scg::InflateMember)) * sizeof(scg::InflateMember);
+        char* const stage = s.text.as<char>();
+        size_t text_bytes = 0;
+        bool last = false;
+        const size_t in_bytes = src.next_members(stage + table_cap, cap_in - table_cap, slack, cap_text, members, text_bytes, last);
+        if (src.unusual()) throw UnusualInput();
+        if (in_bytes == 0) { ended = true; return; }
+        if (members.size() * sizeof(scg::InflateMember) > table_cap) throw UnusualInput();        // (members of < 32 bytes: not a real file)
+        static_assert(sizeof(scg::InflateMember) == sizeof(scg::CompressedMember), "same layout");
+        scg::InflateMember* table = reinterpret_cast<scg::InflateMember*>(stage);
+        for (size_t i = 0; i < members.size(); ++i) {
+            table[i].in_off = static_cast<uint32_t>(table_cap) + members[i].in_off;
+            table[i].in_len = members[i].in_len;
+            table[i].out_off = static_cast<uint32_t>(GAP) + members[i].out_off;
+            table[i].out_len = members[i].out_len;
+            table[i].crc = members[i].crc;
+        }
+        t_fill += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - f0).count();
+        const uint32_t n = static_cast<uint32_t>(members.size());
+        const ScanSlot* prev = filled ? slots[(filled - 1) % slots.size()].get() : nullptr;
+        ScanSlot& next = *slots[(filled + 1) % slots.size()];        // the window after this slot's previous one read its tail from here
+        HIP_CHECK(hipStreamWaitEvent(s.stream, next.carried, 0));
+        HIP_CHECK(hipMemsetAsync(s.d_status.p, 0, sizeof(uint32_t), s.stream));
+        HIP_CHECK(hipMemcpyAsync(s.d_in.p, stage, n * sizeof(scg::InflateMember), hipMemcpyHostToDevice, s.stream));
+        HIP_CHECK(hipMemcpyAsync(s.d_in.as<char>() + table_cap, stage + table_cap, in_bytes, hipMemcpyHostToDevice, s.stream));
+        HIP_CHECK(scg::launch_inflate_members(s.d_in.as<uint8_t>(), s.d_in.as<scg::InflateMember>(), n, s.d_text.as<char>(), s.d_status.as<uint32_t>(), s.stream));
+        s.text_bytes = static_cast<uint32_t>(GAP + text_bytes);
+        if (last) {
+            // the reference accepts a final record without its newline: one is appended (a second one is harmless, see finish_next)
+            HIP_CHECK(hipMemsetAsync(s.d_text.as<char>() + s.text_bytes, '\n', 1, s.stream));
+            s.text_bytes += 1;
+        }
+        s.last = last;
+        if (prev) HIP_CHECK(hipStreamWaitEvent(s.stream, prev->scanned, 0));
+        HIP_CHECK(scg::launch_carry_tail(prev ? prev->d_text.as<char>() : nullptr, prev ? prev->B.result : nullptr, prev ? prev->text_bytes : 0u,
+                                         s.d_text.as<char>(), static_cast<uint32_t>(GAP), s.d_status.as<uint32_t>(), s.stream));
+        HIP_CHECK(hipEventRecord(s.carried, s.stream));
+        HIP_CHECK(scg::launch_text_scan(s.d_text.as<char>(), s.text_bytes, s.B, s.stream, true));
+        HIP_CHECK(hipEventRecord(s.scanned, s.stream));
+        HIP_CHECK(hipMemcpyAsync(s.h_result.p, s.d_result.p, sizeof(scg::TextScanResult), hipMemcpyDeviceToHost, s.stream));
+        HIP_CHECK(hipMemcpyAsync(s.h_status.p, s.d_status.p, sizeof(uint32_t), hipMemcpyDeviceToHost, s.stream));
+        s.parsed = false;
+        s.pending = true;
+        ++filled;
+        if (last) ended = true;
+    }
+
+    void finish_next() {
+        ScanSlot& s = *slots[finished % slots.size()];
+        const auto f1 = std::chrono::steady_clock::now();
+        DeviceGuard g(device);
+        HIP_CHECK(hipStreamSynchronize(s.stream));
+        t_finish += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - f1).count();
+        s.pending = false;
+        ++finished;
+        // a member zlib has to look at (corrupt, or in a form this decoder declines), a record longer than the gap,
+        // anything but ordinary records: the host paths redo the file
+        if (*s.h_status.as<uint32_t>()) throw UnusualInput();
+        const scg::TextScanResult r = *s.h_result.as<scg::TextScanResult>();
+        if (r.flags || r.n_records == 0) throw UnusualInput();
+        if (s.last) {
+            // behind the last whole record: nothing, or the newline appended above
+            if (s.text_bytes - r.cut > 1) throw UnusualInput();
+        }
+        if (r.n_records > 1) {                                       // record 0 is the gap's dummy
+            launch_batch(s.plan, make_reads(s.B.seqs, s.B.offsets + 1, 0, static_cast<int32_t>(std::min<uint32_t>(r.max_len, 1u << 30))),
+                         static_cast<int64_t>(r.n_records - 1), s.stream);
         }
         s.busy = true;
     }
@@ -1271,6 +1451,20 @@ bool device_scan_enabled() {
 void count_single_end(const std::vector<scg_plan*>& plans, const char* path, scg::FastqStream& fq, int nthreads) {
     if (device_scan_enabled()) {
         bool done = false;
+        if (device_inflate_enabled()) {
+            // BGZF: members inflated on the device; whatever that declines gets the host threads' zlib next
+            try {
+                std::unique_ptr<scg::TextSource> src = scg::TextSource::open(path, scg::default_host_threads(nthreads));
+                if (src->has_members()) {
+                    InflatePipeline pipe(*src, plans[0]->device);
+                    pipe.run(plans[0]);
+                    done = true;
+                }
+            } catch (const UnusualInput&) {
+                for (scg_plan* P : plans) reset_plan(P);
+            }
+            if (done) return;
+        }
         try {
             std::unique_ptr<scg::TextSource> src = scg::TextSource::open(path, scg::default_host_threads(nthreads));
             count_text_stream(plans, *src);
@@ -1473,18 +1667,27 @@ std::unique_ptr<PlanSet> compile_and_count_single_end(const char* path, scg::Fas
     std::vector<int> devices;
     std::unique_ptr<scg::TextSource> src;
     std::unique_ptr<TextPipeline> pipe;
+    std::unique_ptr<InflatePipeline> inflate;
     try {
         devices = devices_for_input(text_bytes_hint(path));
         if (device_scan_enabled()) {
             src = scg::TextSource::open(path, scg::default_host_threads(nthreads));
-            pipe.reset(new TextPipeline(*src, devices));
-            pipe->start();
+            if (src->has_members() && device_inflate_enabled()) {
+                devices.resize(1);                     // the windows of a BGZF file are chained by their partial records
+                inflate.reset(new InflatePipeline(*src, devices[0]));
+                inflate->start();
+            } else {
+                pipe.reset(new TextPipeline(*src, devices));
+                pipe->start();
+            }
         }
     } catch (const UnusualInput&) {
         pipe.reset();
+        inflate.reset();
     } catch (...) {
         early = std::current_exception();
         pipe.reset();
+        inflate.reset();
     }
     th.join();
     if (compile_err) std::rethrow_exception(compile_err);
@@ -1493,6 +1696,24 @@ std::unique_ptr<PlanSet> compile_and_count_single_end(const char* path, scg::Fas
     std::unique_ptr<PlanSet> set(new PlanSet(std::move(compiled), devices));
     tr.mark("upload to device(s)");
     bool done = false;
+    if (inflate) {
+        try {
+            inflate->run(set->first());
+            done = true;
+        } catch (const UnusualInput&) {
+            set->reset();
+        }
+        inflate.reset();
+        if (!done) {
+            // second chance for BGZF: members inflated by the host threads' zlib, records scanned on the device
+            try {
+                src = scg::TextSource::open(path, scg::default_host_threads(nthreads));
+                pipe.reset(new TextPipeline(*src, devices));
+            } catch (const UnusualInput&) {
+                pipe.reset();
+            }
+        }
+    }
     if (pipe) {
         try {
             pipe->run(set->all());

@@ -382,6 +382,51 @@ public:
         BgzfMember m;
         return g.size && bgzf_member(g.data, g.size, 0, m);
     }
+    bool has_members() const override { return true; }
+    size_t next_members(char* staging, size_t cap, size_t slack, size_t cap_text, std::vector<CompressedMember>& members, size_t& text_bytes,
+                        bool& last) override {
+        members.clear();
+        text_bytes = 0;
+        last = false;
+        if (odd || off >= f.size) return 0;
+        std::vector<size_t> from;          // payload offsets within the file
+        size_t in = 0, out = 0;
+        while (off < f.size) {
+            BgzfMember m;
+            if (!bgzf_member(f.data, f.size, off, m)) { odd = true; return 0; }
+            const unsigned char* p = reinterpret_cast<const unsigned char*>(f.data) + off;
+            const size_t xlen = p[10] | (static_cast<size_t>(p[11]) << 8);
+            // FEXTRA only (what bgzip writes): names, comments and header CRCs are for zlib to judge
+            if (p[3] != 4 || m.csize < 12 + xlen + 8) { odd = true; return 0; }
+            const size_t payload = m.csize - 12 - xlen - 8;
+            if (in + payload + slack > cap || out + m.isize > cap_text) break;
+            const unsigned char* t = p + m.csize - 8;
+            CompressedMember c;
+            c.in_off = static_cast<uint32_t>(in);
+            c.in_len = static_cast<uint32_t>(payload);
+            c.out_off = static_cast<uint32_t>(out);
+            c.out_len = m.isize;
+            c.crc = t[0] | (static_cast<uint32_t>(t[1]) << 8) | (static_cast<uint32_t>(t[2]) << 16) | (static_cast<uint32_t>(t[3]) << 24);
+            members.push_back(c);
+            from.push_back(off + 12 + xlen);
+            in += payload;
+            out += m.isize;
+            off += m.csize;
+        }
+        if (members.empty()) { odd = true; return 0; }            // one member larger than a window
+        last = off >= f.size;
+        text_bytes = out;
+        // the payloads, back to back (a fifth of the text: the copy is cheap next to inflating it)
+        const int n = static_cast<int>(members.size());
+        const int parts = std::min(n, threads * 4);
+        pool.run(parts, [&](int i) {
+            for (int k = static_cast<int>(static_cast<int64_t>(n) * i / parts), e = static_cast<int>(static_cast<int64_t>(n) * (i + 1) / parts); k < e; ++k) {
+                std::memcpy(staging + members[k].in_off, f.data + from[k], members[k].in_len);
+            }
+        });
+        std::memset(staging + in, 0, slack);
+        return in + slack;
+    }
 protected:
     size_t fill(char* dst, size_t have, size_t cap) override {
         std::vector<BgzfMember> batch;

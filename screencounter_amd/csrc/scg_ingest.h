@@ -13,6 +13,7 @@
 #include <cstdint>
 #include <functional>
 #include <memory>
+#include <vector>
 
 namespace scg {
 
@@ -51,6 +52,14 @@ struct ParsedWindow {
     uint32_t max_len = 0;
 };
 
+// One gzip member of a batch handed to the device inflater (TextSource::next_members; the layout of
+// scg::InflateMember in scg_textscan.h).
+struct CompressedMember {
+    uint32_t in_off, in_len;      // raw DEFLATE payload within the staging buffer
+    uint32_t out_off, out_len;    // its text within the window (relative to the window's first inflated byte)
+    uint32_t crc;
+};
+
 class TextSource {
 public:
     // plain file (mapped), BGZF / blocked gzip (members inflated in parallel) or any other gzip (one inflate stream)
@@ -67,6 +76,13 @@ public:
     // bytes consumed, 0 at the end of the input; sets unusual() for anything but ordinary 4-line records.
     virtual bool parses() const { return false; }
     virtual size_t next_parsed(char*, size_t, uint32_t*, size_t, ParsedWindow&) { return 0; }
+    // BGZF: the members can be inflated independently, which the device does better than sixteen host threads.  The
+    // payloads of the next members -- as many as fit `cap` staging bytes (incl. `slack` readable bytes behind the last)
+    // and `cap_text` bytes of text -- are copied to staging[0 ...) back to back and described in `members`; `last` says
+    // that the input ends with them.  Returns the staging bytes used, 0 at the end of the input (or with unusual()
+    // set: a member in a form only zlib should judge).
+    virtual bool has_members() const { return false; }
+    virtual size_t next_members(char*, size_t, size_t, size_t, std::vector<CompressedMember>&, size_t&, bool&) { return 0; }
     // The text could not be cut at a verified record boundary: the caller must redo the file sequentially.
     bool unusual() const { return odd; }
     // An upper estimate of the text bytes still to come (window sizing only).

@@ -21,6 +21,8 @@ struct TextScanResult {
     uint32_t max_len;      // longest sequence of the window
     uint32_t flags;        // TEXTSCAN_*: non-zero => the host falls back to the sequential reference-exact reader
     uint64_t seq_bytes;    // total sequence bytes (= offsets[n_records])
+    uint32_t cut;          // allow_tail scans: the byte behind the last whole record (everything from there on is carried over)
+    uint32_t reserved;
 };
 
 // Device scratch and outputs of one window.
@@ -38,7 +40,9 @@ size_t text_scan_padded(size_t n_bytes);    // device text buffers must be reada
 
 // Asynchronous on `stream`.  The text must start at a record start; the last byte of the final window of a file must be
 // a newline (the host appends one when the file lacks it, as the reference accepts a final record without it).
-hipError_t launch_text_scan(const char* d_text, size_t n_bytes, const TextScanBuffers& B, hipStream_t stream);
+// allow_tail: the text may end anywhere (windows cut at gzip member boundaries): the records are the whole groups of
+// four lines, and `cut` says where the rest begins.
+hipError_t launch_text_scan(const char* d_text, size_t n_bytes, const TextScanBuffers& B, hipStream_t stream, bool allow_tail = false);
 
 // Host-side record scan (scg_ingest.h): the sequences and offsets of a window lie in pinned host memory in segments,
 // one per host thread, the offsets of each relative to its own first sequence.  One kernel pulls them over the link
@@ -54,6 +58,26 @@ struct GatherSegments {
     uint32_t first[65];
 };
 hipError_t launch_gather_segments(char* seqs, uint32_t* offsets, const GatherSegments& G, hipStream_t stream);
+
+// ---- BGZF members inflated on the device (scg_inflate.hip) ----
+struct InflateMember {
+    uint32_t in_off, in_len;      // the member's raw DEFLATE payload within the compressed buffer
+    uint32_t out_off, out_len;    // where its text goes within the window's text buffer, and how much (ISIZE)
+    uint32_t crc;                 // CRC-32 of the text (gzip trailer)
+};
+enum : uint32_t {
+    INFLATE_STATUS_BAD = 1,       // some member is not a valid DEFLATE stream of the announced sizes
+    INFLATE_STATUS_CRC = 2,       // some member's text does not match its CRC-32
+    INFLATE_STATUS_TAIL = 4,      // the partial record carried over from the previous window does not fit the gap
+};
+struct CrcPowers { uint32_t x2n[32]; };       // x^(2^k) mod the CRC-32 polynomial
+size_t inflate_input_slack();                 // bytes that must be readable behind the compressed buffer's last payload
+// Inflates members[0 .. n) from d_in into d_text and checks their CRCs; failures are ORed into *d_status.
+hipError_t launch_inflate_members(const uint8_t* d_in, const InflateMember* d_members, uint32_t n, char* d_text, uint32_t* d_status, hipStream_t stream);
+// text[0 .. gap) = a dummy record with an empty sequence + the bytes of prev_text[0 .. prev_bytes) behind prev_result->cut
+// (prev_text == nullptr: the first window, nothing to carry).
+hipError_t launch_carry_tail(const char* prev_text, const TextScanResult* prev_result, uint32_t prev_bytes, char* text, uint32_t gap, uint32_t* d_status,
+                             hipStream_t stream);
 
 } // namespace scg
 

@@ -118,16 +118,17 @@ __global__ __launch_bounds__(TS_BLOCK) void newline_positions_kernel(const char*
 
 // One lane per record: structure checks, sequence length (written to lens[i], scanned into offsets afterwards).
 __global__ __launch_bounds__(TS_BLOCK) void records_kernel(const char* __restrict__ text, const uint32_t* __restrict__ nl, uint32_t cap_lines,
-                                                           uint32_t cap_records, uint32_t* __restrict__ lens, scg::TextScanResult* __restrict__ res) {
+                                                           uint32_t cap_records, uint32_t* __restrict__ lens, scg::TextScanResult* __restrict__ res, int allow_tail) {
     const uint32_t n_lines = res->n_lines;
     const uint32_t n_rec = n_lines / 4;
     const uint32_t i = blockIdx.x * TS_BLOCK + threadIdx.x;
     if (i == 0) {
         uint32_t f = 0;
-        if (n_lines % 4 != 0) f |= scg::TEXTSCAN_NOT_FOUR_LINES;
+        if (n_lines % 4 != 0 && !allow_tail) f |= scg::TEXTSCAN_NOT_FOUR_LINES;
         if (n_lines > cap_lines || n_rec > cap_records) f |= scg::TEXTSCAN_CAPACITY;
         if (f) atomicOr(&res->flags, f);
         res->n_records = n_rec;
+        res->cut = (n_rec && !(f & scg::TEXTSCAN_CAPACITY)) ? nl[4 * n_rec - 1] + 1 : 0;
     }
     uint32_t len = 0;
     if (i < n_rec && n_lines <= cap_lines && n_rec <= cap_records) {
@@ -230,7 +231,7 @@ hipError_t launch_gather_segments(char* seqs, uint32_t* offsets, const GatherSeg
 size_t text_scan_blocks(size_t n_bytes) { return (n_bytes + TS_TILE - 1) / TS_TILE; }
 size_t text_scan_padded(size_t n_bytes) { return text_scan_blocks(n_bytes) * TS_TILE; }
 
-hipError_t launch_text_scan(const char* d_text, size_t n_bytes, const TextScanBuffers& B, hipStream_t stream) {
+hipError_t launch_text_scan(const char* d_text, size_t n_bytes, const TextScanBuffers& B, hipStream_t stream, bool allow_tail) {
     hipError_t e = hipMemsetAsync(B.result, 0, sizeof(TextScanResult), stream);
     if (e != hipSuccess) return e;
     if (n_bytes == 0) return hipSuccess;
@@ -243,7 +244,7 @@ hipError_t launch_text_scan(const char* d_text, size_t n_bytes, const TextScanBu
     // a window holds at most n_bytes / 6 records (six bytes is the shortest 4-line record): never launch more lanes than that
     const unsigned need = (unsigned)((n_bytes / 6 + TS_BLOCK) / TS_BLOCK);
     hipLaunchKernelGGL(records_kernel, dim3(need < rec_blocks ? need : rec_blocks), dim3(TS_BLOCK), 0, stream, d_text, B.nl, (uint32_t)B.cap_lines,
-                       (uint32_t)B.cap_records, B.offsets, B.result);
+                       (uint32_t)B.cap_records, B.offsets, B.result, allow_tail ? 1 : 0);
     hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(SCAN_BLOCK), 0, stream, B.offsets, 0u, &B.result->n_records, (uint32_t)B.cap_records, (uint32_t*)nullptr);
     hipLaunchKernelGGL(compact_kernel, dim3(2048), dim3(TS_BLOCK), 0, stream, d_text, B.nl, B.offsets, B.seqs, (uint64_t)B.cap_seq_bytes, B.result);
     return hipGetLastError();

@@ -25,6 +25,14 @@ def plain_scan(request, monkeypatch):
     return request.param
 
 
+@pytest.fixture(params=["device_inflate", "host_inflate"])
+def bgzf_inflate(request, monkeypatch):
+    """Who inflates the members of BGZF files in single-end calls: the device (default) or the host threads' zlib."""
+    if request.param == "host_inflate":
+        monkeypatch.setenv("SCG_DEVICE_INFLATE", "0")
+    return request.param
+
+
 def make_case(seed, n=6000):
     rng = random.Random(seed)
     pool = gen.make_pool(rng, 60, 12, "ACGT")
@@ -47,7 +55,7 @@ def write_forms(tmp_path, reads, trailing_newline=True):
 
 @pytest.mark.parametrize("window_kb", [None, 8])
 @pytest.mark.parametrize("trailing_newline", [True, False])
-def test_every_input_form_counts_like_the_oracle(sc, oracle, gpu, tmp_path, monkeypatch, plain_scan, window_kb, trailing_newline):
+def test_every_input_form_counts_like_the_oracle(sc, oracle, gpu, tmp_path, monkeypatch, plain_scan, bgzf_inflate, window_kb, trailing_newline):
     pool, reads = make_case(11)
     exp, total = oracle.count_single(reads, TEMPLATE, 2, pool, 1, True)
     paths = write_forms(tmp_path, reads, trailing_newline)
@@ -65,7 +73,7 @@ def test_every_input_form_counts_like_the_oracle(sc, oracle, gpu, tmp_path, monk
     assert n == total and np.array_equal(got, exp)
 
 
-def test_several_pipelines_share_one_file(sc, oracle, gpu, tmp_path, monkeypatch, plain_scan):
+def test_several_pipelines_share_one_file(sc, oracle, gpu, tmp_path, monkeypatch, plain_scan, bgzf_inflate):
     """$SCG_DEVICES lists the devices one call may use; an id may repeat.  Windows go round-robin over the plans and the
     per-device counters are summed at the end: the result must not depend on the list."""
     pool, reads = make_case(12, n=20000)
@@ -85,7 +93,7 @@ def test_several_pipelines_share_one_file(sc, oracle, gpu, tmp_path, monkeypatch
         assert e.value.code == _lib.SCG_ERR_DEVICE and "out of range" in str(e.value)
 
 
-def test_combo_and_dual_single_end_through_the_scan(sc, oracle, gpu, tmp_path, monkeypatch):
+def test_combo_and_dual_single_end_through_the_scan(sc, oracle, gpu, tmp_path, monkeypatch, bgzf_inflate):
     rng = random.Random(13)
     t = "ACGTAC" + "-" * 8 + "GGATCC" + "-" * 6 + "TGCATG"
     p0, p1 = gen.make_pool(rng, 20, 8, "ACGT"), gen.make_pool(rng, 15, 6, "ACGT")
@@ -139,6 +147,71 @@ def test_unordinary_files_fall_back_to_the_sequential_reader(sc, oracle, gpu, tm
     with pytest.raises(_lib.ScgError) as e:
         sc.count_single_barcodes(s, TEMPLATE, 2, pool, 1, True, 4)
     assert "read name should start with '@'" in str(e.value)
+
+
+def test_bgzf_members_on_the_device(sc, oracle, gpu, tmp_path, monkeypatch):
+    """BGZF members inflated by the device: members of every size up to the format's 64 KiB (one lane each), stored and
+    fixed-Huffman members, empty members in the middle, windows that end in the middle of a record (the partial record is
+    carried to the next window on the device), a corrupt member (the host's zlib gets the last word: its error), a
+    member whose text was changed but still inflates (only the CRC tells)."""
+    import struct
+    import zlib
+    from screencounter_amd import _lib
+    pool, reads = make_case(21, n=30000)
+    exp, total = oracle.count_single(reads, TEMPLATE, 2, pool, 1, True)
+    text = gen.fastq_text(reads, trailing_newline=False)
+
+    def member(chunk, level=6, strategy=zlib.Z_DEFAULT_STRATEGY):
+        c = zlib.compressobj(level, zlib.DEFLATED, -15, 8, strategy)
+        payload = c.compress(chunk) + c.flush()
+        head = b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(payload) + 25)
+        return head + payload + struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk))
+
+    rng = random.Random(22)
+    parts, at = [], 0
+    while at < len(text):
+        n = rng.choice([1, 17, 300, 5000, 65280, 65280, 40000])
+        chunk = text[at:at + n]
+        at += n
+        kind = rng.randrange(6)
+        if kind == 0:
+            parts.append(member(chunk, 0))                              # stored blocks
+        elif kind == 1:
+            parts.append(member(chunk, 6, zlib.Z_FIXED))                # fixed Huffman code
+        elif kind == 2:
+            parts.append(member(b"") + member(chunk, 9))                # an empty member in the middle
+        else:
+            parts.append(member(chunk, rng.choice([1, 6, 9])))
+    parts.append(member(b""))                                           # bgzip's end-of-file marker
+    p = str(tmp_path / "mixed.bgzf.gz")
+    open(p, "wb").write(b"".join(parts))
+    for kb in (None, 200, 1000):
+        if kb:
+            monkeypatch.setenv("SCG_WINDOW_KB", str(kb))
+        got, n = sc.count_single_barcodes(p, TEMPLATE, 2, pool, 1, True, 4)
+        assert n == total and np.array_equal(got, exp), kb
+    monkeypatch.delenv("SCG_WINDOW_KB")
+    # a flipped bit in the middle of a member
+    raw = bytearray(b"".join(parts))
+    raw[len(raw) // 2] ^= 0x10
+    bad = str(tmp_path / "flipped.bgzf.gz")
+    open(bad, "wb").write(bytes(raw))
+    with pytest.raises(_lib.ScgError) as e:
+        sc.count_single_barcodes(bad, TEMPLATE, 2, pool, 1, True, 4)
+    assert e.value.code == _lib.SCG_ERR_IO
+    # text changed, CRC kept: still a valid DEFLATE stream of the right size
+    k = len(parts) // 2
+    chunk = bytearray(text[:5000])
+    good = member(bytes(chunk), 6)
+    i = chunk.index(b"\n") + 3
+    chunk[i] = ord("A") if chunk[i] != ord("A") else ord("C")
+    forged = member(bytes(chunk), 6)
+    forged = forged[:-8] + good[-8:]                                     # the original's CRC and size
+    f2 = str(tmp_path / "forged.bgzf.gz")
+    open(f2, "wb").write(forged + member(b""))
+    with pytest.raises(_lib.ScgError) as e:
+        sc.count_single_barcodes(f2, TEMPLATE, 2, pool, 1, True, 4)
+    assert e.value.code == _lib.SCG_ERR_IO and "incorrect data check" in str(e.value)
 
 
 def test_multi_file_entries_equal_per_file_calls(sc, oracle, gpu, tmp_path, monkeypatch, plain_scan):
