@@ -390,7 +390,7 @@ def end_to_end(sc, synth, torch, np, w, plan, mates, args) -> dict:
                                  "total": int(total), "mapped": mapped}
             if w.entry != "dual":
                 # the same reads as BGZF (blocked gzip as written by bgzip): members inflated in parallel by the host threads
-                s3 = min(s2, 8_000_000)
+                s3 = min(s2, 16_000_000)
                 plain = os.path.join(d, "sub.fastq")
                 synth.reads_to_fastq(plain, mates[0][: s3 * L].cpu().numpy(), L)
                 gz = os.path.join(d, "sub.fastq.gz")

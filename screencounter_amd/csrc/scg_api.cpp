@@ -1128,6 +1128,15 @@ bool device_inflate_enabled() {
     const char* e = std::getenv("SCG_DEVICE_INFLATE");       // test hook: 0 inflates BGZF members on the host threads
     return !(e && *e == '0');
 }
+// Test hook SCG_DEVICE_INFLATE=2: a file the device inflater hands back is an error instead of a quiet second try on the
+// host (so that a test on a well-formed file cannot pass on the fall-back).
+[[noreturn]] void inflate_declined() {
+    throw Error(SCG_ERR_UNSUPPORTED, "the device inflater handed the file back (SCG_DEVICE_INFLATE=2 forbids the fall-back)");
+}
+bool device_inflate_strict() {
+    const char* e = std::getenv("SCG_DEVICE_INFLATE");
+    return e && *e == '2';
+}
 
 // The single-end pipeline for BGZF input with the members inflated on the device (scg_inflate.hip).  Per window, on
 // the slot's stream: compressed members + their table -> HBM; inflate + CRC check into the text buffer behind a gap of
@@ -1245,8 +1254,7 @@ private:
         HIP_CHECK(scg::launch_carry_tail(prev ? prev->d_text.as<char>() : nullptr, prev ? prev->B.result : nullptr, prev ? prev->text_bytes : 0u,
                                          s.d_text.as<char>(), static_cast<uint32_t>(GAP), s.d_status.as<uint32_t>(), s.stream));
         HIP_CHECK(hipEventRecord(s.carried, s.stream));
-        HIP_CHECK(scg::launch_text_scan(s.d_text.as<char>(), s.text_bytes, s.B, s.stream, true));
-        HIP_CHECK(hipEventRecord(s.scanned, s.stream));
+        HIP_CHECK(scg::launch_text_scan(s.d_text.as<char>(), s.text_bytes, s.B, s.stream, true, s.scanned));
         HIP_CHECK(hipMemcpyAsync(s.h_result.p, s.d_result.p, sizeof(scg::TextScanResult), hipMemcpyDeviceToHost, s.stream));
         HIP_CHECK(hipMemcpyAsync(s.h_status.p, s.d_status.p, sizeof(uint32_t), hipMemcpyDeviceToHost, s.stream));
         s.parsed = false;
@@ -1461,6 +1469,7 @@ void count_single_end(const std::vector<scg_plan*>& plans, const char* path, scg
                     done = true;
                 }
             } catch (const UnusualInput&) {
+                if (device_inflate_strict()) inflate_declined();
                 for (scg_plan* P : plans) reset_plan(P);
             }
             if (done) return;
@@ -1701,6 +1710,7 @@ std::unique_ptr<PlanSet> compile_and_count_single_end(const char* path, scg::Fas
             inflate->run(set->first());
             done = true;
         } catch (const UnusualInput&) {
+            if (device_inflate_strict()) inflate_declined();
             set->reset();
         }
         inflate.reset();
@@ -2217,12 +2227,18 @@ int scg_count_single_barcodes(const char* path, const char* constant, int strand
                               char* err, size_t errcap) {
     return guarded(err, errcap, [&] {
         if (!path || !counts_out || !total_out) throw Error(SCG_ERR_INVALID, "null argument");
+        Trace tr;
         scg::FastqStream fq(path);                                           // src/count_single_barcodes.cpp:30
+        tr.mark("open");
         auto set = compile_and_count_single_end(path, fq, nthreads, [&] {
             return compile_single(constant, strand, pool, n_pool, mismatches, use_first);   // :31-47
         });
+        tr.mark("compile + count");
         set->read(counts_out);
         *total_out = narrow_total(set->total());
+        tr.mark("read counters");
+        set.reset();
+        tr.mark("release the plan");
     });
 }
 

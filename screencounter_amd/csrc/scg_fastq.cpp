@@ -40,7 +40,11 @@ struct FastqStream::Impl {
     bool okay = false;       // a record starts at *cur
     int64_t line_count = 0;
 
-    explicit Impl(const char* p) : path(p), buf(size_t(8) << 20) {
+    bool started = false;
+
+    // Opens the file; the first read happens with the first record (the reference opens its reader before it builds
+    // the handler and reads only once processing starts: src/count_single_barcodes.cpp:30-49).
+    explicit Impl(const char* p) : path(p) {
         unsigned char header[3];
         size_t got = 0;
         {
@@ -62,6 +66,11 @@ struct FastqStream::Impl {
             fd = ::open(p, O_RDONLY);
             if (fd < 0) throw Error(SCG_ERR_IO, "failed to open file at '" + path + "'");
         }
+    }
+
+    void start() {
+        started = true;
+        buf.resize(size_t(8) << 20);
         refill();
         okay = cur < end;    // kaori/FastqReader.hpp:32
     }
@@ -180,6 +189,7 @@ FastqStream::~FastqStream() { delete impl; }
 
 bool FastqStream::next_batch(ReadBatch& out, int64_t max_reads, int64_t max_bytes) {
     out.clear();
+    if (!impl->started) impl->start();
     while (impl->okay && out.size() < max_reads && static_cast<int64_t>(out.seqs.size()) < max_bytes) {
         impl->record(out.seqs);
         out.offsets.push_back(out.seqs.size());

@@ -50,10 +50,31 @@ struct LaneTables {
     uint16_t offs[16];                // scratch of the table builder
 };
 
-// The lanes that walk a member together.  lane() < width(); every lane passes the same arguments.
-struct SoloLane {
-    SCG_HD uint32_t lane() const { return 0; }
-    SCG_HD uint32_t width() const { return 1; }
+// The lanes that walk a member together ("Wave" below).  The decoder's own state is the same in every lane; the lanes
+// differ only inside a Wave::Vec, a vector with one byte per lane, which the decoder moves around but never looks into:
+//   width()                          lanes
+//   set(v, j, byte)                  v[j] = byte
+//   load(v, src, n, dist)            v[j] = src[j mod dist], j < n <= width()
+//   store(dst, v, n)                 dst[j] = v[j], j < n
+//   copy(dst, src, n, dist)          dst[j] = src[j mod dist], j < n, any n (src + dist <= dst: nothing it reads is written by it)
+// On the device a Vec is one register and each operation one instruction per lane (scg_inflate.hip); the host tests
+// run the same decoder with arrays (tests/inflate_harness.cpp), both one lane wide and 64 lanes wide.
+template<int WIDTH>
+struct HostWave {
+    struct Vec { uint8_t b[WIDTH]; };
+    SCG_HD uint32_t width() const { return WIDTH; }
+    SCG_HD void set(Vec& v, uint32_t j, uint32_t byte) const { v.b[j] = static_cast<uint8_t>(byte); }
+    SCG_HD void load(Vec& v, const uint8_t* src, uint32_t n, uint32_t dist) const { for (uint32_t j = 0; j < n; ++j) v.b[j] = src[j % dist]; }
+    SCG_HD void store(uint8_t* dst, const Vec& v, uint32_t n) const { for (uint32_t j = 0; j < n; ++j) dst[j] = v.b[j]; }
+    SCG_HD void copy(uint8_t* dst, const uint8_t* src, uint32_t n, uint32_t dist) const {
+        // all loads of a round of WIDTH bytes before its stores, as the lanes of a wavefront do it
+        for (uint32_t at = 0; at < n; at += WIDTH) {
+            Vec v;
+            const uint32_t m = n - at < static_cast<uint32_t>(WIDTH) ? n - at : static_cast<uint32_t>(WIDTH);
+            for (uint32_t j = 0; j < m; ++j) v.b[j] = src[(at + j) % dist];
+            for (uint32_t j = 0; j < m; ++j) dst[at + j] = v.b[j];
+        }
+    }
 };
 
 SCG_HD uint32_t load32(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
@@ -62,17 +83,31 @@ SCG_HD void store64(uint8_t* p, uint64_t v) { __builtin_memcpy(p, &v, 8); }
 
 struct BitReader {
     const uint8_t* in;
-    uint32_t pos;        // next byte to load
+    uint32_t pos;        // bytes of the stream that have entered buf
     uint32_t len;        // payload bytes; in[0 .. len + IN_SLACK) is readable
     uint64_t buf;        // LSB first
     uint32_t cnt;        // valid bits in buf
+    uint32_t a0, a1;     // the stream's next two words, loaded ahead of their use: in[pos .. pos + 8)
 
-    // At least 33 bits afterwards.
+    SCG_HD void open(const uint8_t* p, uint32_t n) {
+        in = p; pos = 0; len = n; buf = 0; cnt = 0;
+        a0 = load32(in);
+        a1 = load32(in + 4);
+    }
+    // Continues at byte `at` of the stream (bit buffer empty).
+    SCG_HD void seek(uint32_t at) {
+        pos = at; buf = 0; cnt = 0;
+        a0 = load32(in + pos);
+        a1 = load32(in + pos + 4);
+    }
+    // At least 33 bits afterwards.  The word that enters the buffer was requested two refills ago.
     SCG_HD void refill() {
         if (cnt <= 32) {
-            buf |= static_cast<uint64_t>(load32(in + pos)) << cnt;
-            pos += 4;
+            buf |= static_cast<uint64_t>(a0) << cnt;
             cnt += 32;
+            pos += 4;
+            a0 = a1;
+            a1 = load32(in + pos + 4);
         }
     }
     SCG_HD uint32_t bits(uint32_t n) {
@@ -82,6 +117,67 @@ struct BitReader {
         return v;
     }
     SCG_HD bool overrun() const { return pos > len + 8; }     // more than the refill look-ahead beyond the payload
+};
+
+// The member's text.  Literals are collected, one per lane, and written a wavefront's width at a time.  A match of
+// at most that many bytes is loaded at once but stored only when the next match comes along (or the text ends): the
+// wavefront does not need the bytes to go on decoding, so the load's latency overlaps the next symbols.  Whatever reads
+// text that is still pending -- a match whose source reaches into the pending literals or the pending match -- has it
+// written out first.
+template<class Wave>
+struct TextWriter {
+    const Wave& wave;
+    uint8_t* out;
+    uint32_t op;             // bytes produced
+    uint32_t n_lit;          // of which the last n_lit are literals still in `lit`
+    typename Wave::Vec lit;
+    uint32_t m_at, m_n;      // a match of m_n bytes for out[m_at ...) still in `held`
+    typename Wave::Vec held;
+
+    SCG_HD TextWriter(const Wave& w, uint8_t* o) : wave(w), out(o), op(0), n_lit(0), m_at(0), m_n(0) {}
+    SCG_HD void flush_literals() {
+        if (n_lit) wave.store(out + op - n_lit, lit, n_lit);
+        n_lit = 0;
+    }
+    SCG_HD void flush_match() {
+        if (m_n) wave.store(out + m_at, held, m_n);
+        m_n = 0;
+    }
+    SCG_HD void literal(uint32_t byte) {
+        wave.set(lit, n_lit, byte);
+        ++n_lit;
+        ++op;
+        if (n_lit == wave.width()) flush_literals();
+    }
+    // out[op + j] = out[op - dist + j mod dist], j < n; dist <= op.
+    SCG_HD void match(uint32_t n, uint32_t dist) {
+        const uint32_t src = op - dist, reach = src + (n < dist ? n : dist);      // reads out[src .. reach)
+        flush_literals();                       // (pending literals are always the text's last bytes)
+        if (m_n && reach > m_at && src < m_at + m_n) flush_match();
+        if (n <= wave.width()) {
+            typename Wave::Vec v;
+            wave.load(v, out + src, n, dist);
+            flush_match();                      // (the one before: its bytes have had a symbol or more to arrive)
+            held = v;
+            m_at = op;
+            m_n = n;
+        } else {
+            flush_match();
+            wave.copy(out + op, out + src, n, dist);
+        }
+        op += n;
+    }
+    // n bytes from elsewhere (a stored block)
+    SCG_HD void raw(const uint8_t* from, uint32_t n) {
+        flush_literals();
+        flush_match();
+        wave.copy(out + op, from, n, n ? n : 1u);
+        op += n;
+    }
+    SCG_HD void finish() {
+        flush_literals();
+        flush_match();
+    }
 };
 
 SCG_HD uint32_t reverse_bits(uint32_t code, int len) {
@@ -168,9 +264,10 @@ SCG_HD int decode_symbol(BitReader& br, const uint16_t* table, int tbits, const 
 // exactly at in_len and produces exactly out_len bytes.  in must be readable up to in_len + IN_SLACK.
 template<class Wave>
 SCG_HD int inflate_member(const uint8_t* in, uint32_t in_len, uint8_t* out, uint32_t out_len, LaneTables& T, const Wave& wave) {
-    const uint32_t lane = wave.lane(), width = wave.width();
-    BitReader br{in, 0, in_len, 0, 0};
-    uint32_t op = 0;
+    BitReader br;
+    br.open(in, in_len);
+    TextWriter<Wave> w(wave, out);
+    uint32_t& op = w.op;
     uint8_t* const lens = reinterpret_cast<uint8_t*>(T.lit);             // 320 code lengths fit the 1 KiB of T.lit
     uint32_t last;
     do {
@@ -188,17 +285,14 @@ SCG_HD int inflate_member(const uint8_t* in, uint32_t in_len, uint8_t* out, uint
             if (n > out_len - op) return INFLATE_BAD_SIZE;
             uint32_t left = n;
             while (left && br.cnt) {
-                const uint8_t b = static_cast<uint8_t>(br.bits(8));
-                if (lane == 0) out[op] = b;
-                ++op;
+                w.literal(br.bits(8));
                 --left;
             }
             if (left) {
                 // the bit buffer is empty: br.pos is the next byte of the stream
                 if (br.pos > in_len || left > in_len - br.pos) return INFLATE_BAD_DATA;
-                for (uint32_t i = lane; i < left; i += width) out[op + i] = in[br.pos + i];
-                op += left;
-                br.pos += left;
+                w.raw(in + br.pos, left);
+                br.seek(br.pos + left);
             }
             continue;
         }
@@ -265,8 +359,7 @@ SCG_HD int inflate_member(const uint8_t* in, uint32_t in_len, uint8_t* out, uint
             if (s < 0) return INFLATE_BAD_DATA;                          // "invalid literal/length code"
             if (s < 256) {
                 if (op >= out_len) return INFLATE_BAD_SIZE;
-                if (lane == 0) out[op] = static_cast<uint8_t>(s);
-                ++op;
+                w.literal(static_cast<uint32_t>(s));
                 continue;
             }
             if (s == 256) break;
@@ -293,17 +386,10 @@ SCG_HD int inflate_member(const uint8_t* in, uint32_t in_len, uint8_t* out, uint
             }
             if (dist > op) return INFLATE_BAD_DATA;                      // "invalid distance too far back"
             if (n > out_len - op) return INFLATE_BAD_SIZE;
-            // out[op + j] = out[op - dist + j mod dist]: every source byte lies before op, so the lanes need not wait
-            // for one another
-            const uint8_t* const src = out + op - dist;
-            if (dist >= n) {
-                for (uint32_t j = lane; j < n; j += width) out[op + j] = src[j];
-            } else {
-                for (uint32_t j = lane; j < n; j += width) out[op + j] = src[j % dist];
-            }
-            op += n;
+            w.match(n, dist);
         }
     } while (!last);
+    w.finish();
     // the stream must end where the member's payload ends, and fill the announced size
     const uint32_t consumed = br.pos - (br.cnt >> 3);
     if (consumed != in_len || op != out_len) return INFLATE_BAD_SIZE;

@@ -26,10 +26,23 @@ namespace {
 // than a window has members.
 constexpr int INFLATE_BLOCK = 64;
 
+// The wavefront as scg_inflate.h's decoder sees it: a Vec is one register, lane j holds byte j.
 struct WaveLanes {
+    typedef uint32_t Vec;
     uint32_t id;
-    __device__ __forceinline__ uint32_t lane() const { return id; }
     __device__ __forceinline__ uint32_t width() const { return INFLATE_BLOCK; }
+    __device__ __forceinline__ void set(Vec& v, uint32_t j, uint32_t byte) const { if (id == j) v = byte; }
+    // j mod dist for this lane (dist is wave-uniform; matches that reach into their own output are the rare case)
+    __device__ __forceinline__ uint32_t wrap(uint32_t j, uint32_t n, uint32_t dist) const { return dist >= n ? j : (dist == 1 ? 0u : j % dist); }
+    __device__ __forceinline__ void load(Vec& v, const uint8_t* src, uint32_t n, uint32_t dist) const {
+        if (id < n) v = src[wrap(id, n, dist)];
+    }
+    __device__ __forceinline__ void store(uint8_t* dst, const Vec& v, uint32_t n) const {
+        if (id < n) dst[id] = static_cast<uint8_t>(v);
+    }
+    __device__ __forceinline__ void copy(uint8_t* dst, const uint8_t* src, uint32_t n, uint32_t dist) const {
+        for (uint32_t j = id; j < n; j += INFLATE_BLOCK) dst[j] = src[wrap(j, n, dist)];
+    }
 };
 
 __global__ __launch_bounds__(INFLATE_BLOCK) void inflate_members_kernel(const uint8_t* __restrict__ in, const scg::InflateMember* __restrict__ members,
@@ -70,11 +83,24 @@ __global__ __launch_bounds__(CRC_BLOCK) void crc_members_kernel(const uint8_t* _
     __syncthreads();
     for (uint32_t m = blockIdx.x; m < n; m += gridDim.x) {
         const scg::InflateMember M = members[m];
-        const uint32_t piece = (M.out_len + CRC_BLOCK - 1) / CRC_BLOCK;
+        // pieces of whole 16-byte loads (a byte at a time, the 64 lanes of a load would touch 64 cache lines for 64 bytes)
+        const uint32_t piece = ((M.out_len + CRC_BLOCK - 1) / CRC_BLOCK + 15u) & ~15u;
         const uint32_t a = min(threadIdx.x * piece, M.out_len), b = min(a + piece, M.out_len);
         uint32_t c = 0xFFFFFFFFu;
         const uint8_t* p = text + M.out_off;
-        for (uint32_t i = a; i < b; ++i) c = table[(c ^ p[i]) & 0xFFu] ^ (c >> 8);
+        uint32_t i = a;
+        for (; i + 16 <= b; i += 16) {
+            uint4 v;
+            __builtin_memcpy(&v, p + i, 16);
+            const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                c ^= d[k];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) c = table[c & 0xFFu] ^ (c >> 8);
+            }
+        }
+        for (; i < b; ++i) c = table[(c ^ p[i]) & 0xFFu] ^ (c >> 8);
         c = (b > a) ? ~c : 0u;                                 // (the CRC of nothing is 0)
         // x^(8 * (out_len - b)): product of the precomputed x^(2^k) over the set bits of the exponent
         uint32_t behind = M.out_len - b, x = 1u << 31;

@@ -42,7 +42,10 @@ size_t text_scan_padded(size_t n_bytes);    // device text buffers must be reada
 // a newline (the host appends one when the file lacks it, as the reference accepts a final record without it).
 // allow_tail: the text may end anywhere (windows cut at gzip member boundaries): the records are the whole groups of
 // four lines, and `cut` says where the rest begins.
-hipError_t launch_text_scan(const char* d_text, size_t n_bytes, const TextScanBuffers& B, hipStream_t stream, bool allow_tail = false);
+// `structure_known`, if given, is recorded once n_records, cut and the structure flags are in B.result (the sequences
+// are still being cut out then): what the next window of a chained pipeline waits for.
+hipError_t launch_text_scan(const char* d_text, size_t n_bytes, const TextScanBuffers& B, hipStream_t stream, bool allow_tail = false,
+                            hipEvent_t structure_known = nullptr);
 
 // Host-side record scan (scg_ingest.h): the sequences and offsets of a window lie in pinned host memory in segments,
 // one per host thread, the offsets of each relative to its own first sequence.  One kernel pulls them over the link

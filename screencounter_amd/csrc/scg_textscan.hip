@@ -231,7 +231,7 @@ hipError_t launch_gather_segments(char* seqs, uint32_t* offsets, const GatherSeg
 size_t text_scan_blocks(size_t n_bytes) { return (n_bytes + TS_TILE - 1) / TS_TILE; }
 size_t text_scan_padded(size_t n_bytes) { return text_scan_blocks(n_bytes) * TS_TILE; }
 
-hipError_t launch_text_scan(const char* d_text, size_t n_bytes, const TextScanBuffers& B, hipStream_t stream, bool allow_tail) {
+hipError_t launch_text_scan(const char* d_text, size_t n_bytes, const TextScanBuffers& B, hipStream_t stream, bool allow_tail, hipEvent_t structure_known) {
     hipError_t e = hipMemsetAsync(B.result, 0, sizeof(TextScanResult), stream);
     if (e != hipSuccess) return e;
     if (n_bytes == 0) return hipSuccess;
@@ -245,6 +245,10 @@ hipError_t launch_text_scan(const char* d_text, size_t n_bytes, const TextScanBu
     const unsigned need = (unsigned)((n_bytes / 6 + TS_BLOCK) / TS_BLOCK);
     hipLaunchKernelGGL(records_kernel, dim3(need < rec_blocks ? need : rec_blocks), dim3(TS_BLOCK), 0, stream, d_text, B.nl, (uint32_t)B.cap_lines,
                        (uint32_t)B.cap_records, B.offsets, B.result, allow_tail ? 1 : 0);
+    if (structure_known) {
+        e = hipEventRecord(structure_known, stream);
+        if (e != hipSuccess) return e;
+    }
     hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(SCAN_BLOCK), 0, stream, B.offsets, 0u, &B.result->n_records, (uint32_t)B.cap_records, (uint32_t*)nullptr);
     hipLaunchKernelGGL(compact_kernel, dim3(2048), dim3(TS_BLOCK), 0, stream, d_text, B.nl, B.offsets, B.seqs, (uint64_t)B.cap_seq_bytes, B.result);
     return hipGetLastError();

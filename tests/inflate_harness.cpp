@@ -88,13 +88,23 @@ static bool zlib_inflate(const std::vector<uint8_t>& c, size_t n, std::vector<ui
     return ok;
 }
 
+// The decoder with "wavefronts" of 1, 7 and 64 lanes (the device runs 64): all must agree, byte for byte and verdict
+// for verdict -- the wider ones exercise the batched literals and the deferred stores of short matches.
 static int ours(const std::vector<uint8_t>& c, size_t n, std::vector<uint8_t>& out) {
     // exact-size buffers so that ASan sees any access beyond the slack or the output
     std::vector<uint8_t> in(c.size() + scginf::IN_SLACK, 0xA5);
     memcpy(in.data(), c.data(), c.size());
-    out.assign(n, 0xEE);
     static scginf::LaneTables T;
-    return scginf::inflate_member(in.data(), (uint32_t)c.size(), out.data(), (uint32_t)n, T, scginf::SoloLane());
+    out.assign(n, 0xEE);
+    const int rc = scginf::inflate_member(in.data(), (uint32_t)c.size(), out.data(), (uint32_t)n, T, scginf::HostWave<64>());
+    std::vector<uint8_t> o1(n, 0xEE), o7(n, 0xEE);
+    const int rc1 = scginf::inflate_member(in.data(), (uint32_t)c.size(), o1.data(), (uint32_t)n, T, scginf::HostWave<1>());
+    const int rc7 = scginf::inflate_member(in.data(), (uint32_t)c.size(), o7.data(), (uint32_t)n, T, scginf::HostWave<7>());
+    if (rc1 != rc || rc7 != rc || (rc == scginf::INFLATE_OK && (o1 != out || o7 != out))) {
+        fprintf(stderr, "FAIL the lane widths disagree: rc %d / %d / %d\n", rc, rc1, rc7);
+        exit(1);
+    }
+    return rc;
 }
 
 int main(int argc, char** argv) {

@@ -28,8 +28,8 @@ def plain_scan(request, monkeypatch):
 @pytest.fixture(params=["device_inflate", "host_inflate"])
 def bgzf_inflate(request, monkeypatch):
     """Who inflates the members of BGZF files in single-end calls: the device (default) or the host threads' zlib."""
-    if request.param == "host_inflate":
-        monkeypatch.setenv("SCG_DEVICE_INFLATE", "0")
+    # 2 = the device, and handing a file back to the host is an error (these files are well-formed)
+    monkeypatch.setenv("SCG_DEVICE_INFLATE", "0" if request.param == "host_inflate" else "2")
     return request.param
 
 
@@ -185,12 +185,14 @@ def test_bgzf_members_on_the_device(sc, oracle, gpu, tmp_path, monkeypatch):
     parts.append(member(b""))                                           # bgzip's end-of-file marker
     p = str(tmp_path / "mixed.bgzf.gz")
     open(p, "wb").write(b"".join(parts))
+    monkeypatch.setenv("SCG_DEVICE_INFLATE", "2")                       # no quiet fall-back to the host
     for kb in (None, 200, 1000):
         if kb:
             monkeypatch.setenv("SCG_WINDOW_KB", str(kb))
         got, n = sc.count_single_barcodes(p, TEMPLATE, 2, pool, 1, True, 4)
         assert n == total and np.array_equal(got, exp), kb
     monkeypatch.delenv("SCG_WINDOW_KB")
+    monkeypatch.delenv("SCG_DEVICE_INFLATE")
     # a flipped bit in the middle of a member
     raw = bytearray(b"".join(parts))
     raw[len(raw) // 2] ^= 0x10
