@@ -979,12 +979,13 @@ struct SlotPool {
     std::vector<std::unique_ptr<ScanSlot> > idle;
     // pinned_bytes = 0: as much pinned staging as text (the raw-text and host-scan pipelines)
     std::unique_ptr<ScanSlot> take(int device, size_t window, size_t pinned_bytes = 0) {
-        if (pinned_bytes == 0) pinned_bytes = window;
+        const bool whole = pinned_bytes == 0;          // these pipelines fill the pinned buffer up to the slot's capacity
+        if (whole) pinned_bytes = window;
         {
             std::lock_guard<std::mutex> g(mu);
             for (size_t i = 0; i < idle.size(); ++i) {
                 if (idle[i]->plan_device == device && idle[i]->cap >= window && idle[i]->cap <= 2 * window + (size_t(8) << 20) &&
-                    idle[i]->pinned_cap >= pinned_bytes) {
+                    idle[i]->pinned_cap >= (whole ? idle[i]->cap : pinned_bytes)) {
                     std::unique_ptr<ScanSlot> s = std::move(idle[i]);
                     idle.erase(idle.begin() + static_cast<long>(i));
                     s->plan = nullptr;
@@ -1711,6 +1712,7 @@ std::unique_ptr<PlanSet> compile_and_count_single_end(const char* path, scg::Fas
             done = true;
         } catch (const UnusualInput&) {
             if (device_inflate_strict()) inflate_declined();
+            inflate.reset();                       // (its kernels have finished before the counters are cleared)
             set->reset();
         }
         inflate.reset();
@@ -1729,6 +1731,7 @@ std::unique_ptr<PlanSet> compile_and_count_single_end(const char* path, scg::Fas
             pipe->run(set->all());
             done = true;
         } catch (const UnusualInput&) {
+            pipe.reset();
             set->reset();
         }
         pipe.reset();
@@ -1933,6 +1936,7 @@ std::unique_ptr<scg_plan> compile_and_count_paired(const char* path1, const char
             pipe->run(P.get());
             done = true;
         } catch (const UnusualInput&) {
+            pipe.reset();                          // (its kernels have finished before the counters are cleared)
             reset_plan(P.get());
         }
         pipe.reset();

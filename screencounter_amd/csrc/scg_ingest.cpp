@@ -447,9 +447,16 @@ protected:
         }
         if (off >= f.size) exhausted = true;
         if (batch.empty() && !exhausted) { odd = true; return have; }     // one member larger than a window
-        pool.run(static_cast<int>(batch.size()), [&](int i) {
-            if (batch[i].isize) inflate_member(f.data + batch[i].off, batch[i].csize, dst + where[i], batch[i].isize);
-        });
+        try {
+            pool.run(static_cast<int>(batch.size()), [&](int i) {
+                if (batch[i].isize) inflate_member(f.data + batch[i].off, batch[i].csize, dst + where[i], batch[i].isize);
+            });
+        } catch (const Error&) {
+            // a corrupt member: the sequential reader reports it the way the reference does -- zlib's message with the
+            // path in front, and only after whatever the text before it holds
+            odd = true;
+            return have;
+        }
         return at;
     }
 };

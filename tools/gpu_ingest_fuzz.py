@@ -1,0 +1,123 @@
+#!/usr/bin/env python3
+"""Time-boxed fuzz of the ingestion paths on the GPU: random FASTQ text -- ordinary records of random shapes, and now and
+then something the fast paths must hand back (multi-line records, blank lines, missing '@' / '+', truncated ends, CRLF,
+a flipped bit in a BGZF member) -- counted through every path:
+  plain file   host record scan | device record scan
+  BGZF         members inflated on the device | by the host threads
+with random window sizes; every path must give what the sequential reference-exact reader gives (SCG_DEVICE_SCAN=0):
+the same counts, or the same error.
+usage: python3 tools/gpu_ingest_fuzz.py [seconds] [first_seed]"""
+import os
+import random
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import screencounter_amd as sc  # noqa: E402
+from screencounter_amd import _lib  # noqa: E402
+from tests import gen  # noqa: E402
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 50_000
+TEMPLATE = "ACGTACGA" + "-" * 12 + "TGCATGCA"
+MODE_VARS = ("SCG_DEVICE_SCAN", "SCG_HOST_SCAN", "SCG_DEVICE_INFLATE", "SCG_WINDOW_KB")
+
+
+def set_mode(**kw):
+    for v in MODE_VARS:
+        os.environ.pop(v, None)
+    for k, v in kw.items():
+        if v is not None:
+            os.environ[k] = str(v)
+
+
+def run(path, pool):
+    try:
+        c, t = sc.count_single_barcodes(path, TEMPLATE, 2, pool, 1, True, 4)
+        return ("ok", t, c.tobytes())
+    except _lib.ScgError as e:
+        return ("error", e.code, str(e))
+
+
+def make_text(rng):
+    pool = gen.make_pool(rng, 40, 12, "ACGT")
+    n = rng.choice([0, 1, 5, 200, 3000, 12000])
+    reads = gen.make_reads(rng, TEMPLATE, [pool], n, 2, 0.03, 0.01, 0.02, 0.1, rng.choice([0, 10, 60, 200])) if n else []
+    if reads and rng.random() < 0.3:
+        reads[rng.randrange(len(reads))] = ""                      # an empty read
+    recs = []
+    for i, r in enumerate(reads):
+        name = rng.choice(["r%d" % i, "@odd+name %d" % i, "x" * rng.randint(1, 300), ""])
+        plus = rng.choice(["", "", "", "r%d" % i])
+        recs.append(b"@" + name.encode() + b"\n" + r.encode() + b"\n+" + plus.encode() + b"\n" + bytes(rng.choice(b"FI:,#") for _ in r) + b"\n")
+    flaw = rng.choice(["none"] * 5 + ["multiline", "blank", "no_at", "no_plus", "short_quality", "truncated", "crlf", "no_final_newline", "plus_in_seq"])
+    if recs:
+        k = rng.randrange(len(recs))
+        r = reads[k] or "ACGT"
+        if flaw == "multiline" and len(r) >= 2:
+            recs[k] = b"@m\n" + r[:len(r) // 2].encode() + b"\n" + r[len(r) // 2:].encode() + b"\n+\n" + b"I" * len(r) + b"\n"
+        elif flaw == "blank":
+            recs[k] = recs[k] + b"\n"
+        elif flaw == "no_at":
+            recs[k] = recs[k][1:]
+        elif flaw == "no_plus":
+            recs[k] = recs[k].replace(b"\n+", b"\n-", 1)
+        elif flaw == "short_quality":
+            recs[k] = b"@q\n" + r.encode() + b"\n+\n" + b"I" * max(len(r) - 1, 0) + b"\n"
+        elif flaw == "plus_in_seq":
+            recs[k] = b"@p\nAC+GT\n+\nIIIII\n"
+    text = b"".join(recs)
+    if flaw == "truncated" and len(text) > 10:
+        text = text[:-rng.randint(1, min(len(text) - 1, 200))]
+    elif flaw == "crlf":
+        text = text.replace(b"\n", b"\r\n")
+    elif flaw == "no_final_newline" and text.endswith(b"\n"):
+        text = text[:-1]
+    return pool, text, flaw
+
+
+tally = {}
+t0 = time.time()
+it = 0
+with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as tmp:
+    last = t0
+    while time.time() - t0 < budget:
+        seed = seed0 + it
+        it += 1
+        rng = random.Random(seed)
+        pool, text, flaw = make_text(rng)
+        plain = os.path.join(tmp, "f.fastq")
+        open(plain, "wb").write(text)
+        bg = os.path.join(tmp, "f.bgzf.gz")
+        gen.write_bgzf(bg, text, block=rng.choice([300, 3000, 30000, 65280]), eof_block=rng.random() < 0.8)
+        bitflip = rng.random() < 0.1 and os.path.getsize(bg) > 100
+        if bitflip:
+            raw = bytearray(open(bg, "rb").read())
+            raw[rng.randrange(30, len(raw) - 10)] ^= 1 << rng.randrange(8)
+            open(bg, "wb").write(bytes(raw))
+        set_mode(SCG_DEVICE_SCAN=0)
+        want = run(plain, pool)
+        want_bg = run(bg, pool) if bitflip else want
+        kb = rng.choice([None, None, 4, 16, 100, 700])
+        modes = [("host_scan", plain, dict(SCG_WINDOW_KB=kb)), ("device_scan", plain, dict(SCG_HOST_SCAN=0, SCG_WINDOW_KB=kb)),
+                 ("device_inflate", bg, dict(SCG_WINDOW_KB=kb)), ("host_inflate", bg, dict(SCG_DEVICE_INFLATE=0, SCG_WINDOW_KB=kb))]
+        for name, path, env in modes:
+            set_mode(**env)
+            if os.environ.get("FUZZ_VERBOSE"):
+                print(f"seed {seed} flaw {flaw} bitflip {bitflip} mode {name} window_kb {kb} bytes {len(text)}", file=sys.stderr, flush=True)
+            got = run(path, pool)
+            exp = want_bg if path == bg else want
+            if got != exp:
+                print(f"MISMATCH seed {seed} flaw {flaw} bitflip {bitflip} mode {name} window_kb {kb}: got {got[:2]} {got[2][:80] if got[0] == 'error' else ''} "
+                      f"want {exp[:2]} {exp[2][:80] if exp[0] == 'error' else ''}", flush=True)
+                sys.exit(1)
+        key = flaw + ("+bitflip" if bitflip else "") + ":" + want[0]
+        tally[key] = tally.get(key, 0) + 1
+        if time.time() - last > 10:
+            last = time.time()
+            print(f"{it} files, {time.time() - t0:.0f} s", flush=True)
+set_mode()
+print(f"ingest fuzz: {it} files x 4 paths, no mismatch; {dict(sorted(tally.items()))}")
