@@ -355,3 +355,22 @@ def test_error_order_and_buffer_cache(sc, oracle, gpu, tmp_path, monkeypatch, pl
         sc.load().scg_release_buffers()
     got, n = sc.count_single_barcodes(good, TEMPLATE, 2, prepared, 1, True, 2)
     assert n == total and np.array_equal(got, exp)
+
+
+def test_cached_slots_serve_every_pipeline(sc, oracle, gpu, tmp_path, monkeypatch):
+    """Idle staging slots are kept between calls and shared by all pipelines, whose needs differ: the device-inflate
+    pipeline pins only what the compressed bytes take, the others fill the pinned buffer up to the slot's text capacity.
+    Alternating the pipelines over files larger than a slot must never hand a pipeline a slot it overruns (found by
+    tools/gpu_ingest_fuzz.py as heap corruption)."""
+    pool, reads = make_case(31, n=30000)
+    exp, total = oracle.count_single(reads, TEMPLATE, 2, pool, 1, True)
+    paths = write_forms(tmp_path, reads)
+    for kb in (700, 100, 700, 16):
+        monkeypatch.setenv("SCG_WINDOW_KB", str(kb))
+        for form, env in (("bgzf", {"SCG_DEVICE_INFLATE": "2"}), ("plain", {}), ("bgzf", {"SCG_DEVICE_INFLATE": "0"}), ("plain", {"SCG_HOST_SCAN": "0"})):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            got, n = sc.count_single_barcodes(paths[form], TEMPLATE, 2, pool, 1, True, 4)
+            assert n == total and np.array_equal(got, exp), (kb, form, env)
+            for k in env:
+                monkeypatch.delenv(k)
