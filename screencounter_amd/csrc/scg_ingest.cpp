@@ -7,6 +7,7 @@
 #include <condition_variable>
 #include <cstdio>
 #include <cstring>
+#include <dlfcn.h>
 #include <exception>
 #include <fcntl.h>
 #include <mutex>
@@ -148,7 +149,8 @@ size_t find_cut(const char* data, size_t len, size_t slack = size_t(1) << 20) {
 struct MappedFile {
     int fd = -1;
     const char* data = nullptr;
-    size_t size = 0;
+    size_t size = 0;          // bytes of content
+    size_t mapped = 0;        // bytes of the mapping (>= size for an adopted anonymous one)
     explicit MappedFile(const char* path) {
         fd = ::open(path, O_RDONLY);
         if (fd < 0) throw Error(SCG_ERR_IO, std::string("failed to open file at '") + path + "'");
@@ -160,10 +162,14 @@ struct MappedFile {
             if (m == MAP_FAILED) { ::close(fd); throw Error(SCG_ERR_IO, "failed to map the FASTQ file"); }
             ::madvise(m, size, MADV_SEQUENTIAL);
             data = static_cast<const char*>(m);
+            mapped = size;
         }
     }
+    // Adopts an anonymous mapping of `reserved` bytes holding `content` bytes of text.
+    MappedFile(char* anonymous, size_t reserved, size_t content) : data(anonymous), size(content), mapped(reserved) {}
+    MappedFile(MappedFile&& o) noexcept : fd(o.fd), data(o.data), size(o.size), mapped(o.mapped) { o.fd = -1; o.data = nullptr; o.size = o.mapped = 0; }
     ~MappedFile() {
-        if (data) ::munmap(const_cast<char*>(data), size);
+        if (data && mapped) ::munmap(const_cast<char*>(data), mapped);
         if (fd >= 0) ::close(fd);
     }
     MappedFile(const MappedFile&) = delete;
@@ -201,9 +207,12 @@ class PlainSource : public TextSource {
         if (!take) odd = true;
         return take;
     }
+    const char* what = "plain";
 public:
     PlainSource(const char* path, int nthreads) : f(path), pool(nthreads) { threads = nthreads; }
-    const char* kind() const override { return "plain"; }
+    // text that already lies in memory (a gzip file inflated whole): consumed pages are given back as the windows go by
+    PlainSource(MappedFile&& text, int nthreads, const char* kind_name) : f(std::move(text)), pool(nthreads), what(kind_name) { threads = nthreads; }
+    const char* kind() const override { return what; }
     uint64_t size_hint() const override { return f.size - pos; }
     size_t next(char* dst, size_t cap) override {
         bool pad;
@@ -354,7 +363,45 @@ bool bgzf_member(const char* data, size_t size, size_t off, BgzfMember& m) {
     return true;
 }
 
+// libdeflate (whole-buffer DEFLATE, 2-3 x zlib's inflate) is part of this image as a shared library without headers;
+// it is looked up at run time and used for the members it accepts (CRC and size checked by it, all input consumed);
+// anything else -- and everything when it is absent or SCG_LIBDEFLATE=0 -- is zlib's, whose verdict and message count.
+struct Libdeflate {
+    void* (*alloc)() = nullptr;
+    void (*release)(void*) = nullptr;
+    int (*gzip_ex)(void*, const void*, size_t, void*, size_t, size_t*, size_t*) = nullptr;
+    Libdeflate() {
+        void* h = ::dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
+        if (!h) return;
+        alloc = reinterpret_cast<void* (*)()>(::dlsym(h, "libdeflate_alloc_decompressor"));
+        release = reinterpret_cast<void (*)(void*)>(::dlsym(h, "libdeflate_free_decompressor"));
+        gzip_ex = reinterpret_cast<int (*)(void*, const void*, size_t, void*, size_t, size_t*, size_t*)>(::dlsym(h, "libdeflate_gzip_decompress_ex"));
+        if (!alloc || !release || !gzip_ex) alloc = nullptr;
+    }
+    bool usable() const {
+        const char* e = std::getenv("SCG_LIBDEFLATE");
+        return alloc != nullptr && !(e && *e == '0');
+    }
+};
+const Libdeflate& libdeflate() {
+    static const Libdeflate* L = new Libdeflate;      // (never unloaded)
+    return *L;
+}
+struct ThreadDecompressor {
+    void* d = nullptr;
+    ~ThreadDecompressor() { if (d) libdeflate().release(d); }
+};
+
 void inflate_member(const char* src, size_t csize, char* dst, uint32_t isize) {
+    const Libdeflate& L = libdeflate();
+    if (L.usable()) {
+        thread_local ThreadDecompressor td;
+        if (!td.d) td.d = L.alloc();
+        if (td.d) {
+            size_t used = 0, made = 0;
+            if (L.gzip_ex(td.d, src, csize, dst, isize, &used, &made) == 0 && used == csize && made == isize) return;
+        }
+    }
     z_stream zs;
     std::memset(&zs, 0, sizeof(zs));
     if (inflateInit2(&zs, 15 + 16) != Z_OK) throw Error(SCG_ERR_IO, "failed to initialise zlib");
@@ -493,6 +540,41 @@ protected:
     }
 };
 
+// ---- any other gzip file, when it is small enough to be inflated whole: libdeflate needs the complete member and the
+//      complete output buffer, but runs at three times zlib's speed; the text then lies in (anonymous, lazily
+//      committed) memory and is treated like a mapped plain file, record scan by the host threads included.  The limit
+//      ($SCG_GZIP_WHOLE_GB, default 8, 0 = never) bounds the memory this takes; larger files, files libdeflate
+//      declines, and files with anything but whole gzip members in them are streamed through zlib as before ----
+std::unique_ptr<MappedFile> inflate_whole(const char* path) {
+    const Libdeflate& L = libdeflate();
+    if (!L.usable()) return nullptr;
+    size_t limit = size_t(8) << 30;
+    if (const char* e = std::getenv("SCG_GZIP_WHOLE_GB")) limit = static_cast<size_t>(std::max(0.0, std::atof(e)) * double(size_t(1) << 30));
+    MappedFile in(path);
+    if (limit == 0 || in.size < 18) return nullptr;
+    // address space is free: reserve what the most compressible FASTQ could need, commit what is written
+    const size_t cap = std::min(limit, in.size * 24 + (size_t(1) << 20)) + 4096;
+    void* m = ::mmap(nullptr, cap, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+    if (m == MAP_FAILED) return nullptr;
+    void* d = L.alloc();
+    size_t at = 0, made = 0;
+    bool ok = d != nullptr;
+    while (ok && at < in.size) {
+        size_t used = 0, got = 0;
+        const unsigned char* p = reinterpret_cast<const unsigned char*>(in.data) + at;
+        ok = in.size - at >= 18 && p[0] == 0x1f && p[1] == 0x8b &&
+             L.gzip_ex(d, p, in.size - at, static_cast<char*>(m) + made, cap - 4096 - made, &used, &got) == 0 && used > 0;
+        at += used;
+        made += got;
+    }
+    if (d) L.release(d);
+    if (!ok) {                     // (too large, corrupt, trailing bytes ...: zlib's stream decides)
+        ::munmap(m, cap);
+        return nullptr;
+    }
+    return std::unique_ptr<MappedFile>(new MappedFile(static_cast<char*>(m), cap, made));
+}
+
 } // namespace
 
 std::unique_ptr<TextSource> TextSource::open(const char* path, int threads) {
@@ -507,6 +589,9 @@ std::unique_ptr<TextSource> TextSource::open(const char* path, int threads) {
     const bool gz = got == 2 && h[0] == 0x1f && h[1] == 0x8b;      // byteme/magic_numbers.hpp:19-22
     if (!gz) return std::unique_ptr<TextSource>(new PlainSource(path, threads));
     if (BgzfSource::looks_like(path)) return std::unique_ptr<TextSource>(new BgzfSource(path, threads));
+    if (std::unique_ptr<MappedFile> text = inflate_whole(path)) {
+        return std::unique_ptr<TextSource>(new PlainSource(std::move(*text), threads, "gzip"));
+    }
     return std::unique_ptr<TextSource>(new GzipSource(path));
 }
 

@@ -167,7 +167,7 @@ def test_host_record_scan_of_plain_files(sc, tmp_path, window, threads):
         assert nw > 50
 
 
-def test_host_record_scan_declines_what_the_device_scan_declines(sc, tmp_path):
+def test_host_record_scan_declines_what_the_device_scan_declines(sc, tmp_path, monkeypatch):
     from screencounter_amd import _lib
     good = gen.fastq_text(random_reads(random.Random(3), 50))
     cases = {
@@ -186,11 +186,18 @@ def test_host_record_scan_declines_what_the_device_scan_declines(sc, tmp_path):
             with pytest.raises(_lib.ScgError) as e:
                 scan_windows(sc, p, window)
             assert e.value.code == _lib.SCG_ERR_UNSUPPORTED, name
+    # gzip: inflated whole (libdeflate, when the image has it) and scanned like a plain file; streamed through zlib
+    # otherwise, which leaves the record scan to the device
     g = tmp_path / "x.fastq.gz"
-    g.write_bytes(gzip.compress(good))
+    g.write_bytes(gzip.compress(good[:1000]) + gzip.compress(good[1000:]))
+    import ctypes.util
+    if ctypes.util.find_library("deflate"):
+        assert b"\n".join(scan_windows(sc, g, 2048)[0]) == b"\n".join(strict_records(good))
+    monkeypatch.setenv("SCG_LIBDEFLATE", "0")
     with pytest.raises(_lib.ScgError) as e:
         scan_windows(sc, g, 1 << 20)
     assert e.value.code == _lib.SCG_ERR_UNSUPPORTED and "gzip" in str(e.value)
+    monkeypatch.delenv("SCG_LIBDEFLATE")
     e0 = tmp_path / "empty.fastq"
     e0.write_bytes(b"")
     assert scan_windows(sc, e0, 4096) == ([], 0)
