@@ -1139,6 +1139,83 @@ bool device_inflate_strict() {
     return e && *e == '2';
 }
 
+// ---- BGZF members inflated on the device: what the single-end (InflatePipeline) and paired (PairedPipeline) paths share ----
+constexpr size_t INFLATE_GAP = size_t(1) << 20;      // room in front of a window's text for the previous window's partial record
+
+// Text capacity of a device-inflate window: 256 MB (4 000 members in flight), less for small inputs.
+size_t inflate_window_text(uint64_t hint) {
+    size_t w = size_t(256) << 20;
+    if (const char* e = std::getenv("SCG_WINDOW_KB")) { const long kb = std::atol(e); if (kb > 0) w = static_cast<size_t>(kb) << 10; }
+    const uint64_t need = hint + (hint >> 4) + 4096;
+    if (need < w) w = static_cast<size_t>(need);
+    return std::max<size_t>(w, std::getenv("SCG_WINDOW_KB") ? size_t(4) << 10 : scg::TextSource::min_capacity());
+}
+size_t inflate_window_staging(size_t cap_text) { return cap_text / 2 + (size_t(1) << 20); }     // compressed bytes + member table
+size_t inflate_window_slot(size_t cap_text) { return INFLATE_GAP + cap_text + 64; }
+
+// Takes the next members of `src` into slot `s` (staging = its pinned buffer) and enqueues, on the slot's stream:
+// members + table -> HBM, inflate + CRC check behind the gap, then -- once `prev` (the window before, if any) has its
+// record structure -- the carry of prev's partial record into the gap, the record scan, and the copies back of the
+// scan result and the status word.  `reader` is the slot whose carry read this slot's previous text (its `carried`
+// event is waited for before the text is overwritten).  Returns false at the end of the input.
+bool enqueue_inflate_window(scg::TextSource& src, ScanSlot& s, const ScanSlot* prev, const ScanSlot& reader, size_t cap_text, size_t cap_in,
+                            std::vector<scg::CompressedMember>& members, double* t_fill) {
+    const auto f0 = std::chrono::steady_clock::now();
+    // staging: [member table | payloads]; room for one member per 32 bytes of compressed input is never short
+    const size_t slack = scg::inflate_input_slack();
+    const size_t table_cap = (cap_in / 32 / sizeof(scg::InflateMember)) * sizeof(scg::InflateMember);
+    char* const stage = s.text.as<char>();
+    size_t text_bytes = 0;
+    bool last = false;
+    const size_t in_bytes = src.next_members(stage + table_cap, cap_in - table_cap, slack, cap_text, members, text_bytes, last);
+    if (src.unusual()) throw UnusualInput();
+    if (in_bytes == 0) return false;
+    if (members.size() * sizeof(scg::InflateMember) > table_cap) throw UnusualInput();        // (members of < 32 bytes: not a real file)
+    static_assert(sizeof(scg::InflateMember) == sizeof(scg::CompressedMember), "same layout");
+    scg::InflateMember* table = reinterpret_cast<scg::InflateMember*>(stage);
+    for (size_t i = 0; i < members.size(); ++i) {
+        table[i].in_off = static_cast<uint32_t>(table_cap) + members[i].in_off;
+        table[i].in_len = members[i].in_len;
+        table[i].out_off = static_cast<uint32_t>(INFLATE_GAP) + members[i].out_off;
+        table[i].out_len = members[i].out_len;
+        table[i].crc = members[i].crc;
+    }
+    if (t_fill) *t_fill += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - f0).count();
+    const uint32_t n = static_cast<uint32_t>(members.size());
+    HIP_CHECK(hipStreamWaitEvent(s.stream, reader.carried, 0));
+    HIP_CHECK(hipMemsetAsync(s.d_status.p, 0, sizeof(uint32_t), s.stream));
+    HIP_CHECK(hipMemcpyAsync(s.d_in.p, stage, n * sizeof(scg::InflateMember), hipMemcpyHostToDevice, s.stream));
+    HIP_CHECK(hipMemcpyAsync(s.d_in.as<char>() + table_cap, stage + table_cap, in_bytes, hipMemcpyHostToDevice, s.stream));
+    HIP_CHECK(scg::launch_inflate_members(s.d_in.as<uint8_t>(), s.d_in.as<scg::InflateMember>(), n, s.d_text.as<char>(), s.d_status.as<uint32_t>(), s.stream));
+    s.text_bytes = static_cast<uint32_t>(INFLATE_GAP + text_bytes);
+    if (last) {
+        // the reference accepts a final record without its newline: one is appended (a second one is harmless, see inflate_window_records)
+        HIP_CHECK(hipMemsetAsync(s.d_text.as<char>() + s.text_bytes, '\n', 1, s.stream));
+        s.text_bytes += 1;
+    }
+    s.last = last;
+    if (prev) HIP_CHECK(hipStreamWaitEvent(s.stream, prev->scanned, 0));
+    HIP_CHECK(scg::launch_carry_tail(prev ? prev->d_text.as<char>() : nullptr, prev ? prev->B.result : nullptr, prev ? prev->text_bytes : 0u,
+                                     s.d_text.as<char>(), static_cast<uint32_t>(INFLATE_GAP), s.d_status.as<uint32_t>(), s.stream));
+    HIP_CHECK(hipEventRecord(s.carried, s.stream));
+    HIP_CHECK(scg::launch_text_scan(s.d_text.as<char>(), s.text_bytes, s.B, s.stream, true, s.scanned));
+    HIP_CHECK(hipMemcpyAsync(s.h_result.p, s.d_result.p, sizeof(scg::TextScanResult), hipMemcpyDeviceToHost, s.stream));
+    HIP_CHECK(hipMemcpyAsync(s.h_status.p, s.d_status.p, sizeof(uint32_t), hipMemcpyDeviceToHost, s.stream));
+    return true;
+}
+
+// After the slot's stream has been synchronised: the window's records (record 0 is the gap's dummy: count from
+// offsets + 1).  Throws UnusualInput for whatever the host paths have to redo: a member zlib has to look at (corrupt, or
+// in a form the device's decoder declines), a record longer than the gap, anything but ordinary records.
+scg::TextScanResult inflate_window_records(const ScanSlot& s) {
+    if (*s.h_status.as<uint32_t>()) throw UnusualInput();
+    const scg::TextScanResult r = *s.h_result.as<scg::TextScanResult>();
+    if (r.flags || r.n_records == 0) throw UnusualInput();
+    // behind the last whole record of the input: nothing, or the newline appended above
+    if (s.last && s.text_bytes - r.cut > 1) throw UnusualInput();
+    return r;
+}
+
 // The single-end pipeline for BGZF input with the members inflated on the device (scg_inflate.hip).  Per window, on
 // the slot's stream: compressed members + their table -> HBM; inflate + CRC check into the text buffer behind a gap of
 // GAP bytes; then -- once the previous window has been scanned -- the gap receives that window's partial last record
@@ -1146,17 +1223,10 @@ bool device_inflate_strict() {
 // up to three windows overlap; only the carry chains the windows.  One device.
 class InflatePipeline {
 public:
-    static constexpr size_t GAP = size_t(1) << 20;
     InflatePipeline(scg::TextSource& source, int dev) : src(source), device(dev) {
-        // windows of 256 MB of text (4 000 members in flight per window), less for small inputs
-        size_t w = size_t(256) << 20;
-        if (const char* e = std::getenv("SCG_WINDOW_KB")) { const long kb = std::atol(e); if (kb > 0) w = static_cast<size_t>(kb) << 10; }
-        const uint64_t need = source.size_hint() + (source.size_hint() >> 4) + 4096;
-        if (need < w) w = static_cast<size_t>(need);
-        w = std::max<size_t>(w, std::getenv("SCG_WINDOW_KB") ? size_t(4) << 10 : scg::TextSource::min_capacity());
-        cap_text = w;
-        window = GAP + cap_text + 64;
-        cap_in = cap_text / 2 + (size_t(1) << 20);          // compressed bytes + member table of a window
+        cap_text = inflate_window_text(source.size_hint());
+        window = inflate_window_slot(cap_text);
+        cap_in = inflate_window_staging(cap_text);
         for (int k = 0; k < 3; ++k) {
             slots.push_back(slot_pool().take(device, window, cap_in));
             slots.back()->ensure_inflate();
@@ -1213,51 +1283,11 @@ private:
         if (s.pending) finish_next();
         const auto b0 = std::chrono::steady_clock::now();
         if (s.busy) { HIP_CHECK(hipStreamSynchronize(s.stream)); s.busy = false; }
-        const auto f0 = std::chrono::steady_clock::now();
-        t_busy += std::chrono::duration<double, std::milli>(f0 - b0).count();
-        // staging: [member table | payloads]; the table's size is not known before the members are, so it takes the
-        // end of the buffer's first part: room for one member per 32 bytes of compressed input is never short
-        const size_t slack = scg::inflate_input_slack();
-        const size_t table_cap = (cap_in / 32 / sizeof(scg::InflateMember)) * sizeof(scg::InflateMember);
-        char* const stage = s.text.as<char>();
-        size_t text_bytes = 0;
-        bool last = false;
-        const size_t in_bytes = src.next_members(stage + table_cap, cap_in - table_cap, slack, cap_text, members, text_bytes, last);
-        if (src.unusual()) throw UnusualInput();
-        if (in_bytes == 0) { ended = true; return; }
-        if (members.size() * sizeof(scg::InflateMember) > table_cap) throw UnusualInput();        // (members of < 32 bytes: not a real file)
-        static_assert(sizeof(scg::InflateMember) == sizeof(scg::CompressedMember), "same layout");
-        scg::InflateMember* table = reinterpret_cast<scg::InflateMember*>(stage);
-        for (size_t i = 0; i < members.size(); ++i) {
-            table[i].in_off = static_cast<uint32_t>(table_cap) + members[i].in_off;
-            table[i].in_len = members[i].in_len;
-            table[i].out_off = static_cast<uint32_t>(GAP) + members[i].out_off;
-            table[i].out_len = members[i].out_len;
-            table[i].crc = members[i].crc;
-        }
-        t_fill += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - f0).count();
-        const uint32_t n = static_cast<uint32_t>(members.size());
+        t_busy += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - b0).count();
         const ScanSlot* prev = filled ? slots[(filled - 1) % slots.size()].get() : nullptr;
-        ScanSlot& next = *slots[(filled + 1) % slots.size()];        // the window after this slot's previous one read its tail from here
-        HIP_CHECK(hipStreamWaitEvent(s.stream, next.carried, 0));
-        HIP_CHECK(hipMemsetAsync(s.d_status.p, 0, sizeof(uint32_t), s.stream));
-        HIP_CHECK(hipMemcpyAsync(s.d_in.p, stage, n * sizeof(scg::InflateMember), hipMemcpyHostToDevice, s.stream));
-        HIP_CHECK(hipMemcpyAsync(s.d_in.as<char>() + table_cap, stage + table_cap, in_bytes, hipMemcpyHostToDevice, s.stream));
-        HIP_CHECK(scg::launch_inflate_members(s.d_in.as<uint8_t>(), s.d_in.as<scg::InflateMember>(), n, s.d_text.as<char>(), s.d_status.as<uint32_t>(), s.stream));
-        s.text_bytes = static_cast<uint32_t>(GAP + text_bytes);
-        if (last) {
-            // the reference accepts a final record without its newline: one is appended (a second one is harmless, see finish_next)
-            HIP_CHECK(hipMemsetAsync(s.d_text.as<char>() + s.text_bytes, '\n', 1, s.stream));
-            s.text_bytes += 1;
-        }
-        s.last = last;
-        if (prev) HIP_CHECK(hipStreamWaitEvent(s.stream, prev->scanned, 0));
-        HIP_CHECK(scg::launch_carry_tail(prev ? prev->d_text.as<char>() : nullptr, prev ? prev->B.result : nullptr, prev ? prev->text_bytes : 0u,
-                                         s.d_text.as<char>(), static_cast<uint32_t>(GAP), s.d_status.as<uint32_t>(), s.stream));
-        HIP_CHECK(hipEventRecord(s.carried, s.stream));
-        HIP_CHECK(scg::launch_text_scan(s.d_text.as<char>(), s.text_bytes, s.B, s.stream, true, s.scanned));
-        HIP_CHECK(hipMemcpyAsync(s.h_result.p, s.d_result.p, sizeof(scg::TextScanResult), hipMemcpyDeviceToHost, s.stream));
-        HIP_CHECK(hipMemcpyAsync(s.h_status.p, s.d_status.p, sizeof(uint32_t), hipMemcpyDeviceToHost, s.stream));
+        const ScanSlot& next = *slots[(filled + 1) % slots.size()];  // the window after this slot's previous one read its tail from here
+        if (!enqueue_inflate_window(src, s, prev, next, cap_text, cap_in, members, &t_fill)) { ended = true; return; }
+        const bool last = s.last;
         s.parsed = false;
         s.pending = true;
         ++filled;
@@ -1272,15 +1302,7 @@ private:
         t_finish += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - f1).count();
         s.pending = false;
         ++finished;
-        // a member zlib has to look at (corrupt, or in a form this decoder declines), a record longer than the gap,
-        // anything but ordinary records: the host paths redo the file
-        if (*s.h_status.as<uint32_t>()) throw UnusualInput();
-        const scg::TextScanResult r = *s.h_result.as<scg::TextScanResult>();
-        if (r.flags || r.n_records == 0) throw UnusualInput();
-        if (s.last) {
-            // behind the last whole record: nothing, or the newline appended above
-            if (s.text_bytes - r.cut > 1) throw UnusualInput();
-        }
+        const scg::TextScanResult r = inflate_window_records(s);
         if (r.n_records > 1) {                                       // record 0 is the gap's dummy
             launch_batch(s.plan, make_reads(s.B.seqs, s.B.offsets + 1, 0, static_cast<int32_t>(std::min<uint32_t>(r.max_len, 1u << 30))),
                          static_cast<int64_t>(r.n_records - 1), s.stream);
@@ -1310,7 +1332,11 @@ struct MateWindows {
     hipEvent_t used[2] = {nullptr, nullptr};// the last kernel reading slot k has been enqueued before this event
     hipEvent_t ready = nullptr;             // the current window has arrived in HBM
     bool host_scan = false, done = false, fresh = false;
+    bool inflate = false;                   // BGZF mate, members inflated on the device (enqueue_inflate_window)
+    bool any = false;                       // (inflate) a window has been taken before: its partial last record is carried on
+    size_t cap_text = 0, cap_in = 0;        // (inflate) window sizes
     int cur = 1;
+    uint32_t first = 0;                     // records of the current window start at offsets[first] (1 behind a gap's dummy record)
     uint32_t n = 0, k = 0, max_len = 0;     // records in the current window, of which k have been paired
     uint32_t remaining() const { return n - k; }
     ~MateWindows() {
@@ -1321,21 +1347,34 @@ struct MateWindows {
 
 class PairedPipeline {
 public:
-    PairedPipeline(int dev, scg::TextSource& src1, scg::TextSource& src2)
+    // device_inflate: BGZF mates may have their members inflated on the device (false: by the host threads)
+    PairedPipeline(int dev, scg::TextSource& src1, scg::TextSource& src2, bool device_inflate)
         : device(dev), window(std::max(scan_window_bytes(src1.size_hint()), scan_window_bytes(src2.size_hint()))) {
         DeviceGuard g(device);
         mate[0].src = &src1; mate[1].src = &src2;
         HIP_CHECK(hipStreamCreateWithFlags(&compute, hipStreamNonBlocking));
         for (auto& m : mate) {
             m.host_scan = m.src->parses() && host_scan_enabled();
+            m.inflate = device_inflate && m.src->has_members() && device_inflate_enabled();
+            if (m.inflate) {
+                m.cap_text = inflate_window_text(m.src->size_hint());
+                m.cap_in = inflate_window_staging(m.cap_text);
+            }
             for (int k = 0; k < 2; ++k) {
-                m.slot[k] = slot_pool().take(device, window);
+                if (m.inflate) {
+                    m.slot[k] = slot_pool().take(device, inflate_window_slot(m.cap_text), m.cap_in);
+                    m.slot[k]->ensure_inflate();
+                } else {
+                    m.slot[k] = slot_pool().take(device, window);
+                }
                 HIP_CHECK(hipEventCreateWithFlags(&m.used[k], hipEventDisableTiming));
             }
             HIP_CHECK(hipEventCreateWithFlags(&m.ready, hipEventDisableTiming));
+            any_inflate |= m.inflate;
         }
         tr.mark("  scan slots (pinned + HBM)");
     }
+    bool inflates() const { return any_inflate; }
     ~PairedPipeline() {
         int prev = -1;
         if (hipGetDevice(&prev) == hipSuccess && prev != device) (void)hipSetDevice(device); else prev = -1;
@@ -1367,6 +1406,13 @@ public:
                 const auto w0 = std::chrono::steady_clock::now();
                 HIP_CHECK(hipStreamSynchronize(s.stream));
                 t_wait += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
+                if (m.inflate) {
+                    const scg::TextScanResult r = inflate_window_records(s);
+                    m.n = r.n_records - 1;                            // record 0 is the gap's dummy
+                    m.first = 1;
+                    m.max_len = r.max_len;
+                    continue;
+                }
                 const scg::TextScanResult r = *s.h_result.as<scg::TextScanResult>();
                 if (r.flags) throw UnusualInput();
                 m.n = r.n_records;
@@ -1387,7 +1433,7 @@ public:
                 MateWindows& m = mate[i];
                 const ScanSlot& s = *m.slot[m.cur];
                 HIP_CHECK(hipStreamWaitEvent(compute, m.ready, 0));
-                R[i] = make_reads(s.B.seqs, s.B.offsets + m.k, 0, max_len);
+                R[i] = make_reads(s.B.seqs, s.B.offsets + m.first + m.k, 0, max_len);
             }
             launch_batch_paired(P, R[0], R[1], static_cast<int64_t>(np), compute);
             for (auto& m : mate) {
@@ -1406,7 +1452,8 @@ private:
     size_t window;
     MateWindows mate[2];
     hipStream_t compute = nullptr;
-    bool ok = false, advanced = false;
+    bool ok = false, advanced = false, any_inflate = false;
+    std::vector<scg::CompressedMember> members;
     Trace tr;
     double t_fill = 0, t_wait = 0;
 
@@ -1421,6 +1468,20 @@ private:
             HIP_CHECK(hipEventSynchronize(m.used[m.cur]));        // its previous content is no longer being read
             const auto f0 = std::chrono::steady_clock::now();
             t_wait += std::chrono::duration<double, std::milli>(f0 - w0).count();
+            if (m.inflate) {
+                // the window before lies in the mate's other slot: its partial last record is carried over on the device
+                const ScanSlot& other = *m.slot[m.cur ^ 1];
+                m.n = m.k = 0;
+                m.first = 1;
+                if (!enqueue_inflate_window(*m.src, s, m.any ? &other : nullptr, other, m.cap_text, m.cap_in, members, &t_fill)) {
+                    m.done = true;
+                    continue;
+                }
+                m.any = true;
+                m.fresh = true;
+                HIP_CHECK(hipEventRecord(m.ready, s.stream));
+                continue;
+            }
             scg::ParsedWindow w;
             const size_t bytes = m.host_scan ? m.src->next_parsed(s.text.as<char>(), s.cap, s.h_offsets.as<uint32_t>(), s.B.cap_records + 1, w)
                                              : m.src->next(s.text.as<char>(), s.cap);
@@ -1876,16 +1937,35 @@ void count_paired_host(scg_plan* P, const char* path1, const char* path2, scg::F
     st.drain();
 }
 
-void count_paired_files(scg_plan* P, const char* path1, const char* path2, scg::FastqStream& fq1, scg::FastqStream& fq2, int nthreads) {
+void count_paired_files(scg_plan* P, const char* path1, const char* path2, scg::FastqStream& fq1, scg::FastqStream& fq2, int nthreads,
+                        bool try_device_inflate = true) {
     if (device_scan_enabled()) {
         // ordinary files: windows of sequences paired on the device (PairedPipeline); anything else: the host readers
         bool done = false;
         try {
             const int threads = scg::default_host_threads(nthreads);
             std::unique_ptr<scg::TextSource> s1 = scg::TextSource::open(path1, threads), s2 = scg::TextSource::open(path2, threads);
-            PairedPipeline pipe(P->device, *s1, *s2);
-            pipe.run(P);
-            done = true;
+            bool device_inflate = try_device_inflate;
+            for (;;) {
+                {
+                    PairedPipeline pipe(P->device, *s1, *s2, device_inflate);
+                    const bool retry = pipe.inflates();
+                    try {
+                        pipe.run(P);
+                        done = true;
+                    } catch (const UnusualInput&) {
+                        if (!retry) throw;
+                        if (device_inflate_strict()) inflate_declined();
+                    }
+                }
+                if (done) break;
+                // a BGZF mate the device handed back: once more with the host threads' zlib (the pipeline is gone: its
+                // kernels have finished)
+                reset_plan(P);
+                s1 = scg::TextSource::open(path1, threads);
+                s2 = scg::TextSource::open(path2, threads);
+                device_inflate = false;
+            }
         } catch (const UnusualInput&) {
             reset_plan(P);
         }
@@ -1914,7 +1994,7 @@ std::unique_ptr<scg_plan> compile_and_count_paired(const char* path1, const char
             const int threads = scg::default_host_threads(nthreads);
             s1 = scg::TextSource::open(path1, threads);
             s2 = scg::TextSource::open(path2, threads);
-            pipe.reset(new PairedPipeline(device, *s1, *s2));
+            pipe.reset(new PairedPipeline(device, *s1, *s2, true));
             pipe->start();
         }
     } catch (const UnusualInput&) {
@@ -1930,18 +2010,24 @@ std::unique_ptr<scg_plan> compile_and_count_paired(const char* path1, const char
     P->to_device(device);
     DeviceGuard g(P->device);
     tr.mark("upload to device");
-    bool done = false;
+    bool done = false, inflate_declined_it = false;
     if (pipe) {
         try {
             pipe->run(P.get());
             done = true;
         } catch (const UnusualInput&) {
+            inflate_declined_it = pipe->inflates();
+            if (inflate_declined_it && device_inflate_strict()) inflate_declined();
             pipe.reset();                          // (its kernels have finished before the counters are cleared)
             reset_plan(P.get());
         }
         pipe.reset();
     }
-    if (!done) count_paired_host(P.get(), path1, path2, fq1, fq2, nthreads);
+    if (!done) {
+        // a BGZF mate the device handed back gets the host threads' zlib next; everything else the host readers
+        if (inflate_declined_it) count_paired_files(P.get(), path1, path2, fq1, fq2, nthreads, false);
+        else count_paired_host(P.get(), path1, path2, fq1, fq2, nthreads);
+    }
     tr.mark("count files");
     return P;
 }

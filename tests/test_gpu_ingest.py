@@ -266,10 +266,10 @@ def test_multi_file_entries_equal_per_file_calls(sc, oracle, gpu, tmp_path, monk
         assert tot[c] == tt and np.array_equal(mat[:, c], cc)
 
 
-def test_paired_files_through_the_scan(sc, oracle, gpu, tmp_path, monkeypatch, plain_scan):
+def test_paired_files_through_the_scan(sc, oracle, gpu, tmp_path, monkeypatch, plain_scan, bgzf_inflate):
     """The windows of the two mates hold different numbers of records (names and read lengths differ), so the cursors that
     bring the two streams into step on the device are exercised; mate 1 is plain (scanned by the host threads or the
-    device), mate 2 BGZF (always the device) or plain."""
+    device) or BGZF, mate 2 BGZF (members inflated on the device or by the host threads) or plain."""
     from screencounter_amd import _lib
     rng = random.Random(16)
     t1, t2 = "ACGTAC" + "-" * 10 + "TGCATG", "GGATCC" + "-" * 8 + "AAGCTT"
@@ -292,14 +292,16 @@ def test_paired_files_through_the_scan(sc, oracle, gpu, tmp_path, monkeypatch, p
     gen.write_bgzf(p2, gen.fastq_text(r2, trailing_newline=False), block=2500)
     p2_plain = str(tmp_path / "m2.fastq")
     open(p2_plain, "wb").write(gen.fastq_text(r2, trailing_newline=False))
+    p1_bgzf = str(tmp_path / "m1.fastq.gz")
+    gen.write_bgzf(p1_bgzf, gen.fastq_text(r1, name_prefix="a_rather_long_read_name_"), block=7000)
     for kb in (None, 16, 64):
         if kb:
             monkeypatch.setenv("SCG_WINDOW_KB", str(kb))
         for first in (True, False):
             e, t = (exp, total) if first else oracle.count_dual(r1, r2, t1, False, 1, pool1, t2, False, 1, pool2, False, False)
-            for second in (p2, p2_plain):
-                got, n = sc.count_dual_barcodes(p1, t1, False, 1, pool1, second, t2, False, 1, pool2, False, first, False, 4)
-                assert n == t == len(r1) and np.array_equal(got, e), (kb, first, second)
+            for one, second in ((p1, p2), (p1, p2_plain), (p1_bgzf, p2)):
+                got, n = sc.count_dual_barcodes(one, t1, False, 1, pool1, second, t2, False, 1, pool2, False, first, False, 4)
+                assert n == t == len(r1) and np.array_equal(got, e), (kb, first, one, second)
     # include.invalid = TRUE and randomized through the same pipeline
     d = oracle.count_dual_diag(r1, r2, t1, False, 1, pool1, t2, False, 1, pool2, True, True)
     counts, (idx, freq), tot, b1, b2 = sc.count_dual_barcodes(p1, t1, False, 1, pool1, p2, t2, False, 1, pool2, True, True, True, 4)
@@ -310,6 +312,15 @@ def test_paired_files_through_the_scan(sc, oracle, gpu, tmp_path, monkeypatch, p
     got, n = sc.count_dual_barcodes(p1, t1, False, 1, pool1, p2, t2, False, 1, pool2, False, True, False, 4)
     assert n == total and np.array_equal(got, exp)
     monkeypatch.delenv("SCG_DEVICE_SCAN")
+    # a corrupt member in a BGZF mate: zlib's error, whoever inflated first
+    monkeypatch.setenv("SCG_DEVICE_INFLATE", "0" if bgzf_inflate == "host_inflate" else "1")
+    raw = bytearray(open(p2, "rb").read())
+    raw[len(raw) // 2] ^= 0x04
+    pbad = str(tmp_path / "m2_bad.fastq.gz")
+    open(pbad, "wb").write(bytes(raw))
+    with pytest.raises(_lib.ScgError) as e:
+        sc.count_dual_barcodes(p1, t1, False, 1, pool1, pbad, t2, False, 1, pool2, False, True, False, 4)
+    assert e.value.code == _lib.SCG_ERR_IO
     # unequal numbers of reads: the reference's error
     p3 = str(tmp_path / "short.fastq")
     open(p3, "wb").write(gen.fastq_text(r2[:-7]))
