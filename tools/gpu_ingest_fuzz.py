@@ -42,6 +42,36 @@ def run(path, pool):
         return ("error", e.code, str(e))
 
 
+def run_paired(p1, p2, pool1, pool2):
+    try:
+        c, t = sc.count_dual_barcodes(p1, T1, False, 1, pool1, p2, T2, False, 1, pool2, False, True, False, 4)
+        return ("ok", t, c.tobytes())
+    except _lib.ScgError as e:
+        return ("error", e.code, str(e))
+
+
+T1, T2 = "ACGTAC" + "-" * 10 + "TGCATG", "GGATCC" + "-" * 8 + "AAGCTT"
+
+
+def make_pair(rng):
+    """Two mates of the same (or, now and then, not the same) number of records; ordinary text."""
+    u1, u2 = gen.make_pool(rng, 10, 10, "ACGT", min_dist=3), gen.make_pool(rng, 8, 8, "ACGT", min_dist=3)
+    pairs = [(a, b) for a in u1 for b in u2]
+    rng.shuffle(pairs)
+    pairs = pairs[:40]
+    n = rng.choice([1, 50, 2000, 9000])
+    r1, r2 = [], []
+    for _ in range(n):
+        a, b = rng.choice(pairs) if rng.random() < 0.8 else (rng.choice(u1), rng.choice(u2))
+        r1.append(gen.rand_seq(rng, rng.randint(0, 80)) + gen.mutate(rng, gen.fill_template(T1, [a]), 0.02, 0.01, 0.02))
+        r2.append(gen.rand_seq(rng, rng.randint(0, 8)) + gen.mutate(rng, gen.fill_template(T2, [b]), 0.02, 0.01, 0.02))
+    if rng.random() < 0.15 and n > 3:
+        r2 = r2[:-rng.randint(1, 3)]
+    t1 = gen.fastq_text(r1, name_prefix=rng.choice(["r", "a_much_longer_read_name_"]), trailing_newline=rng.random() < 0.8)
+    t2 = gen.fastq_text(r2, trailing_newline=rng.random() < 0.8)
+    return [a for a, _ in pairs], [b for _, b in pairs], t1, t2
+
+
 def make_text(rng):
     pool = gen.make_pool(rng, 40, 12, "ACGT")
     n = rng.choice([0, 1, 5, 200, 3000, 12000])
@@ -88,6 +118,27 @@ with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") els
         seed = seed0 + it
         it += 1
         rng = random.Random(seed)
+        if it % 4 == 0:
+            pool1, pool2, t1, t2 = make_pair(rng)
+            files = {}
+            for name, text in (("m1", t1), ("m2", t2)):
+                files[name] = os.path.join(tmp, name + ".fastq")
+                open(files[name], "wb").write(text)
+                files[name + "z"] = os.path.join(tmp, name + ".bgzf.gz")
+                gen.write_bgzf(files[name + "z"], text, block=rng.choice([900, 9000, 65280]))
+            set_mode(SCG_DEVICE_SCAN=0)
+            want = run_paired(files["m1"], files["m2"], pool1, pool2)
+            kb = rng.choice([None, 16, 100, 700])
+            for name, a, b, env in (("plain+plain", "m1", "m2", {}), ("bgzf+bgzf device", "m1z", "m2z", {}), ("bgzf+plain host", "m1z", "m2", dict(SCG_DEVICE_INFLATE=0)),
+                                    ("plain+bgzf device scan", "m1", "m2z", dict(SCG_HOST_SCAN=0))):
+                set_mode(SCG_WINDOW_KB=kb, **env)
+                got = run_paired(files[a], files[b], pool1, pool2)
+                if got != want:
+                    print(f"MISMATCH seed {seed} paired mode {name} window_kb {kb}: got {got[:2]} want {want[:2]}", flush=True)
+                    sys.exit(1)
+            key = "paired:" + want[0]
+            tally[key] = tally.get(key, 0) + 1
+            continue
         pool, text, flaw = make_text(rng)
         plain = os.path.join(tmp, "f.fastq")
         open(plain, "wb").write(text)
