@@ -874,7 +874,7 @@ struct ScanSlot {
     int plan_device = -1;
     hipStream_t stream = nullptr;
     PinnedBuf text, h_result, h_offsets;
-    DevBuf d_text, d_counts, d_nl, d_offsets, d_seqs, d_result;
+    DevBuf d_text, d_counts, d_nl, d_offsets, d_seqs, d_result, d_scan;
     scg::TextScanBuffers B;
     size_t cap = 0;
     bool pending = false;      // scan enqueued; the counting kernels still have to be launched
@@ -909,6 +909,8 @@ struct ScanSlot {
         d_offsets.alloc((B.cap_records + 1) * sizeof(uint32_t));
         d_seqs.alloc(B.cap_seq_bytes + 64);
         d_result.alloc(sizeof(scg::TextScanResult));
+        d_scan.alloc(scg::text_scan_scratch(B.cap_blocks, B.cap_records) * sizeof(uint32_t));
+        B.scan_scratch = d_scan.as<uint32_t>();
         B.block_counts = d_counts.as<uint32_t>();
         B.nl = d_nl.as<uint32_t>();
         B.offsets = d_offsets.as<uint32_t>();

@@ -32,11 +32,13 @@ struct TextScanBuffers {
     uint32_t* offsets;        // [cap_records + 1]: out, byte offset of every sequence in `seqs`
     char* seqs;               // [cap_seq_bytes]: out, the sequences back to back
     TextScanResult* result;
+    uint32_t* scan_scratch;   // [text_scan_scratch(cap_blocks, cap_records)]: tile totals of the prefix scans
     size_t cap_blocks, cap_lines, cap_records, cap_seq_bytes;
 };
 
 size_t text_scan_blocks(size_t n_bytes);    // text tiles of a window
 size_t text_scan_padded(size_t n_bytes);    // device text buffers must be readable up to this many bytes
+size_t text_scan_scratch(size_t cap_blocks, size_t cap_records);   // entries of TextScanBuffers::scan_scratch
 
 // Asynchronous on `stream`.  The text must start at a record start; the last byte of the final window of a file must be
 // a newline (the host appends one when the file lacks it, as the reference accepts a final record without it).

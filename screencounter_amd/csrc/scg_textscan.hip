@@ -57,36 +57,107 @@ __global__ __launch_bounds__(TS_BLOCK) void count_newlines_kernel(const char* __
     }
 }
 
-// In-place exclusive scan of data[0 .. n) by ONE workgroup of 1024 lanes (n is a few hundred thousand at most);
-// data[n] receives the total.  n comes from *n_ptr when n_ptr is given (a count produced by an earlier kernel).
+// In-place exclusive scan of data[0 .. n); data[n] receives the total.  n comes from *n_ptr when n_ptr is given (a
+// count produced by an earlier kernel; the grids are sized for `cap`).  Three small kernels: every workgroup scans a tile
+// of 8 192 elements in place and notes its total; one workgroup scans the totals; every element receives its tile's
+// offset.  (One workgroup doing it all took 1 ms for the 860 k sequence lengths of a 256 MB window -- on the chain
+// that links the windows of a BGZF file.)
 constexpr int SCAN_BLOCK = 1024;
-__global__ __launch_bounds__(SCAN_BLOCK) void exclusive_scan_kernel(uint32_t* __restrict__ data, uint32_t n_fixed, const uint32_t* __restrict__ n_ptr,
-                                                                    uint32_t cap, uint32_t* __restrict__ total_out) {
-    __shared__ uint32_t sums[SCAN_BLOCK];
-    uint32_t n = n_ptr ? *n_ptr : n_fixed;
-    if (n > cap) n = cap;
-    const uint32_t per = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
-    const uint32_t lo = threadIdx.x * per, hi = (lo + per < n) ? lo + per : n;
-    uint32_t s = 0;
-    for (uint32_t i = lo; i < hi; ++i) s += data[i];
-    sums[threadIdx.x] = s;
+constexpr int SCAN_PER_LANE = 8;
+constexpr uint32_t SCAN_TILE = SCAN_BLOCK * SCAN_PER_LANE;
+
+__device__ __forceinline__ uint32_t scan_count(uint32_t n_fixed, const uint32_t* n_ptr, uint32_t cap) {
+    const uint32_t n = n_ptr ? *n_ptr : n_fixed;
+    return n > cap ? cap : n;
+}
+
+// Exclusive scan over the workgroup of one value per lane; *total = the sum.
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* total) {
+    __shared__ uint32_t wave_sum[SCAN_BLOCK / 64];
+    __shared__ uint32_t all;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = v;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
+    }
+    if (lane == 63) wave_sum[wave] = incl;
     __syncthreads();
-    for (int off = 1; off < SCAN_BLOCK; off <<= 1) {                 // Hillis-Steele over the 1024 partial sums
-        uint32_t v = threadIdx.x >= (unsigned)off ? sums[threadIdx.x - off] : 0;
+    if (wave == 0) {
+        uint32_t w = lane < SCAN_BLOCK / 64 ? wave_sum[lane] : 0u, wi = w;
+        for (int off = 1; off < SCAN_BLOCK / 64; off <<= 1) {
+            const uint32_t o = __shfl_up(wi, off, 64);
+            if (lane >= off) wi += o;
+        }
+        if (lane < SCAN_BLOCK / 64) wave_sum[lane] = wi - w;            // exclusive over the wavefronts
+        if (lane == SCAN_BLOCK / 64 - 1) all = wi;
+    }
+    __syncthreads();
+    *total = all;
+    return wave_sum[wave] + incl - v;
+}
+
+__global__ __launch_bounds__(SCAN_BLOCK) void scan_tiles_kernel(uint32_t* __restrict__ data, uint32_t n_fixed, const uint32_t* __restrict__ n_ptr, uint32_t cap,
+                                                                uint32_t* __restrict__ tile_sums) {
+    const uint32_t n = scan_count(n_fixed, n_ptr, cap);
+    const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_PER_LANE;
+    if (blockIdx.x * SCAN_TILE >= n) return;                             // (whole workgroup)
+    uint32_t v[SCAN_PER_LANE], sum = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_PER_LANE; ++k) {
+        v[k] = base + k < n ? data[base + k] : 0u;
+        sum += v[k];
+    }
+    uint32_t total;
+    uint32_t run = block_exclusive_scan(sum, &total);
+#pragma unroll
+    for (int k = 0; k < SCAN_PER_LANE; ++k) {
+        if (base + k < n) data[base + k] = run;
+        run += v[k];
+    }
+    if (threadIdx.x == 0) tile_sums[blockIdx.x] = total;
+}
+
+// Exclusive scan of the tile totals (one workgroup; a window has a few hundred tiles), the grand total to data[n] and *total_out.
+__global__ __launch_bounds__(SCAN_BLOCK) void scan_sums_kernel(uint32_t* __restrict__ data, uint32_t n_fixed, const uint32_t* __restrict__ n_ptr, uint32_t cap,
+                                                               uint32_t* __restrict__ tile_sums, uint32_t* __restrict__ total_out) {
+    const uint32_t n = scan_count(n_fixed, n_ptr, cap);
+    const uint32_t tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+    uint32_t carry = 0;
+    for (uint32_t t0 = 0; t0 < tiles; t0 += SCAN_BLOCK) {               // (uniform trip count)
+        const uint32_t t = t0 + threadIdx.x;
+        const uint32_t v = t < tiles ? tile_sums[t] : 0u;
+        uint32_t total;
+        const uint32_t ex = block_exclusive_scan(v, &total);
+        if (t < tiles) tile_sums[t] = carry + ex;
+        carry += total;
         __syncthreads();
-        sums[threadIdx.x] += v;
-        __syncthreads();
     }
-    uint32_t run = threadIdx.x ? sums[threadIdx.x - 1] : 0;
-    for (uint32_t i = lo; i < hi; ++i) {
-        const uint32_t v = data[i];
-        data[i] = run;
-        run += v;
+    if (threadIdx.x == 0) {
+        data[n] = carry;
+        if (total_out) *total_out = carry;
     }
-    if (threadIdx.x == SCAN_BLOCK - 1) {
-        data[n] = sums[SCAN_BLOCK - 1];
-        if (total_out) *total_out = sums[SCAN_BLOCK - 1];
-    }
+}
+
+__global__ __launch_bounds__(SCAN_BLOCK) void add_sums_kernel(uint32_t* __restrict__ data, uint32_t n_fixed, const uint32_t* __restrict__ n_ptr, uint32_t cap,
+                                                              const uint32_t* __restrict__ tile_sums) {
+    const uint32_t n = scan_count(n_fixed, n_ptr, cap);
+    if (blockIdx.x == 0 || blockIdx.x * SCAN_TILE >= n) return;          // (tile 0 has nothing to add)
+    const uint32_t add = tile_sums[blockIdx.x];
+    const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_PER_LANE;
+#pragma unroll
+    for (int k = 0; k < SCAN_PER_LANE; ++k) if (base + k < n) data[base + k] += add;
+}
+
+// (stream-ordered) data[0 .. n) -> exclusive prefix sums, data[n] = total; n = *n_ptr (clamped to cap) or n_fixed.
+hipError_t launch_exclusive_scan(uint32_t* data, uint32_t n_fixed, const uint32_t* n_ptr, uint32_t cap, uint32_t* tile_sums, uint32_t* total_out,
+                                 hipStream_t stream) {
+    const uint32_t bound = n_ptr ? cap : (n_fixed < cap ? n_fixed : cap);
+    const unsigned tiles = bound ? (bound + SCAN_TILE - 1) / SCAN_TILE : 1;
+    hipLaunchKernelGGL(scan_tiles_kernel, dim3(tiles), dim3(SCAN_BLOCK), 0, stream, data, n_fixed, n_ptr, cap, tile_sums);
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(SCAN_BLOCK), 0, stream, data, n_fixed, n_ptr, cap, tile_sums, total_out);
+    hipLaunchKernelGGL(add_sums_kernel, dim3(tiles), dim3(SCAN_BLOCK), 0, stream, data, n_fixed, n_ptr, cap, (const uint32_t*)tile_sums);
+    return hipGetLastError();
 }
 
 // nl[k] = byte position of the k-th newline of the window.
@@ -228,6 +299,10 @@ hipError_t launch_gather_segments(char* seqs, uint32_t* offsets, const GatherSeg
     return hipGetLastError();
 }
 
+size_t text_scan_scratch(size_t cap_blocks, size_t cap_records) {
+    const size_t n = cap_blocks > cap_records ? cap_blocks : cap_records;
+    return (n + SCAN_TILE - 1) / SCAN_TILE + 2;
+}
 size_t text_scan_blocks(size_t n_bytes) { return (n_bytes + TS_TILE - 1) / TS_TILE; }
 size_t text_scan_padded(size_t n_bytes) { return text_scan_blocks(n_bytes) * TS_TILE; }
 
@@ -238,7 +313,8 @@ hipError_t launch_text_scan(const char* d_text, size_t n_bytes, const TextScanBu
     const unsigned blocks = (unsigned)text_scan_blocks(n_bytes);
     if (blocks + 1 > B.cap_blocks) return hipErrorInvalidValue;
     hipLaunchKernelGGL(count_newlines_kernel, dim3(blocks), dim3(TS_BLOCK), 0, stream, d_text, (uint64_t)n_bytes, B.block_counts);
-    hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(SCAN_BLOCK), 0, stream, B.block_counts, blocks, (const uint32_t*)nullptr, blocks, &B.result->n_lines);
+    e = launch_exclusive_scan(B.block_counts, blocks, nullptr, blocks, B.scan_scratch, &B.result->n_lines, stream);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(newline_positions_kernel, dim3(blocks), dim3(TS_BLOCK), 0, stream, d_text, (uint64_t)n_bytes, B.block_counts, B.nl, (uint32_t)B.cap_lines);
     const unsigned rec_blocks = (unsigned)((B.cap_records + TS_BLOCK - 1) / TS_BLOCK);
     // a window holds at most n_bytes / 6 records (six bytes is the shortest 4-line record): never launch more lanes than that
@@ -249,7 +325,8 @@ hipError_t launch_text_scan(const char* d_text, size_t n_bytes, const TextScanBu
         e = hipEventRecord(structure_known, stream);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(SCAN_BLOCK), 0, stream, B.offsets, 0u, &B.result->n_records, (uint32_t)B.cap_records, (uint32_t*)nullptr);
+    e = launch_exclusive_scan(B.offsets, 0u, &B.result->n_records, (uint32_t)B.cap_records, B.scan_scratch, nullptr, stream);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(compact_kernel, dim3(2048), dim3(TS_BLOCK), 0, stream, d_text, B.nl, B.offsets, B.seqs, (uint64_t)B.cap_seq_bytes, B.result);
     return hipGetLastError();
 }
