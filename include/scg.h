@@ -242,6 +242,16 @@ int scg_fastq_scan_windows(const char* path, int64_t window_bytes, int nthreads,
                            char** seqs_out, uint64_t** offsets_out, int64_t* n_reads_out, int64_t* n_windows_out,
                            char* err, size_t errcap);
 
+/* The host's part of the BGZF staging (host only, no device needed): the batches of gzip members whose raw DEFLATE
+ * payloads the file-level entry points ship to the GPU, where one wavefront inflates one member.  A batch takes at most
+ * staging_bytes of payloads and text_bytes of inflated text.  *table_out: 6 uint32 per member -- batch index, payload
+ * offset within *payloads_out, payload length, text offset within its batch, text length (ISIZE), CRC-32 of the text;
+ * *payloads_out: the payloads of all batches back to back.  Release both with scg_free.  SCG_ERR_UNSUPPORTED for input
+ * that is not BGZF or whose members carry header fields other than the BGZF extra field. */
+int scg_bgzf_member_batches(const char* path, int64_t staging_bytes, int64_t text_bytes, int nthreads,
+                            uint32_t** table_out, int64_t* n_members_out, char** payloads_out, int64_t* n_payload_bytes_out,
+                            int64_t* n_batches_out, char* err, size_t errcap);
+
 /* ---------------------------------------------------------------------------------------------
  * Plans: a compiled (template, library, options) bound to one device, reusable across batches.
  * Replaces the construction of kaori::SingleBarcodeSingleEnd / CombinatorialBarcodesSingleEnd /

@@ -70,6 +70,8 @@ SIGNATURES = {
                                          C.c_char_p, C.c_char_p, C.c_size_t]),
     "scg_fastq_scan_windows": (C.c_int, [C.c_char_p, C.c_int64, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), i64_p, i64_p,
                                          C.c_char_p, C.c_size_t]),
+    "scg_bgzf_member_batches": (C.c_int, [C.c_char_p, C.c_int64, C.c_int64, C.c_int, C.POINTER(C.c_void_p), i64_p, C.POINTER(C.c_void_p), i64_p, i64_p,
+                                          C.c_char_p, C.c_size_t]),
     "scg_free": (None, [C.c_void_p]),
     "scg_release_buffers": (None, []),
     "scg_parse_fastq": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), i64_p, C.c_char_p, C.c_size_t]),

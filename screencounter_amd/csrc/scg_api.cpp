@@ -2149,6 +2149,44 @@ int scg_fastq_scan_windows(const char* path, int64_t window_bytes, int nthreads,
     });
 }
 
+int scg_bgzf_member_batches(const char* path, int64_t staging_bytes, int64_t text_bytes, int nthreads, uint32_t** table_out, int64_t* n_members_out,
+                            char** payloads_out, int64_t* n_payload_bytes_out, int64_t* n_batches_out, char* err, size_t errcap) {
+    return guarded(err, errcap, [&] {
+        if (!path || !table_out || !n_members_out || !payloads_out || !n_payload_bytes_out || !n_batches_out || staging_bytes < 64 || text_bytes < 1) {
+            throw Error(SCG_ERR_INVALID, "null argument");
+        }
+        std::unique_ptr<scg::TextSource> src = scg::TextSource::open(path, scg::default_host_threads(nthreads));
+        if (!src->has_members()) throw Error(SCG_ERR_UNSUPPORTED, std::string("no member batches for ") + src->kind() + " input");
+        const size_t slack = scg::inflate_input_slack();
+        std::vector<char> staging(static_cast<size_t>(staging_bytes) + slack), all;
+        std::vector<uint32_t> table;
+        std::vector<scg::CompressedMember> members;
+        int64_t batches = 0;
+        for (;;) {
+            size_t text = 0;
+            bool last = false;
+            const size_t got = src->next_members(staging.data(), staging.size(), slack, static_cast<size_t>(text_bytes), members, text, last);
+            if (src->unusual()) throw Error(SCG_ERR_UNSUPPORTED, "a member the device inflater does not take (not BGZF throughout, extra header fields, or larger than a batch)");
+            if (!got) break;
+            for (const scg::CompressedMember& m : members) {
+                const uint32_t row[6] = {static_cast<uint32_t>(batches), static_cast<uint32_t>(all.size() + m.in_off), m.in_len, m.out_off, m.out_len, m.crc};
+                table.insert(table.end(), row, row + 6);
+            }
+            all.insert(all.end(), staging.begin(), staging.begin() + static_cast<long>(got - slack));
+            ++batches;
+            if (last) break;
+        }
+        uint32_t* t = static_cast<uint32_t*>(std::malloc(sizeof(uint32_t) * (table.size() + 1)));
+        char* p = static_cast<char*>(std::malloc(all.size() + 1));
+        if (!t || !p) { std::free(t); std::free(p); throw std::bad_alloc(); }
+        if (!table.empty()) std::memcpy(t, table.data(), sizeof(uint32_t) * table.size());
+        if (!all.empty()) std::memcpy(p, all.data(), all.size());
+        *table_out = t; *n_members_out = static_cast<int64_t>(table.size() / 6);
+        *payloads_out = p; *n_payload_bytes_out = static_cast<int64_t>(all.size());
+        *n_batches_out = batches;
+    });
+}
+
 int scg_set_device(int device, char* err, size_t errcap) {
     return guarded(err, errcap, [&] {
         int n = 0;

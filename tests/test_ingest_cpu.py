@@ -205,3 +205,60 @@ def test_host_record_scan_declines_what_the_device_scan_declines(sc, tmp_path, m
     crlf = tmp_path / "crlf.fastq"
     crlf.write_bytes(b"@r1\r\nACGT\r\n+\r\nIIII\r\n@r2\r\nGG\r\n+\r\nII\r\n")
     assert scan_windows(sc, crlf, 4096)[0] == [b"ACGT\r", b"GG\r"]
+
+
+def member_batches(sc, path, staging, text, threads=4):
+    """scg_bgzf_member_batches -> (rows of (batch, payload offset, payload length, text offset, text length, crc), payload bytes, batches)."""
+    from screencounter_amd import _lib
+    import numpy as np
+    L = sc.load()
+    table, payloads = C.c_void_p(), C.c_void_p()
+    n, nb, nbatch = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+    err = _lib.errbuf()
+    rc = L.scg_bgzf_member_batches(os.fspath(path).encode(), int(staging), int(text), int(threads), C.byref(table), C.byref(n), C.byref(payloads),
+                                   C.byref(nb), C.byref(nbatch), err, _lib.ERRCAP)
+    if rc:
+        raise _lib.ScgError(rc, err.value.decode())
+    try:
+        rows = np.ctypeslib.as_array(C.cast(table, C.POINTER(C.c_uint32)), shape=(max(n.value, 1) * 6,))[: n.value * 6].reshape(-1, 6).copy()
+        data = C.string_at(payloads, nb.value)
+    finally:
+        L.scg_free(table)
+        L.scg_free(payloads)
+    return rows, data, nbatch.value
+
+
+@pytest.mark.parametrize("block", [700, 20000, 65280])
+def test_bgzf_member_batches_for_the_device_inflater(sc, tmp_path, block):
+    """What the GPU is handed for a BGZF file: every member's raw DEFLATE payload, its place in the batch's text, its
+    size and CRC; batches within the staging and text limits; the text reassembled from the payloads is the file's."""
+    import zlib
+    from screencounter_amd import _lib
+    rng = random.Random(block)
+    text = gen.fastq_text(random_reads(rng, 4000), trailing_newline=False)
+    p = str(tmp_path / "x.bgzf.gz")
+    gen.write_bgzf(p, text, block=block, eof_block=True)
+    staging, limit = 150_000, 200_000
+    rows, data, batches = member_batches(sc, p, staging, limit)
+    assert batches > 3 and len(rows) >= len(text) // block
+    out, at_batch, batch_text = [], -1, 0
+    for b, off, n, toff, tlen, crc in rows.tolist():
+        if b != at_batch:
+            assert b == at_batch + 1 and toff == 0
+            at_batch, batch_text, batch_in = b, 0, 0
+        assert toff == batch_text
+        d = zlib.decompressobj(-15)
+        piece = d.decompress(data[off:off + n]) + d.flush()
+        assert d.eof and d.unused_data == b"" and len(piece) == tlen and (zlib.crc32(piece) & 0xFFFFFFFF) == crc
+        out.append(piece)
+        batch_text += tlen
+        batch_in += n
+        assert batch_text <= limit and batch_in <= staging
+    assert b"".join(out) == text
+    # input the device inflater does not take
+    g = tmp_path / "plain.gz"
+    g.write_bytes(gzip.compress(text))
+    for path, lim in ((g, limit), (p, block // 2 if block > 1000 else 10)):
+        with pytest.raises(_lib.ScgError) as e:
+            member_batches(sc, path, staging, lim)
+        assert e.value.code == _lib.SCG_ERR_UNSUPPORTED
