@@ -635,7 +635,9 @@ ScgScan build_scan(const ScgTemplate& t, int max_mm) {
     // k + 1 disjoint groups of constant positions for a budget of k mismatches; with fewer than
     // k + 1 constant bases (or k + 1 > SCG_MAX_SEEDS) no filter is possible and every position is
     // a candidate.
-    int seed_max = SCG_SEED_LEN;
+    // (9 of the SCG_SEED_LEN = 10 bases a seed may have: measured -1 % on config 2, -2 % on config 3, neutral elsewhere;
+    // 8 costs +11 %: a false candidate then precedes the true one in a third of the wavefronts)
+    int seed_max = SCG_SEED_LEN - 1;
     if (const char* e = std::getenv("SCG_SEED_MAX")) { const int v = std::atoi(e); if (v >= 4 && v <= SCG_SEED_LEN) seed_max = v; }   // tuning aid
     auto fill = [&](ScgSeeds& S, const uint8_t* pos, const uint8_t* code) {
         int want = max_mm + 1;
