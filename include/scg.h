@@ -64,8 +64,16 @@ int scg_device_count(void);
  * repeat) if set; else $SCG_DEVICE alone if set; else the visible devices starting with the calling thread's current
  * one -- as many of them as the input has groups of four 128 MB windows of FASTQ text, so that a small file stays on
  * one GPU and a large one spreads its windows over all of them.  The single-end entry points shard one file over
- * their devices (per-device counts are summed before the call returns); paired-end files run on the first device;
- * the *_files entry points give every device one file at a time. */
+ * their devices (per-device counts are summed before the call returns); paired-end files and BGZF files run on the
+ * first device; the *_files entry points give every device one file at a time.
+ *
+ * Input forms of the file-level entry points: plain FASTQ (records found by the host threads, sequences shipped), BGZF
+ * (members inflated, checked and scanned on the device), any other gzip (one inflate stream on the host: libdeflate on
+ * the whole file when the image has it and the text fits $SCG_GZIP_WHOLE_GB, default 8; zlib streaming otherwise).
+ * nthreads raises the number of host threads above the default (min(16, cores); $SCG_HOST_THREADS overrides).
+ * Test and measurement switches, none of which changes a result: SCG_HOST_SCAN=0 (plain files: raw text to the
+ * device), SCG_DEVICE_INFLATE=0 (BGZF members inflated by the host threads), SCG_DEVICE_SCAN=0 (host readers only),
+ * SCG_LIBDEFLATE=0 (zlib only), SCG_WINDOW_KB, SCG_BUFFER_CACHE=0, SCG_TRACE=1 (stage timings on stderr). */
 int scg_set_device(int device, char* err, size_t errcap);
 
 /* ---------------------------------------------------------------------------------------------

@@ -38,7 +38,7 @@ constexpr int LIT_BITS = 9;       // primary table of the literal/length code
 constexpr int DIST_BITS = 7;      // primary table of the distance code
 constexpr uint32_t IN_SLACK = 64; // bytes readable beyond a member's payload (the caller pads its buffer)
 
-// One lane's tables (LDS on the device): 2016 bytes.
+// One member's tables (LDS on the device, one set per wavefront): 2016 bytes.
 struct LaneTables {
     uint16_t lit[1 << LIT_BITS];      // (code length << 12) | symbol, 0 = the code is longer than LIT_BITS (or invalid);
                                       // while a dynamic header is read, the code lengths live here (bytes)
@@ -189,8 +189,8 @@ SCG_HD uint32_t reverse_bits(uint32_t code, int len) {
 // Builds the decoding tables of one canonical Huffman code from lens[0 .. n) (inftrees.c: inflate_table).
 // kind: 0 = code-length code (incomplete sets rejected), 1 = literal/length or distance code (an incomplete set is
 // accepted only when its longest code has one bit).  Returns false for a set zlib rejects.
-// `table` has 1 << tbits entries; `count`, `sym`, `offs` as in LaneTables.  lens may alias `table` when
-// lens_in_table is set: it is not read any more once the table is being written.
+// `table` has 1 << tbits entries; `count`, `sym`, `offs` as in LaneTables.  lens may lie inside `table`: it is not read
+// any more once the table is being written.
 SCG_HD bool build_code(const uint8_t* lens, int n, int kind, uint16_t* table, int tbits, uint16_t* count, uint16_t* sym, uint16_t* offs) {
     for (int l = 0; l < 16; ++l) count[l] = 0;
     for (int s = 0; s < n; ++s) count[lens[s]] = static_cast<uint16_t>(count[lens[s]] + 1);

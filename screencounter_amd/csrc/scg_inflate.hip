@@ -1,7 +1,7 @@
-// scg_inflate.hip -- BGZF members inflated on the device: one member per lane (scg_inflate.h), Huffman tables in LDS.
+// scg_inflate.hip -- BGZF members inflated on the device: one member per wavefront (scg_inflate.h), Huffman tables in LDS.
 //
 // A window of a BGZF file is a few thousand independent gzip members of <= 64 KiB of text each.  Their compressed
-// bytes are shipped as they are (a fifth of the text), every lane of inflate_members_kernel decodes one member straight
+// bytes are shipped as they are (a fifth of the text), every wavefront of inflate_members_kernel decodes one member straight
 // into its place in the window's text buffer in HBM, crc_members_kernel checks every member's CRC-32 against its
 // trailer (one workgroup per member; the pieces are combined in GF(2) like zlib's crc32_combine), and the record scan
 // (scg_textscan.hip) runs on the text where it lies.  The host never sees the text: its threads -- sixteen zlib streams
