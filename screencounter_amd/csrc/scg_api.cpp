@@ -1744,7 +1744,7 @@ std::unique_ptr<PlanSet> compile_and_count_single_end(const char* path, scg::Fas
     try {
         devices = devices_for_input(text_bytes_hint(path));
         if (device_scan_enabled()) {
-            src = scg::TextSource::open(path, scg::default_host_threads(nthreads));
+            src = scg::TextSource::open(path, scg::default_host_threads(nthreads, static_cast<int>(devices.size())));
             if (src->has_members() && device_inflate_enabled()) {
                 devices.resize(1);                     // the windows of a BGZF file are chained by their partial records
                 inflate.reset(new InflatePipeline(*src, devices[0]));

@@ -200,17 +200,35 @@ bool FastqStream::next_batch(ReadBatch& out, int64_t max_reads, int64_t max_byte
 // ---------------------------------------------------------------------------------------------
 // ParallelFastq
 // ---------------------------------------------------------------------------------------------
-int default_host_threads(int requested) {
-    // R's num.threads defaults to 1 and is advisory; the stager sizes itself from the machine
-    // unless SCG_HOST_THREADS says otherwise.
+// CPUs this process may keep busy: the hardware threads, or less under a cgroup CPU quota (cgroup v2 cpu.max,
+// v1 cpu.cfs_quota_us / cpu.cfs_period_us) -- threads beyond the quota are only throttled.
+static int cpu_share() {
+    unsigned hw = std::thread::hardware_concurrency();
+    int n = hw ? static_cast<int>(hw) : 1;
+    long quota = -1, period = -1;
+    if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[32] = {0};
+        if (std::fscanf(f, "%31s %ld", q, &period) == 2 && std::strcmp(q, "max") != 0) quota = std::atol(q);
+        std::fclose(f);
+    } else {
+        if (FILE* a = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (std::fscanf(a, "%ld", &quota) != 1) quota = -1; std::fclose(a); }
+        if (FILE* b = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (std::fscanf(b, "%ld", &period) != 1) period = -1; std::fclose(b); }
+    }
+    if (quota > 0 && period > 0) n = std::min<long>(n, std::max<long>(1, (quota + period - 1) / period));
+    return n;
+}
+
+int default_host_threads(int requested, int devices) {
+    // R's num.threads defaults to 1 and is advisory; the stager sizes itself from the machine -- sixteen threads per
+    // device the call feeds, within the CPUs the process may use -- unless SCG_HOST_THREADS says otherwise.
     const char* env = std::getenv("SCG_HOST_THREADS");
     if (env && *env) {
         int v = std::atoi(env);
         if (v >= 1) return v;
     }
-    unsigned hw = std::thread::hardware_concurrency();
-    int n = hw ? static_cast<int>(hw) : 1;
-    if (n > 16) n = 16;
+    static const int share = cpu_share();
+    int n = std::min(share, 16 * std::max(1, devices));
+    if (n > 64) n = 64;
     if (requested > n) n = requested > 64 ? 64 : requested;
     return n < 1 ? 1 : n;
 }

@@ -140,7 +140,7 @@ private:
     Impl* impl;
 };
 
-int default_host_threads(int requested);
+int default_host_threads(int requested, int devices = 1);
 
 } // namespace scg
 
