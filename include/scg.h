@@ -52,7 +52,7 @@ extern "C" {
 #define SCG_ERR_DEVICE 3      /* HIP error or no device */
 #define SCG_ERR_UNSUPPORTED 4 /* valid for the reference but outside this engine's domain */
 
-/* Library version string, e.g. "scg 0.1.0 (gfx950)". */
+/* Library version string, e.g. "scg 0.2.0 (gfx950)". */
 const char* scg_version(void);
 
 /* Number of visible HIP devices (0 when there is none; never fails). */

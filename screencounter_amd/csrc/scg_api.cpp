@@ -2042,7 +2042,7 @@ std::unique_ptr<scg_plan> compile_and_count_paired(const char* path1, const char
 #pragma GCC visibility push(default)     // the C ABI is the library's whole export list (csrc/Makefile: -fvisibility=hidden)
 extern "C" {
 
-const char* scg_version(void) { return "scg 0.1.0 (gfx950)"; }
+const char* scg_version(void) { return "scg 0.2.0 (gfx950)"; }
 
 int scg_device_count(void) {
     int n = 0;
