@@ -382,11 +382,11 @@ def end_to_end(sc, synth, torch, np, w, plan, mates, args) -> dict:
                 dts.sort()
                 return dts[len(dts) // 2], dts[0], dts[-1], mapped, total
 
-            dt, lo, hi, mapped, total = timed()
+            dt, lo, hi, mapped, total = timed(5)
             res["fastq_file"] = {"value": round(total / dt / 1e6, 2), "unit": unit, "fastq_gbs": round(size / dt / 1e9, 2),
                                  "range": [round(total / hi / 1e6, 2), round(total / lo / 1e6, 2)],
                                  "sample": f"first {s2} of the stream as plain 4-line FASTQ on tmpfs ({size / 1e9:.2f} GB), "
-                                           f"one {('scg_count_' + w.entry + '_barcodes')} call incl. library build, median of 3 calls",
+                                           f"one {('scg_count_' + w.entry + '_barcodes')} call incl. library build, median of 5 calls",
                                  "total": int(total), "mapped": mapped}
             if w.entry != "dual":
                 # the same reads as BGZF (blocked gzip as written by bgzip): members inflated in parallel by the host threads
