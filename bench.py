@@ -346,7 +346,7 @@ def end_to_end(sc, synth, torch, np, w, plan, mates, args) -> dict:
     # (2) FASTQ file on tmpfs -> counts through the file-level C ABI entry (parse + stage + H2D + kernels + D2H)
     s2 = args.e2e_file_sample
     if s2 is None:
-        s2 = min(n, 32_000_000 if w.entry != "dual" else 4_000_000)
+        s2 = min(n, 32_000_000 if w.entry != "dual" else 8_000_000)
     s2 = min(s2, n)
     if s2 > 0:
         d = tempfile.mkdtemp(prefix="scg_e2e_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
