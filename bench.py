@@ -138,7 +138,19 @@ def main() -> None:
     dev_index = local_rank % n_dev if share else local_rank
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
-    if world > 1:
+    # SCG_BENCH_FORCE_DIST=1: the process group and the count reduce also at N = 1, so that the RCCL path (init with a
+    # bound device, all_reduce of the bound counters, barrier) can be exercised on a one-GPU box (tests/test_bench_launcher.py)
+    force_dist = world == 1 and os.environ.get("SCG_BENCH_FORCE_DIST") == "1"
+    if force_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            with socket.socket() as so:
+                so.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(so.getsockname()[1])
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    use_dist = world > 1 or force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if share:
             dist.init_process_group("gloo")
@@ -169,7 +181,7 @@ def main() -> None:
             plan.count_paired(mates[0], mates[1], fixed_len1=L, fixed_len2=L, n_pairs=n)
         else:
             plan.count(mates[0], fixed_len=L, n_reads=n)
-        if world > 1:
+        if use_dist:
             if reduce_dev is not None:
                 dist.all_reduce(reduce_dev, op=dist.ReduceOp.SUM)   # the path's one exchange step
             else:
@@ -189,17 +201,17 @@ def main() -> None:
         settle_steps += 10
         torch.cuda.synchronize()
     plan.set_profiling(True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device if not share else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -218,13 +230,16 @@ def main() -> None:
         achieved = algo_bytes / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
         # HBM-side bytes per launch from the PMC passes recorded under profiles/ (FETCH_SIZE + WRITE_SIZE,
         # separate rocprofv3 --pmc runs of this same command, gfx950 correction applied: DESIGN.md section 5)
-        traffic, traffic_source = None, None
+        # (counting kernel + the tally kernel that turns its index stream into counts)
+        traffic, traffic_source, rocprof_ms, rocprof_source = None, None, None, None
         try:
             with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
                 rec = json.load(f).get(str(args.config))
             if rec and rec.get("bytes_per_read"):
-                traffic = round(rec["bytes_per_read"] * n)
+                traffic = round((rec["bytes_per_read"] + rec.get("tally_bytes_per_read", 0.0)) * n)
                 traffic_source = rec["source"]
+                rocprof_ms = rec.get("rocprof_avg_kernel_ms")       # rocprofv3 --kernel-trace --stats of the same command
+                rocprof_source = rec.get("rocprof_source")
         except (OSError, ValueError):
             pass
         out = {
@@ -242,12 +257,17 @@ def main() -> None:
             "data": "synthetic",
             "config": {"workload": w.describe(), "reads_per_gpu": n, "read_len": L, "library": [len(p) for p in w.pools],
                        "max_mismatches": w.mismatches, "strand": ["forward", "reverse", "both"][w.strand] if w.entry != "dual" else "original/original",
-                       "parallelism": f"read-sharded x{world}" + (" + RCCL all-reduce of counts" if world > 1 and not share else "")
+                       "parallelism": f"read-sharded x{world}" + (" + RCCL all-reduce of counts" if use_dist and not share else "")
                                       + (" (gloo rehearsal, ranks share one GPU)" if share and world > 1 else ""),
                        "inputs": "resident in HBM", "settle_s": args.settle, "settle_steps": settle_steps},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "kernel": KERNEL_OF[w.entry], "avg_kernel_ms": round(avg_kernel_s * 1e3, 4), "launches": launches,
+                         # the committed rocprofv3 summary of this command (full-size runs only), next to the live HIP-event figure
+                         "rocprof_avg_kernel_ms": rocprof_ms if n == synth.workload(args.config).n_reads else None,
+                         "rocprof_frac": (round(algo_bytes / (rocprof_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 5)
+                                          if rocprof_ms and n == synth.workload(args.config).n_reads else None),
+                         "rocprof_source": rocprof_source,
                          "algorithmic_bytes_per_launch": algo_bytes, "traffic_source": traffic_source,
                          # the whole step (counting kernel + tally / fold kernel [+ all-reduce]) against the same peak
                          "step_achieved": round(algo_bytes / (elapsed / args.steps) / 1e9, 2),
@@ -293,10 +313,20 @@ def main() -> None:
                 out["e2e"] = end_to_end(sc, synth, torch, np, w, plan, mates, args)
             except Exception as e:      # the PCIe legs are informative; the headline line must still print
                 out["e2e"] = {"error": f"{type(e).__name__}: {e}"}
+        # north_star's ratio, spelled out: this GPU against the reference CPU path on this lease's own host cores
+        # (`vs_baseline` stays null: BASELINE.md holds no published number for the metric)
+        cb = out.get("cpu_baseline") or {}
+        if cb.get("value"):
+            ratios = {"hbm_resident": round(value / cb["value"], 1)}
+            for leg, rec in (out.get("e2e") or {}).items():
+                if isinstance(rec, dict) and rec.get("value"):
+                    ratios[leg] = round(rec["value"] / cb["value"], 2)
+            out["vs_cpu_reference"] = {"what": f"Mreads/s over cpu_baseline.value ({cb['value']} on {cb.get('cores')} cores of this box); "
+                                               "pinned_batches is SURVEY 8(d) metric 1", **ratios}
         print(json.dumps(out), flush=True)
 
     plan.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
@@ -404,8 +434,9 @@ def end_to_end(sc, synth, torch, np, w, plan, mates, args) -> dict:
                                      "range": [round(total / hi / 1e6, 2), round(total / lo / 1e6, 2)],
                                      "sample": f"first {s3} of the stream as BGZF-compressed FASTQ on tmpfs ({gsize / 1e9:.2f} GB compressed), median of 3 calls",
                                      "total": int(total), "mapped": mapped}
-                # ... and as an ordinary single-member gzip file: one inflate stream on one host thread, whatever else happens
-                s4 = min(s2, 4_000_000)
+                # ... and as an ordinary single-member gzip file (one zlib stream, level 4, as `gzip` or a sequencer's software
+                # writes it): decoded by all host threads at once (csrc/scg_pgzip.h)
+                s4 = min(s2, 8_000_000)
                 plain = os.path.join(d, "sub4.fastq")
                 synth.reads_to_fastq(plain, mates[0][: s4 * L].cpu().numpy(), L)
                 gz1 = os.path.join(d, "sub4.fastq.gz")
@@ -424,7 +455,7 @@ def end_to_end(sc, synth, torch, np, w, plan, mates, args) -> dict:
                 dt, lo, hi, mapped, total = timed()
                 res["fastq_gzip"] = {"value": round(total / dt / 1e6, 2), "unit": unit, "range": [round(total / hi / 1e6, 2), round(total / lo / 1e6, 2)],
                                      "sample": f"first {s4} of the stream as one gzip member on tmpfs ({os.path.getsize(gz1) / 1e9:.2f} GB compressed), "
-                                               "inflated by one host thread, median of 3 calls",
+                                               "decoded by the host threads in parallel, median of 3 calls",
                                      "total": int(total), "mapped": mapped}
         finally:
             shutil.rmtree(d, ignore_errors=True)

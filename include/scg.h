@@ -60,21 +60,30 @@ int scg_device_count(void);
 
 /* Makes `device` the calling thread's current HIP device.
  *
- * Devices of the file-level entry points below: $SCG_DEVICES ("all", or a comma list of device ids in which an id may
- * repeat) if set; else $SCG_DEVICE alone if set; else the visible devices starting with the calling thread's current
+ * Devices of the file-level entry points below: the calling thread's scg_set_devices() list if it has one; else
+ * $SCG_DEVICES ("all", or a comma list of device ids in which an id may repeat) if set; else $SCG_DEVICE alone if set;
+ * else the visible devices starting with the calling thread's current
  * one -- as many of them as the input has groups of four 128 MB windows of FASTQ text, so that a small file stays on
  * one GPU and a large one spreads its windows over all of them.  The single-end entry points shard one file over
  * their devices (per-device counts are summed before the call returns); paired-end files and BGZF files run on the
  * first device; the *_files entry points give every device one file at a time.
  *
  * Input forms of the file-level entry points: plain FASTQ (records found by the host threads, sequences shipped), BGZF
- * (members inflated, checked and scanned on the device), any other gzip (one inflate stream on the host: libdeflate on
- * the whole file when the image has it and the text fits $SCG_GZIP_WHOLE_GB, default 8; zlib streaming otherwise).
- * nthreads raises the number of host threads above the default (min(16, cores); $SCG_HOST_THREADS overrides).
+ * (members inflated, checked and scanned on the device), any other gzip of 2 MB or more (decoded by all host threads at
+ * once: chunks decoded speculatively, stitched in order, every member's CRC-32 and length checked; SCG_PGZIP=0 switches
+ * it off), small gzip files and whatever that decoder hands back (one inflate stream on the host: libdeflate on the whole
+ * file when the image has it and the text fits $SCG_GZIP_WHOLE_GB, default 8; zlib streaming otherwise).
+ * nthreads raises the number of host threads above the default (sixteen per device the call feeds, at most 64 and at
+ * most the CPUs the process may use, cgroup quota included; $SCG_HOST_THREADS overrides).
  * Test and measurement switches, none of which changes a result: SCG_HOST_SCAN=0 (plain files: raw text to the
  * device), SCG_DEVICE_INFLATE=0 (BGZF members inflated by the host threads), SCG_DEVICE_SCAN=0 (host readers only),
  * SCG_LIBDEFLATE=0 (zlib only), SCG_WINDOW_KB, SCG_BUFFER_CACHE=0, SCG_TRACE=1 (stage timings on stderr). */
 int scg_set_device(int device, char* err, size_t errcap);
+
+/* The device list of the calling thread's next file-level calls, in place of $SCG_DEVICES (which is read only when no
+ * list has been set): n ids (an id may repeat: several pipelines on one card), n = 0 clears it.  Thread-local, so that
+ * concurrent callers cannot change each other's list and nothing has to rewrite the process environment. */
+int scg_set_devices(const int* devices, int n, char* err, size_t errcap);
 
 /* ---------------------------------------------------------------------------------------------
  * File-level entry points: what the Rcpp shim binds.
@@ -217,9 +226,11 @@ int scg_match_barcodes(const char* const* sequences, int32_t n_sequences,
 
 void scg_free(void* p);
 
-/* The file-level entry points keep the pinned host windows and HBM scratch of their last run for the next call (at most
- * three windows of <= 128 MB per device; counts never depend on it).  This releases them; SCG_BUFFER_CACHE=0 disables
- * the cache altogether. */
+/* The file-level entry points keep the pinned host windows and HBM scratch of their last run for the next call: at most
+ * four window slots per device (counts never depend on it).  A slot of the plain / gzip pipelines is 128 MB of pinned
+ * memory + ~290 MB of HBM; a slot of the BGZF pipeline (members inflated on the device) ~145 MB pinned + ~0.6 GB of HBM,
+ * so up to ~2.4 GB of HBM and ~0.6 GB of pinned memory per device stay allocated between calls.  This releases them;
+ * SCG_BUFFER_CACHE=0 disables the cache altogether. */
 void scg_release_buffers(void);
 
 /* ---------------------------------------------------------------------------------------------

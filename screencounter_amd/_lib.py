@@ -49,6 +49,7 @@ SIGNATURES = {
     "scg_version": (C.c_char_p, []),
     "scg_device_count": (C.c_int, []),
     "scg_set_device": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t]),
+    "scg_set_devices": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.c_char_p, C.c_size_t]),
     "scg_count_single_barcodes": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, c_str_p, C.c_int32, C.c_int, C.c_int, C.c_int,
                                             i32_p, i32_p, C.c_char_p, C.c_size_t]),
     "scg_count_combo_barcodes_single": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, c_str_p, C.c_int32, c_str_p, C.c_int32,

@@ -1512,6 +1512,10 @@ void reset_plan(scg_plan* P) {
     P->total = 0;
 }
 
+// A gzip file the parallel decoder (scg_pgzip.h) handed back gets a second try with one inflate stream before the
+// host readers take it.
+bool is_parallel_gzip(const scg::TextSource* s) { return s && std::strcmp(s->kind(), "gzip-parallel") == 0; }
+
 bool device_scan_enabled() {
     const char* e = std::getenv("SCG_DEVICE_SCAN");          // test hook: 0 keeps the host parsers
     return !(e && *e == '0');
@@ -1538,12 +1542,17 @@ void count_single_end(const std::vector<scg_plan*>& plans, const char* path, scg
             }
             if (done) return;
         }
-        try {
-            std::unique_ptr<scg::TextSource> src = scg::TextSource::open(path, scg::default_host_threads(nthreads));
-            count_text_stream(plans, *src);
-            done = true;
-        } catch (const UnusualInput&) {
-            for (scg_plan* P : plans) reset_plan(P);
+        for (int attempt = 0; attempt < 2 && !done; ++attempt) {
+            bool again = false;
+            try {
+                std::unique_ptr<scg::TextSource> src = scg::TextSource::open(path, scg::default_host_threads(nthreads), attempt == 0);
+                again = attempt == 0 && is_parallel_gzip(src.get());
+                count_text_stream(plans, *src);
+                done = true;
+            } catch (const UnusualInput&) {
+                for (scg_plan* P : plans) reset_plan(P);
+            }
+            if (!again) break;
         }
         if (done) return;
     }
@@ -1575,10 +1584,19 @@ void read_counters(scg_plan* P, int32_t* counts_out) {
 // ---- devices and plan sets ---------------------------------------------------------------------------------
 // Which devices a file-level call may use: $SCG_DEVICES ("all", or a comma list in which an id may repeat: several
 // pipelines on one card) if set; else every visible device, the calling thread's current one ($SCG_DEVICE) first.
+thread_local std::vector<int> tl_devices;       // scg_set_devices(): overrides $SCG_DEVICES for the calling thread
+
 std::vector<int> device_list(bool* explicit_list = nullptr) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
         throw Error(SCG_ERR_DEVICE, "no HIP device available: libscg has no CPU fallback");
+    }
+    if (!tl_devices.empty()) {
+        for (int v : tl_devices) {
+            if (v < 0 || v >= n) throw Error(SCG_ERR_DEVICE, "HIP device " + std::to_string(v) + " out of range (" + std::to_string(n) + " visible)");
+        }
+        if (explicit_list) *explicit_list = true;
+        return tl_devices;
     }
     std::vector<int> out;
     const char* env = std::getenv("SCG_DEVICES");
@@ -1696,7 +1714,7 @@ struct PlanSet {
 // the next unprocessed file when it is done; per_file(plan, i) counts file i and stores its column.  The error of the
 // lowest-numbered failing file is reported, as a serial loop over the files would.
 void schedule_files(int32_t n_files, const PlanSet& set, const std::function<void(scg_plan*, int32_t)>& per_file) {
-    std::atomic<int32_t> next(0);
+    std::atomic<int32_t> next(0), first_bad(n_files);
     std::mutex mu;
     int32_t bad = n_files;
     int bad_code = 0;
@@ -1705,6 +1723,7 @@ void schedule_files(int32_t n_files, const PlanSet& set, const std::function<voi
         for (;;) {
             const int32_t i = next.fetch_add(1);
             if (i >= n_files) return;
+            if (i > first_bad.load()) return;      // a file before this one has failed: the call reports that error, whatever comes after
             int code = 0;
             std::string msg;
             try {
@@ -1715,7 +1734,7 @@ void schedule_files(int32_t n_files, const PlanSet& set, const std::function<voi
             } catch (const std::bad_alloc&) { code = SCG_ERR_DEVICE; msg = "out of host memory";
             } catch (const std::exception& e) { code = SCG_ERR_INVALID; msg = e.what(); }
             std::lock_guard<std::mutex> g(mu);
-            if (i < bad) { bad = i; bad_code = code; bad_msg = msg; }
+            if (i < bad) { bad = i; bad_code = code; bad_msg = msg; first_bad.store(i); }
         }
     };
     std::vector<std::thread> th;
@@ -1741,6 +1760,7 @@ std::unique_ptr<PlanSet> compile_and_count_single_end(const char* path, scg::Fas
     std::unique_ptr<scg::TextSource> src;
     std::unique_ptr<TextPipeline> pipe;
     std::unique_ptr<InflatePipeline> inflate;
+    bool parallel_gzip_declined = false, inflate_declined_early = false;
     try {
         devices = devices_for_input(text_bytes_hint(path));
         if (device_scan_enabled()) {
@@ -1755,6 +1775,8 @@ std::unique_ptr<PlanSet> compile_and_count_single_end(const char* path, scg::Fas
             }
         }
     } catch (const UnusualInput&) {
+        parallel_gzip_declined = is_parallel_gzip(src.get());
+        inflate_declined_early = src && src->has_members() && device_inflate_enabled();      // the first window already: same second chance as any later one
         pipe.reset();
         inflate.reset();
     } catch (...) {
@@ -1769,16 +1791,19 @@ std::unique_ptr<PlanSet> compile_and_count_single_end(const char* path, scg::Fas
     std::unique_ptr<PlanSet> set(new PlanSet(std::move(compiled), devices));
     tr.mark("upload to device(s)");
     bool done = false;
-    if (inflate) {
-        try {
-            inflate->run(set->first());
-            done = true;
-        } catch (const UnusualInput&) {
-            if (device_inflate_strict()) inflate_declined();
-            inflate.reset();                       // (its kernels have finished before the counters are cleared)
-            set->reset();
+    if (inflate || inflate_declined_early) {
+        if (inflate_declined_early && device_inflate_strict()) inflate_declined();
+        if (inflate) {
+            try {
+                inflate->run(set->first());
+                done = true;
+            } catch (const UnusualInput&) {
+                if (device_inflate_strict()) inflate_declined();
+                inflate.reset();                       // (its kernels have finished before the counters are cleared)
+                set->reset();
+            }
+            inflate.reset();
         }
-        inflate.reset();
         if (!done) {
             // second chance for BGZF: members inflated by the host threads' zlib, records scanned on the device
             try {
@@ -1789,8 +1814,24 @@ std::unique_ptr<PlanSet> compile_and_count_single_end(const char* path, scg::Fas
             }
         }
     }
+    bool retry_gzip = parallel_gzip_declined;
     if (pipe) {
+        const bool parallel = is_parallel_gzip(src.get());
         try {
+            pipe->run(set->all());
+            done = true;
+        } catch (const UnusualInput&) {
+            pipe.reset();
+            set->reset();
+            retry_gzip = parallel;
+        }
+        pipe.reset();
+    }
+    if (!done && retry_gzip) {
+        // the parallel gzip decoder handed the file back: one inflate stream, records scanned on the device
+        try {
+            src = scg::TextSource::open(path, scg::default_host_threads(nthreads), false);
+            pipe.reset(new TextPipeline(*src, devices));
             pipe->run(set->all());
             done = true;
         } catch (const UnusualInput&) {
@@ -1940,13 +1981,16 @@ void count_paired_host(scg_plan* P, const char* path1, const char* path2, scg::F
 }
 
 void count_paired_files(scg_plan* P, const char* path1, const char* path2, scg::FastqStream& fq1, scg::FastqStream& fq2, int nthreads,
-                        bool try_device_inflate = true) {
+                        bool try_device_inflate = true, bool parallel_gzip = true) {
     if (device_scan_enabled()) {
         // ordinary files: windows of sequences paired on the device (PairedPipeline); anything else: the host readers
-        bool done = false;
+        bool done = false, declined_gzip = false;
         try {
             const int threads = scg::default_host_threads(nthreads);
-            std::unique_ptr<scg::TextSource> s1 = scg::TextSource::open(path1, threads), s2 = scg::TextSource::open(path2, threads);
+            // (two parallel gzip decoders share the host threads)
+            std::unique_ptr<scg::TextSource> s1 = scg::TextSource::open(path1, threads, parallel_gzip, std::max(2, threads / 2)),
+                                             s2 = scg::TextSource::open(path2, threads, parallel_gzip, std::max(2, threads / 2));
+            declined_gzip = is_parallel_gzip(s1.get()) || is_parallel_gzip(s2.get());
             bool device_inflate = try_device_inflate;
             for (;;) {
                 {
@@ -1964,14 +2008,18 @@ void count_paired_files(scg_plan* P, const char* path1, const char* path2, scg::
                 // a BGZF mate the device handed back: once more with the host threads' zlib (the pipeline is gone: its
                 // kernels have finished)
                 reset_plan(P);
-                s1 = scg::TextSource::open(path1, threads);
-                s2 = scg::TextSource::open(path2, threads);
+                s1 = scg::TextSource::open(path1, threads, parallel_gzip, std::max(2, threads / 2));
+                s2 = scg::TextSource::open(path2, threads, parallel_gzip, std::max(2, threads / 2));
                 device_inflate = false;
             }
         } catch (const UnusualInput&) {
             reset_plan(P);
         }
         if (done) return;
+        if (declined_gzip) {       // a gzip mate the parallel decoder handed back: once more with one inflate stream per mate
+            count_paired_files(P, path1, path2, fq1, fq2, nthreads, try_device_inflate, false);
+            return;
+        }
     }
     count_paired_host(P, path1, path2, fq1, fq2, nthreads);
 }
@@ -1990,17 +2038,20 @@ std::unique_ptr<scg_plan> compile_and_count_paired(const char* path1, const char
     int device = -1;
     std::unique_ptr<scg::TextSource> s1, s2;
     std::unique_ptr<PairedPipeline> pipe;
+    bool gzip_parallel = false, gzip_declined = false;
     try {
         device = resolve_device(-1);
         if (device_scan_enabled()) {
             const int threads = scg::default_host_threads(nthreads);
-            s1 = scg::TextSource::open(path1, threads);
-            s2 = scg::TextSource::open(path2, threads);
+            s1 = scg::TextSource::open(path1, threads, true, std::max(2, threads / 2));
+            s2 = scg::TextSource::open(path2, threads, true, std::max(2, threads / 2));
+            gzip_parallel = is_parallel_gzip(s1.get()) || is_parallel_gzip(s2.get());
             pipe.reset(new PairedPipeline(device, *s1, *s2, true));
             pipe->start();
         }
     } catch (const UnusualInput&) {
         pipe.reset();
+        gzip_declined = gzip_parallel;
     } catch (...) {
         early = std::current_exception();
         pipe.reset();
@@ -2022,12 +2073,14 @@ std::unique_ptr<scg_plan> compile_and_count_paired(const char* path1, const char
             if (inflate_declined_it && device_inflate_strict()) inflate_declined();
             pipe.reset();                          // (its kernels have finished before the counters are cleared)
             reset_plan(P.get());
+            gzip_declined = gzip_parallel;
         }
         pipe.reset();
     }
     if (!done) {
-        // a BGZF mate the device handed back gets the host threads' zlib next; everything else the host readers
-        if (inflate_declined_it) count_paired_files(P.get(), path1, path2, fq1, fq2, nthreads, false);
+        // a BGZF mate the device handed back gets the host threads' zlib next, a gzip mate the parallel decoder handed back
+        // one inflate stream; everything else the host readers
+        if (inflate_declined_it || gzip_declined) count_paired_files(P.get(), path1, path2, fq1, fq2, nthreads, !inflate_declined_it, !gzip_declined);
         else count_paired_host(P.get(), path1, path2, fq1, fq2, nthreads);
     }
     tr.mark("count files");
@@ -2093,16 +2146,25 @@ int scg_fastq_text_windows(const char* path, int64_t window_bytes, int nthreads,
                            int64_t** cuts_out, int64_t* n_windows_out, char* kind_out, char* err, size_t errcap) {
     return guarded(err, errcap, [&] {
         if (!path || !text_out || !n_bytes_out || !cuts_out || !n_windows_out || window_bytes < 64) throw Error(SCG_ERR_INVALID, "null argument");
-        std::unique_ptr<scg::TextSource> src = scg::TextSource::open(path, scg::default_host_threads(nthreads));
-        if (kind_out) { std::strncpy(kind_out, src->kind(), 15); kind_out[15] = 0; }
         std::vector<char> all, window(static_cast<size_t>(window_bytes));
         std::vector<int64_t> cuts(1, 0);
-        for (;;) {
-            const size_t got = src->next(window.data(), window.size());
-            if (src->unusual()) throw Error(SCG_ERR_UNSUPPORTED, "the text cannot be cut into windows of whole 4-line records");
-            if (!got) break;
-            all.insert(all.end(), window.begin(), window.begin() + got);
-            cuts.push_back(static_cast<int64_t>(all.size()));
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            std::unique_ptr<scg::TextSource> src = scg::TextSource::open(path, scg::default_host_threads(nthreads), attempt == 0);
+            if (kind_out) { std::strncpy(kind_out, src->kind(), 15); kind_out[15] = 0; }
+            bool again = false;
+            all.clear(); cuts.assign(1, 0);
+            for (;;) {
+                const size_t got = src->next(window.data(), window.size());
+                if (src->unusual()) {
+                    // (a gzip file the parallel decoder hands back is read again through one inflate stream, as the pipelines do)
+                    if (attempt == 0 && is_parallel_gzip(src.get())) { again = true; break; }
+                    throw Error(SCG_ERR_UNSUPPORTED, "the text cannot be cut into windows of whole 4-line records");
+                }
+                if (!got) break;
+                all.insert(all.end(), window.begin(), window.begin() + got);
+                cuts.push_back(static_cast<int64_t>(all.size()));
+            }
+            if (!again) break;
         }
         char* t = static_cast<char*>(std::malloc(all.size() + 1));
         int64_t* c = static_cast<int64_t*>(std::malloc(sizeof(int64_t) * cuts.size()));
@@ -2195,6 +2257,13 @@ int scg_set_device(int device, char* err, size_t errcap) {
             throw Error(SCG_ERR_DEVICE, "HIP device " + std::to_string(device) + " out of range (" + std::to_string(n) + " visible)");
         }
         HIP_CHECK(hipSetDevice(device));
+    });
+}
+
+int scg_set_devices(const int* devices, int n, char* err, size_t errcap) {
+    return guarded(err, errcap, [&] {
+        if (n < 0 || (n > 0 && !devices)) throw Error(SCG_ERR_INVALID, "null argument");
+        tl_devices.assign(devices, devices + n);
     });
 }
 

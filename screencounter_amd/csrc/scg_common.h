@@ -36,10 +36,12 @@
 // ScanTemplate reports (kaori/ScanTemplate.hpp:233-252); every candidate is then verified exactly.
 // Packed into dwords so that the whole description travels in the kernel-argument segment and
 // lives in SGPRs (gfx950 has no scalar byte loads).
-// For one (seed, base code): the walk along plane E[code], starting at template position 32 * ScgSeed::blk.  Step k
-// shifts the running copy of the plane right by (byte & 31) bits and then ANDs it into the seed's match mask unless
-// bit 7 is set (a pure shift).  Bytes are consumed from byte 0 of w[0] up.  A seed never straddles a 32-position block,
-// so that the compact scanner can take a shifted plane word with one funnel shift from two adjacent words.
+// For one (seed, base code): the seed's bases with that code, as their offsets (0..31) from template position
+// 32 * ScgSeed::blk, ascending, one per byte from byte 0 of w[0] up.  Plane E[code] shifted right by such an offset is
+// ANDed into the seed's match mask.  The offsets are ABSOLUTE within the block, so that a funnel shift can take a walk
+// word (shifted down by whole bytes) as its shift operand directly -- the instruction reads bits 4:0 only; the
+// general scanner, which moves a running copy of the plane, takes the differences.  A seed never straddles a
+// 32-position block, so that the compact scanner can take a shifted plane word with one funnel shift from two adjacent words.
 #define SCG_SEED_STEPS 16
 struct ScgSeedWalk {
     uint32_t w[SCG_SEED_STEPS / 4];

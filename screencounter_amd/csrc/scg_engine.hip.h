@@ -224,6 +224,9 @@ __device__ __forceinline__ void index_search(const ScgIndex& X, const QueryT<W>&
         uint32_t pos = K::hash(sklo, skhi) & X.slot_mask;
         const uint4* table = X.tables + (size_t)s * nslots * (sizeof(W) / 4);
         // the slot of a group key holds the head node of its chain: an exact hit is one access
+        // (tried: 4-byte slots -- hash tag over head index -- so that the tables of a 100 k-barcode library stay in an
+        // XCD's L2, the node fetched behind a matching tag: +12 % on configs 2 and 5; the second, dependent gather costs
+        // more than the L2 misses it saves, and fewer slots per entry made it worse still)
         typename K::Node ent;
         bool found = false;
         for (;;) {

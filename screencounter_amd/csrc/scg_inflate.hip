@@ -34,14 +34,24 @@ struct WaveLanes {
     __device__ __forceinline__ void set(Vec& v, uint32_t j, uint32_t byte) const { if (id == j) v = byte; }
     // j mod dist for this lane (dist is wave-uniform; matches that reach into their own output are the rare case)
     __device__ __forceinline__ uint32_t wrap(uint32_t j, uint32_t n, uint32_t dist) const { return dist >= n ? j : (dist == 1 ? 0u : j % dist); }
+    // The lanes hand bytes to one another through the text itself: what one lane stores, another may load a few symbols
+    // later.  gfx9 issues a wavefront's vector memory operations in order, so that works as it stands; the
+    // wavefront-scope fences (no instructions on this target) keep the COMPILER from moving a load of the text across
+    // an earlier store of it.
+    static __device__ __forceinline__ void lanes_published() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); }
+    static __device__ __forceinline__ void lanes_may_read() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
     __device__ __forceinline__ void load(Vec& v, const uint8_t* src, uint32_t n, uint32_t dist) const {
+        lanes_may_read();
         if (id < n) v = src[wrap(id, n, dist)];
     }
     __device__ __forceinline__ void store(uint8_t* dst, const Vec& v, uint32_t n) const {
         if (id < n) dst[id] = static_cast<uint8_t>(v);
+        lanes_published();
     }
     __device__ __forceinline__ void copy(uint8_t* dst, const uint8_t* src, uint32_t n, uint32_t dist) const {
+        lanes_may_read();
         for (uint32_t j = id; j < n; j += INFLATE_BLOCK) dst[j] = src[wrap(j, n, dist)];
+        lanes_published();
     }
 };
 

@@ -1,6 +1,7 @@
 // scg_ingest.cpp -- sources of raw FASTQ text for the device-side record scan (see scg_ingest.h).
 #include "scg_ingest.h"
 #include "scg_host.h"
+#include "scg_pgzip.hpp"
 
 #include <algorithm>
 #include <atomic>
@@ -590,9 +591,64 @@ std::unique_ptr<MappedFile> inflate_whole(const char* path) {
     return std::unique_ptr<MappedFile>(new MappedFile(static_cast<char*>(m), cap, made));
 }
 
+// ---- any other gzip file of some size: decoded by all host threads at once (scg_pgzip.h: chunks decoded
+//      speculatively with an unknown window, stitched in order, checked against every member's CRC-32 and length), the
+//      text written straight into the pinned windows the device scans.  Whatever the decoder hands back -- a corrupt
+//      stream, a header CRC, a ratio beyond its buffers -- sets unusual(): the caller redoes the file with the
+//      streams above, whose verdict is zlib's ----
+class PgzipSource : public CarrySource {
+    int fd = -1;
+    uint8_t* map = nullptr;
+    size_t mapped = 0, csize = 0;
+    std::unique_ptr<ParallelGunzip> pg;
+    uint64_t produced = 0;
+public:
+    PgzipSource(const char* path, int nthreads) {
+        threads = nthreads;
+        fd = ::open(path, O_RDONLY);
+        if (fd < 0) throw Error(SCG_ERR_IO, std::string("failed to open file at '") + path + "'");
+        struct stat st;
+        if (::fstat(fd, &st) != 0) { ::close(fd); throw Error(SCG_ERR_IO, "failed to stat the FASTQ file"); }
+        csize = static_cast<size_t>(st.st_size);
+        // the file, followed by a page of zeros: the decoder's bit reader looks a few bytes beyond the last one
+        mapped = ((csize + 4095) & ~size_t(4095)) + 4096;
+        void* m = ::mmap(nullptr, mapped, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (m == MAP_FAILED) { ::close(fd); throw Error(SCG_ERR_IO, "failed to map the FASTQ file"); }
+        if (csize && ::mmap(m, csize, PROT_READ, MAP_PRIVATE | MAP_FIXED, fd, 0) == MAP_FAILED) {
+            ::munmap(m, mapped); ::close(fd);
+            throw Error(SCG_ERR_IO, "failed to map the FASTQ file");
+        }
+        map = static_cast<uint8_t*>(m);
+        pg.reset(new ParallelGunzip(map, csize, nthreads));
+    }
+    ~PgzipSource() override {
+        pg.reset();
+        if (map) ::munmap(map, mapped);
+        if (fd >= 0) ::close(fd);
+    }
+    static bool wanted(const char* path, int nthreads) {
+        const char* e = std::getenv("SCG_PGZIP");             // test hook: 0 keeps the single inflate streams
+        if (e && *e == '0') return false;
+        struct stat st;
+        if (::stat(path, &st) != 0) return false;
+        return ParallelGunzip::chunk_size_for(static_cast<size_t>(st.st_size), nthreads) != 0;
+    }
+    const char* kind() const override { return "gzip-parallel"; }
+    uint64_t size_hint() const override { return static_cast<uint64_t>(csize) * 8 > produced ? static_cast<uint64_t>(csize) * 8 - produced : 4096; }
+protected:
+    size_t fill(char* dst, size_t have, size_t cap) override {
+        const size_t got = pg->read(dst + have, cap - have);
+        if (pg->failed()) { odd = true; return have; }
+        if (got < cap - have) exhausted = true;
+        produced += got;
+        return have + got;
+    }
+};
+
 } // namespace
 
-std::unique_ptr<TextSource> TextSource::open(const char* path, int threads) {
+std::unique_ptr<TextSource> TextSource::open(const char* path, int threads, bool parallel_gzip, int gzip_threads) {
+    if (gzip_threads <= 0) gzip_threads = threads;
     unsigned char h[2] = {0, 0};
     size_t got = 0;
     {
@@ -604,6 +660,7 @@ std::unique_ptr<TextSource> TextSource::open(const char* path, int threads) {
     const bool gz = got == 2 && h[0] == 0x1f && h[1] == 0x8b;      // byteme/magic_numbers.hpp:19-22
     if (!gz) return std::unique_ptr<TextSource>(new PlainSource(path, threads));
     if (BgzfSource::looks_like(path)) return std::unique_ptr<TextSource>(new BgzfSource(path, threads));
+    if (parallel_gzip && PgzipSource::wanted(path, gzip_threads)) return std::unique_ptr<TextSource>(new PgzipSource(path, gzip_threads));
     if (std::unique_ptr<MappedFile> text = inflate_whole(path)) {
         return std::unique_ptr<TextSource>(new PlainSource(std::move(*text), threads, "gzip"));
     }

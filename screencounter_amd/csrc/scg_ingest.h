@@ -62,8 +62,11 @@ struct CompressedMember {
 
 class TextSource {
 public:
-    // plain file (mapped), BGZF / blocked gzip (members inflated in parallel) or any other gzip (one inflate stream)
-    static std::unique_ptr<TextSource> open(const char* path, int threads);
+    // plain file (mapped), BGZF / blocked gzip (members inflated in parallel) or any other gzip: decoded by all threads
+    // at once (scg_pgzip.h; kind() "gzip-parallel") unless the file is small or parallel_gzip is false -- then, and for
+    // the second try at a file the parallel decoder handed back, one inflate stream
+    // (gzip_threads: threads of the parallel gzip decoder, 0 = `threads`; two mates decoded at once share the host)
+    static std::unique_ptr<TextSource> open(const char* path, int threads, bool parallel_gzip = true, int gzip_threads = 0);
     virtual ~TextSource() {}
 
     // Writes the next window of text into dst[0 .. cap): whole records, starting where the previous window ended.

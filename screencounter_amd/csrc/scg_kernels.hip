@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <mutex>
 
 #include "scg_engine.hip.h"
 #include "scg_staged.hip.h"
@@ -399,11 +400,12 @@ __device__ __forceinline__ int single_read_staged(const ScgSingleParams& P, cons
     if (ablate == 1) return (candF[0] ^ candR[NC - 1]) == 0x12345u ? 0 : -1;
 #endif
     int found = 0, index = -1, best = max_mm + 1;
+    const int last = last_position(sr.n, T.len);
     for (;;) {
         int pf = first_bit<NC>(candF), pr = first_bit<NC>(candR);
         bool rev = pr < pf;                           // forward first on ties
         int p = rev ? pr : pf;
-        if (p >= (1 << 30)) break;
+        if (p > last) break;                          // no candidate left inside the read (an empty mask gives 1 << 30)
         clear_bit<NC>(candF, rev ? -1 : p);
         clear_bit<NC>(candR, rev ? p : -1);
         int c = window_mismatches<NW, NT>(tile, sr.bit + p, st, rev);
@@ -492,11 +494,12 @@ __global__ __launch_bounds__(STAGE_BLOCK) __attribute__((amdgpu_num_sgpr(80))) v
     scan_read<NW, NC>(tile, sr, P.scan, P.fwd != 0, P.rev != 0, candF, candR);
     BestHit h{P.max_mm + 1, -1, false};
     int out = -1;
+    const int last = last_position(sr.n, P.scan.len);
     for (;;) {
         int pf = first_bit<NC>(candF), pr = first_bit<NC>(candR);
         bool rev = pr < pf;                           // forward first on ties
         int p = rev ? pr : pf;
-        if (p >= (1 << 30)) break;
+        if (p > last) break;
         clear_bit<NC>(candF, rev ? -1 : p);
         clear_bit<NC>(candR, rev ? p : -1);
         int c = window_mismatches<NW, NT>(tile, sr.bit + p, strands, rev);
@@ -510,15 +513,20 @@ __global__ __launch_bounds__(STAGE_BLOCK) __attribute__((amdgpu_num_sgpr(80))) v
 
 // SECOND: the masked DuplicateAction::FIRST pass of the single-end dual diagnostics -- a compile-time variant, so that
 // the ordinary combination kernel keeps its code (a run-time flag here cost it 9 %).
+// `pools`: the two pools' index descriptors in LDS.  Which pool a region is looked up in depends on the strand, which
+// differs from lane to lane; picking between the two descriptors in the kernel arguments made every field of the
+// chosen one (masks, table base, sizes: ~20 per look-up) a per-lane LOAD from the argument segment -- two thirds of
+// the kernel's vector-memory instructions, each a round trip in the middle of the look-up's dependent chain.  From LDS
+// the same selection is an address offset.
 template<int NW, int NT, bool SECOND, class W>
-__device__ __forceinline__ bool combo_candidate_staged(const ScgComboParams& P, const Tile<NW>& tile, const StrandTable<NT>& st, const StagedRead& sr,
+__device__ __forceinline__ bool combo_candidate_staged(const ScgComboParams& P, const ScgIndex* pools, const Tile<NW>& tile, const StrandTable<NT>& st, const StagedRead& sr,
                                                        int p, bool reverse, int c, int out[SCG_COMBO_REGIONS], int& total) {
     int obs = c;
 #pragma unroll
     for (int r = 0; r < SCG_COMBO_REGIONS; ++r) {
         int slot = reverse ? (SCG_COMBO_REGIONS - 1 - r) : r;
         const int start = region_start<NT>(st, r, reverse);
-        const ScgIndex& tab = P.index[slot];
+        const ScgIndex& tab = pools[slot];
         QueryT<W> q = region_query<NW, W>(tile, sr.bit + p + start, tab.len, reverse);
         int idx, d;
         index_match<W>(tab, q, P.max_mm - obs, idx, d, SECOND);
@@ -536,7 +544,13 @@ __global__ __launch_bounds__(STAGE_BLOCK, SCG_COMBO_WAVES) __attribute__((amdgpu
                                                                   ScgCounters cells, int32_t* __restrict__ error_flag) {
     __shared__ Tile<NW> tile;
     __shared__ StrandTable<NT> strands;
+    __shared__ ScgIndex pools[SCG_COMBO_REGIONS];
     fill_strand_table<NT>(strands, P.scan);
+    if (threadIdx.x < SCG_COMBO_REGIONS * (sizeof(ScgIndex) / 4)) {
+        static_assert(sizeof(ScgIndex) % 4 == 0, "copied by dwords");
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(&P.index[0]);
+        reinterpret_cast<uint32_t*>(&pools[0])[threadIdx.x] = src[threadIdx.x];
+    }
     const int64_t r0 = (int64_t)blockIdx.x * STAGE_BLOCK;
     const int nr = (int)((n_reads - r0) < STAGE_BLOCK ? (n_reads - r0) : STAGE_BLOCK);
     int64_t span0 = 0;
@@ -557,17 +571,18 @@ __global__ __launch_bounds__(STAGE_BLOCK, SCG_COMBO_WAVES) __attribute__((amdgpu
         sr.n = rd.n;
         uint32_t candF[NC], candR[NC];
         scan_read<NW, NC>(tile, sr, T, P.fwd != 0, P.rev != 0, candF, candR);
+        const int last = last_position(sr.n, T.len);
         for (;;) {
             int pf = first_bit<NC>(candF), pr = first_bit<NC>(candR);
             bool rev = pr < pf;
             int p = rev ? pr : pf;
-            if (p >= (1 << 30)) break;
+            if (p > last) break;
             clear_bit<NC>(candF, rev ? -1 : p);
             clear_bit<NC>(candR, rev ? p : -1);
             int c = window_mismatches<NW, NT>(tile, sr.bit + p, strands, rev);
             if (c > P.max_mm) continue;
             int cand[SCG_COMBO_REGIONS], tot;
-            if (!combo_candidate_staged<NW, NT, SECOND, W>(P, tile, strands, sr, p, rev, c, cand, tot)) continue;
+            if (!combo_candidate_staged<NW, NT, SECOND, W>(P, pools, tile, strands, sr, p, rev, c, cand, tot)) continue;
             if (P.use_first) {
                 found = 1; best_id[0] = cand[0]; best_id[1] = cand[1];
                 break;
@@ -596,9 +611,10 @@ __device__ __forceinline__ bool mate_search_staged(const Tile<NW>& tile, const S
     // the extracted region is to be read
     scan_read<NW, NC>(tile, sr, T, true, false, cand, unused);
     const int start = T.fstart[0];
+    const int last = last_position(sr.n, T.len);
     for (;;) {
         int p = first_bit<NC>(cand);
-        if (p >= (1 << 30)) break;
+        if (p > last) break;
         clear_bit<NC>(cand, p);
         int c = window_mismatches<NW, NT>(tile, sr.bit + p, T, false);
         if (c > max_mm) continue;
@@ -634,9 +650,10 @@ __device__ __forceinline__ void dual_orientation_staged(const ScgDualParams& P, 
     uint32_t c1[NC], c2[NC], unused[NC];
     scan_read<NW, NC>(ta, a, T1, true, false, c1, unused);
     scan_read<NW, NC>(tb, b, T2, true, false, c2, unused);
+    const int last1 = last_position(a.n, T1.len), last2 = last_position(b.n, T2.len);
     for (;;) {
         int p1 = first_bit<NC>(c1);
-        if (p1 >= (1 << 30)) break;
+        if (p1 > last1) break;
         clear_bit<NC>(c1, p1);
         int m1 = window_mismatches<NW, NT>(ta, a.bit + p1, T1, false);
         if (m1 > P.max_mm1) continue;
@@ -646,7 +663,7 @@ __device__ __forceinline__ void dual_orientation_staged(const ScgDualParams& P, 
         for (int i = 0; i < NC; ++i) w2[i] = c2[i];
         for (;;) {
             int p2 = first_bit<NC>(w2);
-            if (p2 >= (1 << 30)) break;
+            if (p2 > last2) break;
             clear_bit<NC>(w2, p2);
             int m2 = window_mismatches<NW, NT>(tb, b.bit + p2, T2, false);
             if (m2 > P.max_mm2) {
@@ -1080,20 +1097,23 @@ hipError_t launch_tally(const int32_t* unit_index, int64_t n, int32_t* counters,
     const int passes = (int)((n_counters + max_bins - 1) / max_bins);
     int bins = (int)((n_counters + passes - 1) / passes);
     bins = (bins + 1) & ~1;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tally_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_bins * 2);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    // Per device, once (several host threads launch on several devices at the same time: schedule_files, PlanSet): the
+    // kernel's dynamic-LDS limit and the device's CU count.
+    constexpr int MAX_DEVICES = 64;
+    static std::once_flag once[MAX_DEVICES];
+    static int cu_count[MAX_DEVICES];
+    static hipError_t setup[MAX_DEVICES];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return hipErrorInvalidDevice;
+    std::call_once(once[dev], [dev] {
+        setup[dev] = hipFuncSetAttribute(reinterpret_cast<const void*>(tally_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024 * 2);
+        hipDeviceProp_t prop;
+        cu_count[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
+    });
+    if (setup[dev] != hipSuccess) return setup[dev];
     // one workgroup (160 KB of LDS) per CU at a time: aim at one full wave of workgroups, each with
     // >= 256 K reads so that the final flush (one atomic per non-empty bin and workgroup) stays small
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
-    }
+    const int cus = cu_count[dev];
     int64_t slices = n / (int64_t(1) << 18);
     if (slices < 1) slices = 1;
     if (slices * passes > cus) slices = cus / passes > 0 ? cus / passes : 1;

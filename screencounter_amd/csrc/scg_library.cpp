@@ -681,13 +681,12 @@ ScgScan build_scan(const ScgTemplate& t, int max_mm) {
             sd.blk = runs[static_cast<size_t>(i)].blk;
             for (int c = 0; c < 4; ++c) {
                 uint8_t steps[64];
-                int ns = 0, prev = 32 * sd.blk;
+                int ns = 0;
                 for (int j = 0; j < sd.len; ++j) {
                     if (code[a + j] != c) continue;
-                    steps[ns++] = static_cast<uint8_t>(pos[a + j] - prev);      // < 32: shift (maybe 0) then AND
-                    prev = pos[a + j];
+                    steps[ns++] = static_cast<uint8_t>(pos[a + j] - 32 * sd.blk);      // offset within the block, < 32
                 }
-                if (ns & 1) steps[ns++] = 0;      // even step count: the compact scanner folds bases in pairs (a repeated AND is a no-op)
+                if (ns & 1) { steps[ns] = steps[ns - 1]; ++ns; }      // even step count: the compact scanner folds bases in pairs (a repeated AND is a no-op)
                 for (int k = 0; k < ns; ++k) sd.walk[c].w[k >> 2] |= static_cast<uint32_t>(steps[k]) << (8 * (k & 3));
                 sd.nsteps |= static_cast<uint32_t>(ns) << (8 * c);
             }

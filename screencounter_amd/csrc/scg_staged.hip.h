@@ -55,8 +55,8 @@ struct Tile {
 // place) and XORed with the byte stripped of its case bit: the result z is zero exactly for ACGTacgt.  Plane bits are
 // gathered with v_dot4_u32_u8 against power-of-two weights, straight from ASCII bits 1 and 2 (so
 // scaled by 2 and 4).  When every lane of the wavefront holds only standard bases -- the rule in
-// real data, where N calls are rare -- the validity plane is all ones and its gather (a carry-free
-// nonzero-byte test per dword plus a third dot product) is skipped.
+// real data, where N calls are rare -- the validity plane is all ones and its gather (a second byte
+// permute per dword plus a third dot product) is skipped.
 __device__ __forceinline__ void transpose_chunk(const uint4& x, uint32_t& p0, uint32_t& p1, uint32_t& v) {
     const uint32_t d[4] = {x.x, x.y, x.z, x.w};
     uint32_t a0[2] = {0, 0}, a1[2] = {0, 0};
@@ -76,14 +76,18 @@ __device__ __forceinline__ void transpose_chunk(const uint4& x, uint32_t& p0, ui
     if (__builtin_amdgcn_ballot_w64((z[0] | z[1] | z[2] | z[3]) != 0) == 0) {     // wave-uniform
         v = 0xFFFFu;
     } else {
-        uint32_t ai[2] = {0, 0};
+        // z has no bit in positions 1, 2 (the table byte repeats the code bits) or 5, so z + 0x0C stays inside its byte:
+        // 0x0C for a standard base, >= 0x0D otherwise -- the byte permute's selectors for the constants 0x00 and 0xFF.
+        // A dot product of those bytes with the bit weights is 255 x (the invalid bits); starting from 0xFF its low
+        // byte is their complement: the validity bits of 8 bases from three instructions per dword.
+        uint32_t ai[2] = {0xFFu, 0xFFu};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const uint32_t w = (i & 1) ? 0x80402010u : 0x08040201u;
-            const uint32_t nz = (((z[i] & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | z[i]) & 0x80808080u;
-            ai[i >> 1] = __builtin_amdgcn_udot4(nz, w, ai[i >> 1], false);
+            const uint32_t bad = __builtin_amdgcn_perm(0u, 0u, z[i] + 0x0C0C0C0Cu);
+            ai[i >> 1] = __builtin_amdgcn_udot4(bad, w, ai[i >> 1], false);
         }
-        v = ~((ai[0] >> 7) | (ai[1] << 1)) & 0xFFFFu;
+        v = __builtin_amdgcn_perm(ai[1], ai[0], 0x0C0C0400u);      // low bytes of the two halves side by side
     }
 }
 
@@ -178,16 +182,6 @@ __device__ __forceinline__ void load_bits(const uint32_t* __restrict__ plane, in
     }
 }
 
-// Mask with the low `count` bits set across NW words (count may be <= 0 or >= 32*NW).
-template<int NW>
-__device__ __forceinline__ void low_bits(int count, uint32_t out[NW]) {
-#pragma unroll
-    for (int i = 0; i < NW; ++i) {
-        int c = count - 32 * i;
-        out[i] = c >= 32 ? 0xFFFFFFFFu : (c > 0 ? ((1u << c) - 1u) : 0u);
-    }
-}
-
 // x >>= g over NW little-endian words, g wave-uniform and < 32.
 template<int NW>
 __device__ __forceinline__ void shift_right_small(uint32_t x[NW], int g) {
@@ -223,15 +217,17 @@ struct BasePlanes {
 // NC = words of candidate positions kept (positions 0 .. 32*NC-1).  With NC < NW (the host
 // guarantees that every seed then starts below bit 32 and spans < 32 positions) only NC + 1
 // words of the running plane are ever needed.
+//
+// The masks are NOT cut off at the read's last window position n - T: bits beyond it come from whatever follows
+// the read in the tile and mean nothing.  Every consumer walks the candidates in ascending order and stops at the
+// first position > n - T (StagedRead::last), which costs it nothing -- it replaces the "no bits left" test -- where
+// building and applying per-lane length masks cost ~60 instructions a read.
 template<int NW, int NC>
-__device__ __forceinline__ void seed_candidates(const BasePlanes<NW>& E, const ScgSeeds& S, int tlen, int n,
-                                                uint32_t cand[NC]) {
+__device__ __forceinline__ void seed_candidates(const BasePlanes<NW>& E, const ScgSeeds& S, uint32_t cand[NC]) {
     constexpr int NS = (NC < NW) ? NC + 1 : NW;     // words of the running plane
-    uint32_t ok[NC];
-    low_bits<NC>(n - tlen + 1, ok);
     if (S.nseeds == 0) {
 #pragma unroll
-        for (int i = 0; i < NC; ++i) cand[i] = ok[i];
+        for (int i = 0; i < NC; ++i) cand[i] = 0xFFFFFFFFu;
         return;
     }
 #pragma unroll
@@ -251,7 +247,6 @@ __device__ __forceinline__ void seed_candidates(const BasePlanes<NW>& E, const S
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     int left = (int)((counts >> (8 * c)) & 0xFFu);
-                    int off = 0;
 #pragma unroll
                     for (int wi = 0; wi < SCG_SEED_STEPS / 4; ++wi) {
                         if (left <= 0) break;
@@ -259,9 +254,9 @@ __device__ __forceinline__ void seed_candidates(const BasePlanes<NW>& E, const S
 #pragma unroll
                         for (int h = 0; h < 2; ++h) {
                             if (left <= 2 * h) break;
-                            const int o1 = off + (int)((word >> (16 * h)) & 31u);
-                            const int o2 = o1 + (int)((word >> (16 * h + 8)) & 31u);
-                            off = o2;
+                            // (the funnel shift reads bits 4:0 of its shift operand: no masking of the offsets needed)
+                            const uint32_t o1 = word >> (16 * h);
+                            const uint32_t o2 = word >> (16 * h + 8);
 #pragma unroll
                             for (int i = 0; i < NC; ++i) {
                                 const uint32_t a = __builtin_amdgcn_alignbit(E.e[c][i + B + 1], E.e[c][i + B], o1);
@@ -292,6 +287,7 @@ __device__ __forceinline__ void seed_candidates(const BasePlanes<NW>& E, const S
                 for (int i = 0; i + 1 < NS; ++i) cur[i] = cur[i + 1];
                 cur[NS - 1] = 0;
             }
+            int at = 0;                                   // offset the running copy stands at
 #pragma unroll
             for (int wi = 0; wi < SCG_SEED_STEPS / 4; ++wi) {
                 if (left <= 0) break;
@@ -299,20 +295,18 @@ __device__ __forceinline__ void seed_candidates(const BasePlanes<NW>& E, const S
                 const int cnt = left < 4 ? left : 4;
                 left -= 4;
                 for (int k = 0; k < cnt; ++k) {
-                    const int sh = (int)(word & 31u);
-                    const uint32_t keep = (word & 0x80u) ? 0xFFFFFFFFu : 0u;   // pure shift: AND is a no-op
+                    const int o = (int)(word & 31u);
                     word >>= 8;
-                    shift_right_small<NS>(cur, sh);
+                    shift_right_small<NS>(cur, o - at);      // offsets ascend (a padding byte repeats the last one: shift by 0)
+                    at = o;
 #pragma unroll
-                    for (int i = 0; i < NC; ++i) g[i] &= (cur[i] | keep);
+                    for (int i = 0; i < NC; ++i) g[i] &= cur[i];
                 }
             }
         }
 #pragma unroll
         for (int i = 0; i < NC; ++i) cand[i] |= g[i];
     }
-#pragma unroll
-    for (int i = 0; i < NC; ++i) cand[i] &= ok[i];
 }
 
 // Lowest set bit of an NW-word mask, or 1 << 30 when empty.
@@ -475,34 +469,38 @@ struct StagedRead {
     int n;        // length
 };
 
-// Phase B for both strands of one template.
+// The last window position of a read of n bases for a template of tlen: candidates beyond it are not candidates
+// (seed_candidates leaves them in its masks).  Negative when the read is shorter than the template.
+__device__ __forceinline__ int last_position(int n, int tlen) { return n - tlen; }
+
+// Phase B for both strands of one template.  The candidate masks may hold bits beyond the read's last window position
+// (last_position): walk them in ascending order and stop there.
 template<int NW, int NC = NW>
 __device__ __forceinline__ void scan_read(const Tile<NW>& tile, const StagedRead& sr, const ScgScan& T,
                                           bool fwd, bool rev, uint32_t candF[NC], uint32_t candR[NC]) {
     BasePlanes<NW> E;
     {
-        uint32_t p0[NW], p1[NW], v[NW], lim[NW];
+        // (bits beyond the read's end belong to the next read: no seed looks at them from a position <= n - T)
+        uint32_t p0[NW], p1[NW], v[NW];
         load_bits<NW>(tile.p0, sr.bit, p0);
         load_bits<NW>(tile.p1, sr.bit, p1);
         load_bits<NW>(tile.v, sr.bit, v);
-        low_bits<NW>(sr.n, lim);
 #pragma unroll
         for (int i = 0; i < NW; ++i) {
-            uint32_t vv = v[i] & lim[i];
-            E.e[0][i] = vv & ~p0[i] & ~p1[i];
-            E.e[1][i] = vv & p0[i] & ~p1[i];
-            E.e[2][i] = vv & ~p0[i] & p1[i];
-            E.e[3][i] = vv & p0[i] & p1[i];
+            E.e[0][i] = v[i] & ~p0[i] & ~p1[i];
+            E.e[1][i] = v[i] & p0[i] & ~p1[i];
+            E.e[2][i] = v[i] & ~p0[i] & p1[i];
+            E.e[3][i] = v[i] & p0[i] & p1[i];
         }
     }
     if (fwd) {
-        seed_candidates<NW, NC>(E, T.fseeds, T.len, sr.n, candF);
+        seed_candidates<NW, NC>(E, T.fseeds, candF);
     } else {
 #pragma unroll
         for (int i = 0; i < NC; ++i) candF[i] = 0;
     }
     if (rev) {
-        seed_candidates<NW, NC>(E, T.rseeds, T.len, sr.n, candR);
+        seed_candidates<NW, NC>(E, T.rseeds, candR);
     } else {
 #pragma unroll
         for (int i = 0; i < NC; ++i) candR[i] = 0;

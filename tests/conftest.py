@@ -32,11 +32,25 @@ def oracle():
     return Oracle()
 
 
+class _Both:
+    """The package, plus the tests' R-level mirror (tests/rlevel.py: countSingleBarcodes, matrixOf* ...), under one name --
+    the reference's test files call both layers the same way."""
+
+    def __init__(self, package, rlevel):
+        self._package, self._rlevel = package, rlevel
+
+    def __getattr__(self, name):
+        if hasattr(self._package, name):
+            return getattr(self._package, name)
+        return getattr(self._rlevel, name)
+
+
 @pytest.fixture(scope="session")
 def sc():
     import screencounter_amd
+    from tests import rlevel
     screencounter_amd.load()
-    return screencounter_amd
+    return _Both(screencounter_amd, rlevel)
 
 
 @pytest.fixture(scope="session")

@@ -207,7 +207,7 @@ def test_r_level_helpers(sc):
     p = sc.parseBarcodeTemplate("ACGTNNNNAANNNTT")
     assert p["variable"] == {"pos": [5, 11], "len": [4, 3]}
     assert p["constant"] == ["ACGT", "AA", "TT"]
-    from screencounter_amd.api import ComboCounts
+    from tests.rlevel import ComboCounts
     a = ComboCounts(["first", "second"], {"first": [1, 2], "second": [1, 1]}, np.array([3, 4], dtype=np.int32), 10)
     b = ComboCounts(["first", "second"], {"first": [2, 3], "second": [1, 2]}, np.array([5, 6], dtype=np.int32), 11)
     combos, mat = sc.combineComboCounts(a, b)

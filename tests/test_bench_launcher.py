@@ -51,3 +51,22 @@ def test_two_ranks_on_one_gpu_rehearsal(gpu):
     assert outs[2]["config"]["reads_per_gpu"] == 3000000
     assert abs(outs[2]["mapped_fraction"] - outs[1]["mapped_fraction"]) < 0.002
     assert outs[1]["e2e"] and "pinned_batches" in outs[1]["e2e"] and "fastq_file" in outs[1]["e2e"]
+
+
+@pytest.mark.gpu
+def test_rccl_path_at_world_size_one(gpu):
+    """SCG_BENCH_FORCE_DIST=1: init_process_group("nccl", device_id=...) -- RCCL on ROCm -- the all_reduce of the bound
+    count vector, the barriers and the MAX reduction of the step time all execute at world size 1 on this box's one GPU
+    (the multi-GPU form of the bench differs only in the number of ranks).  Same counts as without the process group."""
+    args = ["--config", "2", "--reads", "2000000", "--steps", "3", "--warmup", "1", "--settle", "0", "--cpu-sample", "0",
+            "--e2e-sample", "0", "--e2e-file-sample", "0"]
+    outs = {}
+    for forced in ("0", "1"):
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + args,
+                           env=_env(SCG_BENCH_FORCE_DIST=forced, HSA_ENABLE_IPC_MODE_LEGACY="0"), cwd=ROOT, capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, p.stderr[-3000:]
+        lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1
+        outs[forced] = json.loads(lines[0])
+    assert "RCCL all-reduce" in outs["1"]["config"]["parallelism"] and "RCCL" not in outs["0"]["config"]["parallelism"]
+    assert outs["1"]["mapped_fraction"] == outs["0"]["mapped_fraction"] and outs["1"]["n_gpus"] == 1

@@ -122,3 +122,73 @@ def test_config1_fixture_gpu(sc, gpu):
         got, total = plan.read()
     assert total == fx["expect"]["total"]
     assert got.tolist() == fx["expect"]["counts"]
+
+
+def _option_cases():
+    cases = []
+    for config in (2, 3, 5):
+        for use_first in (True, False):
+            for strand in (0, 1, 2):
+                if (use_first, strand) == (True, 2):
+                    continue                                  # the configuration's own option point: test_config_scale_parity
+                cases.append((config, use_first, strand, False, None))
+    for use_first in (True, False):
+        for randomized in (False, True):
+            if (use_first, randomized) == (True, False):
+                continue
+            cases.append((4, use_first, 0, randomized, None))
+    for use_first in (True, False):
+        cases.append((3, use_first, 2, False, 2))             # combinations with a budget of 2: the six pairs-of-quarters tables per pool
+        cases.append((2, use_first, 2, False, 0))             # exact matching: one table, no walk
+    return cases
+
+
+@pytest.mark.parametrize("config,use_first,strand,randomized,mismatches", _option_cases())
+def test_config_scale_options(sc, gpu, tmp_path, config, use_first, strand, randomized, mismatches):
+    """The other option points of every entry -- find.best = TRUE (search_best's tie logic over the 100 k-entry index,
+    SimpleSingleMatch.hpp:259-306), strand = original / reverse, randomized = TRUE (DualBarcodesPairedEnd.hpp:353-371;
+    config 4's pools are >= 3 apart, so the reference's cache-order hazard, SURVEY.md A.7, cannot occur) -- on 2^18 reads of
+    the configuration's own stream and library, against real kaori."""
+    from oracle.pyoracle import KaoriRef
+    from screencounter_amd import synth
+    from screencounter_amd.engine import Plan
+    if not KaoriRef.available():
+        pytest.skip("oracle/_ref/libkaori_ref.so is not here")
+    n = (1 << 18) + 77
+    w = synth.workload(config, n_reads=n)
+    L = w.read_len
+    dw = synth.DeviceWorkload(w, gpu)
+    mates = [dw.generate(n, mate=0)]
+    if w.entry == "dual":
+        mates.append(dw.generate(n, mate=1))
+    if mismatches is not None:
+        w.mismatches = mismatches                            # (the stream is the configuration's; only the budget differs)
+    paths = []
+    for m, t in enumerate(mates):
+        p = str(tmp_path / f"opt{config}_{m}.fastq")
+        synth.reads_to_fastq(p, t.cpu().numpy(), L)
+        paths.append(p)
+    ref = KaoriRef()
+    dev = gpu.index if gpu.index is not None else 0
+    if w.entry == "single":
+        exp, exp_total = ref.count_single(paths[0], w.template, strand, w.pools[0], w.mismatches, use_first, 1)
+        plan = Plan.single(w.template, strand, w.pools[0], w.mismatches, use_first, device=dev)
+    elif w.entry == "combo":
+        idx, freq, exp_total = ref.count_combo(paths[0], w.template, strand, w.pools[0], w.pools[1], w.mismatches, use_first, 1)
+        exp = _dense(idx, freq, len(w.pools[1]), len(w.pools[0]) * len(w.pools[1]))
+        plan = Plan.combo(w.template, strand, w.pools[0], w.pools[1], w.mismatches, use_first, device=dev)
+    else:
+        exp, exp_total = ref.count_dual(paths[0], w.template, False, w.mismatches, w.pools[0], paths[1], w.template2, False, w.mismatches,
+                                        w.pools[1], randomized, use_first, 1)
+        plan = Plan.dual(w.template, False, w.mismatches, w.pools[0], w.template2, False, w.mismatches, w.pools[1],
+                         randomized=randomized, use_first=use_first, device=dev)
+    with plan:
+        if w.entry == "dual":
+            plan.count_paired(mates[0], mates[1], fixed_len1=L, fixed_len2=L, n_pairs=n)
+        else:
+            plan.count(mates[0], fixed_len=L, n_reads=n)
+        got, total = plan.read()
+    exp = np.asarray(exp, dtype=np.int64)
+    assert total == exp_total == n
+    assert np.array_equal(got.astype(np.int64), exp), f"HIP path differs from kaori on config {config}, use_first={use_first}, strand={strand}, randomized={randomized}"
+    assert int(exp.sum()) > (0.3 if (strand != 2 and w.entry != "dual") or mismatches == 0 else 0.7) * n

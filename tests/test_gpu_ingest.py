@@ -385,3 +385,66 @@ def test_cached_slots_serve_every_pipeline(sc, oracle, gpu, tmp_path, monkeypatc
             assert n == total and np.array_equal(got, exp), (kb, form, env)
             for k in env:
                 monkeypatch.delenv(k)
+
+
+def test_ordinary_gzip_decoded_by_all_host_threads(sc, oracle, gpu, tmp_path, monkeypatch):
+    """A .fastq.gz that is not BGZF goes through the parallel decoder (csrc/scg_pgzip.h: chunks decoded with an unknown
+    window, stitched, CRC-checked); SCG_PGZIP_CHUNK_KB makes these small files take it.  Single-end and paired, one and
+    several members, tiny windows; and a file the decoder hands back (corrupt: the reference's error, through zlib)."""
+    import zlib
+    from screencounter_amd import _lib
+    pool, reads = make_case(21, n=12000)
+    exp, total = oracle.count_single(reads, TEMPLATE, 2, pool, 1, True)
+    text = gen.fastq_text(reads)
+
+    def gz(data, level=6):
+        c = zlib.compressobj(level, zlib.DEFLATED, 31)
+        return c.compress(data) + c.flush()
+
+    one = str(tmp_path / "one.fastq.gz")
+    open(one, "wb").write(gz(text, 4))
+    several = str(tmp_path / "several.fastq.gz")
+    third = (len(text) // 3)
+    cut1, cut2 = text.index(b"\n@", third) + 1, text.index(b"\n@", 2 * third) + 1
+    open(several, "wb").write(gz(text[:cut1], 6) + gz(text[cut1:cut2], 1) + gz(text[cut2:], 9))
+    monkeypatch.setenv("SCG_PGZIP_CHUNK_KB", "32")
+    for kb in (None, 16):
+        if kb:
+            monkeypatch.setenv("SCG_WINDOW_KB", str(kb))
+        for path in (one, several):
+            got, n = sc.count_single_barcodes(path, TEMPLATE, 2, pool, 1, True, 4)
+            assert n == total == len(reads) and np.array_equal(got, exp), (kb, path)
+    monkeypatch.delenv("SCG_WINDOW_KB")
+    # the same file with the decoder switched off must agree (and is what a declined file falls back to)
+    monkeypatch.setenv("SCG_PGZIP", "0")
+    got, n = sc.count_single_barcodes(one, TEMPLATE, 2, pool, 1, True, 4)
+    assert n == total and np.array_equal(got, exp)
+    monkeypatch.delenv("SCG_PGZIP")
+    # both mates gzip: two decoders share the host threads
+    rng = random.Random(22)
+    t1, t2 = "ACGTAC" + "-" * 10 + "TGCATG", "GGATCC" + "-" * 8 + "AAGCTT"
+    u1, u2 = gen.make_pool(rng, 12, 10, "ACGT", min_dist=3), gen.make_pool(rng, 10, 8, "ACGT", min_dist=3)
+    pairs = [(a, b) for a in u1 for b in u2][:50]
+    pool1, pool2 = [a for a, _ in pairs], [b for _, b in pairs]
+    r1, r2 = [], []
+    for i in range(8000):
+        a, b = rng.choice(pairs)
+        r1.append(gen.rand_seq(rng, rng.randint(0, 40)) + gen.mutate(rng, gen.fill_template(t1, [a]), 0.02, 0.01, 0.02))
+        r2.append(gen.mutate(rng, gen.fill_template(t2, [b]), 0.02, 0.01, 0.02) + gen.rand_seq(rng, rng.randint(0, 9)))
+    e, t = oracle.count_dual(r1, r2, t1, False, 1, pool1, t2, False, 1, pool2, False, True)
+    p1, p2 = str(tmp_path / "m1.fastq.gz"), str(tmp_path / "m2.fastq.gz")
+    open(p1, "wb").write(gz(gen.fastq_text(r1), 6))
+    open(p2, "wb").write(gz(gen.fastq_text(r2), 6))
+    got, n = sc.count_dual_barcodes(p1, t1, False, 1, pool1, p2, t2, False, 1, pool2, False, True, False, 4)
+    assert n == t == len(r1) and np.array_equal(got, e)
+    # a corrupt stream: handed back by the decoder, reported the way the sequential reader (zlib) reports it
+    raw = bytearray(open(one, "rb").read())
+    raw[len(raw) // 2] ^= 0x10
+    bad = str(tmp_path / "bad.fastq.gz")
+    open(bad, "wb").write(bytes(raw))
+    with pytest.raises(_lib.ScgError) as e1:
+        sc.count_single_barcodes(bad, TEMPLATE, 2, pool, 1, True, 4)
+    monkeypatch.setenv("SCG_PGZIP", "0")
+    with pytest.raises(_lib.ScgError) as e2:
+        sc.count_single_barcodes(bad, TEMPLATE, 2, pool, 1, True, 4)
+    assert e1.value.code == e2.value.code == _lib.SCG_ERR_IO and str(e1.value) == str(e2.value)
