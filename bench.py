@@ -43,7 +43,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (guides/MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
-KERNEL_OF = {"single": "single_staged_kernel", "combo": "combo_staged_kernel", "dual": "dual_staged_kernel"}
+KERNEL_OF = {"single": "single_staged_kernel", "combo": "combo_staged_kernel", "dual": "dual_passes_kernel"}
 
 
 def parse_args():

@@ -65,8 +65,13 @@ int scg_device_count(void);
  * else the visible devices starting with the calling thread's current
  * one -- as many of them as the input has groups of four 128 MB windows of FASTQ text, so that a small file stays on
  * one GPU and a large one spreads its windows over all of them.  The single-end entry points shard one file over
- * their devices (per-device counts are summed before the call returns); paired-end files and BGZF files run on the
- * first device; the *_files entry points give every device one file at a time.
+ * their devices, whatever its form -- plain, gzip or BGZF (there the windows are chained by the partial record at each
+ * window's end, which the next device fetches over xGMI; without peer access the file stays on one device) -- and the
+ * per-device counts are summed on the host before the call returns: 400 KB per device, no collective inside the library
+ * (the one RCCL all-reduce of the path belongs to the process-per-GPU driver above it: bench.py, parallel.py).  Paired-end
+ * plain files are shared out by record index: every round of pairs the two files' windows have in common goes to one
+ * device, round-robin, which pulls exactly those records of both mates over its own link; paired files of which one is
+ * compressed run on the first device.  The *_files entry points give every device one file at a time.
  *
  * Input forms of the file-level entry points: plain FASTQ (records found by the host threads, sequences shipped), BGZF
  * (members inflated, checked and scanned on the device), any other gzip of 2 MB or more (decoded by all host threads at
@@ -229,8 +234,9 @@ void scg_free(void* p);
 /* The file-level entry points keep the pinned host windows and HBM scratch of their last run for the next call: at most
  * four window slots per device (counts never depend on it).  A slot of the plain / gzip pipelines is 128 MB of pinned
  * memory + ~290 MB of HBM; a slot of the BGZF pipeline (members inflated on the device) ~145 MB pinned + ~0.6 GB of HBM,
- * so up to ~2.4 GB of HBM and ~0.6 GB of pinned memory per device stay allocated between calls.  This releases them;
- * SCG_BUFFER_CACHE=0 disables the cache altogether. */
+ * so up to ~2.4 GB of HBM and ~0.6 GB of pinned memory per device stay allocated between calls.  The parallel gzip decoder
+ * likewise keeps its symbol buffers (up to 40, ~12 MB resident each).  This releases all of them; SCG_BUFFER_CACHE=0
+ * disables the cache of window slots altogether. */
 void scg_release_buffers(void);
 
 /* ---------------------------------------------------------------------------------------------
@@ -312,7 +318,9 @@ void scg_plan_destroy(scg_plan* plan);
 
 /* Number of int32 counters the plan accumulates into: n_pool (single, dual) or
  * n_pool0 * n_pool1 (combo; dense histogram, cell = first * n_pool1 + second); dual plans with
- * diagnostics add 2 + n_uid1 * n_uid2 counters behind the n_pool pair counts. */
+ * diagnostics add 2 + n_uid1 * n_uid2 counters behind the n_pool pair counts.  Combination spaces of more than 2^26
+ * cells are not kept as cells: the combinations are sorted and run-length encoded instead (scg_plan_read_combinations,
+ * scg_plan_read_diagnostics), as the reference does for any size (kaori/utils.hpp:173-198, src/utils.h:14-45). */
 int64_t scg_plan_num_counters(const scg_plan* plan);
 
 /* Device pointer to those counters (for an RCCL all-reduce across ranks) and, optionally, a
@@ -342,6 +350,14 @@ int scg_count_batch_paired(scg_plan* plan,
  * so far to the host.  Either output may be NULL. */
 int scg_plan_read(scg_plan* plan, int32_t* counts_out, int64_t* total_out, void* stream,
                   char* err, size_t errcap);
+
+/* Combination plans (scg_plan_combo): the counted combinations in the form scg_count_combo_barcodes_single returns them
+ * -- a malloc'd 2 x K matrix of 0-based indices sorted by (first, second), K frequencies (release both with scg_free) --
+ * whether the plan keeps a dense histogram (n_pool0 x n_pool1 <= 2^26 cells: scg_plan_read + scg_combo_compact give the
+ * same) or, beyond that, sorts and run-length encodes the combinations of every batch on the device and merges the runs
+ * (scg_plan_num_counters is 0 then).  Synchronises `stream`. */
+int scg_plan_read_combinations(scg_plan* plan, int32_t** indices_out, int32_t** freq_out, int64_t* k_out, int64_t* total_out,
+                               void* stream, char* err, size_t errcap);
 
 /* Dual plans built with diagnostics != 0: the five outputs of the include.invalid=TRUE branch
  * (see scg_count_dual_barcodes_diagnostics) from the plan's counters; synchronises `stream`. */

@@ -113,6 +113,7 @@ SIGNATURES = {
     "scg_count_batch_paired": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
                                          C.c_int32, C.c_int64, C.c_void_p, C.c_char_p, C.c_size_t]),
     "scg_plan_read": (C.c_int, [C.c_void_p, i32_p, i64_p, C.c_void_p, C.c_char_p, C.c_size_t]),
+    "scg_plan_read_combinations": (C.c_int, [C.c_void_p, C.POINTER(i32_p), C.POINTER(i32_p), i64_p, i64_p, C.c_void_p, C.c_char_p, C.c_size_t]),
     "scg_combo_compact": (C.c_int, [i32_p, C.c_int32, C.c_int32, C.POINTER(i32_p), C.POINTER(i32_p), i64_p, C.c_char_p, C.c_size_t]),
     "scg_plan_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "scg_plan_kernel_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), i64_p, C.c_char_p, C.c_size_t]),

@@ -27,6 +27,7 @@
 
 #include "scg_host.h"
 #include "scg_ingest.h"
+#include "scg_pgzip.hpp"
 #include "scg_launch.h"
 #include "scg_textscan.h"
 
@@ -207,7 +208,24 @@ struct scg_plan {
     DevBuf replicas;     // privatised counter copies (ScgCounters); empty when n_counters is large
     scg::HostIndex htab_combined;   // DUAL_SE_DIAG: wide index of the concatenated combinations (tab[0..1] = the per-region pools)
     DevIndex tab_combined;
+    std::map<hipStream_t, DevBuf> overflow;     // pair search: the batch's pairs left to the byte-wise search (ScgDualParams::overflow)
     std::map<hipStream_t, DevBuf> unit_index;   // tally mode: barcode index per read of the batch in flight on each stream (ScgCounters::unit_index)
+    // Sparse mode: the combination space (n0 x n1 pools, or the invalid pairs of include.invalid=TRUE) is beyond the dense
+    // limit, so combinations travel as a stream of 64-bit keys per batch (ScgCounters::unit_pair), are sorted and
+    // run-length encoded on the device (scg_sparse.hip) and merged here -- the reference's own algorithm
+    // (kaori/utils.hpp:173-198, src/utils.h:14-45).
+    bool sparse = false;
+    struct PairStream {
+        DevBuf keys, sorted, unique, counts, runs, scratch;
+        int64_t pending = 0;                    // reads of the batch whose runs have not been merged yet
+        hipEvent_t done = nullptr;              // behind the batch's sort + run-length encode (the stream may be gone when the runs are read)
+        PairStream() {}
+        PairStream(const PairStream&) = delete;
+        PairStream& operator=(const PairStream&) = delete;
+        ~PairStream() { if (done) (void)hipEventDestroy(done); }
+    };
+    std::map<hipStream_t, PairStream> pair_stream;
+    std::unordered_map<uint64_t, int64_t> sparse_counts;
     int replica_shift = 0;   // log2(replicas)
     DevBuf error_flag;   // set by a staged kernel that met a read longer than the declared maximum
     int32_t* counters = nullptr;
@@ -276,6 +294,13 @@ struct scg_plan {
 };
 
 namespace {
+// 256 MB of int32 cells: beyond that, combinations are sorted and run-length encoded.  $SCG_DENSE_CELLS moves the limit (the
+// tests run every combination case both ways).
+int64_t dense_cells() {
+    const char* e = getenv("SCG_DENSE_CELLS");
+    if (e && *e) return std::min<int64_t>(std::max<int64_t>(atoll(e), 0), int64_t(1) << 30);
+    return int64_t(1) << 26;
+}
 
 ScgReads make_reads(const char* d_seqs, const uint32_t* d_offsets, int32_t fixed_len, int32_t max_len) {
     ScgReads r;
@@ -403,10 +428,8 @@ std::unique_ptr<scg_plan> compile_combo(const char* constant, int strand,
     P->scan1 = scg::build_scan(P->ht1.t, mismatches);
     P->n_pool[0] = n0; P->n_pool[1] = n1;
     int64_t cells = static_cast<int64_t>(n0) * static_cast<int64_t>(n1);
-    if (cells > (int64_t(1) << 30)) {
-        throw Error(SCG_ERR_UNSUPPORTED, "combination space larger than 2^30 cells is not supported by the dense histogram");
-    }
-    P->n_counters = cells;
+    P->sparse = cells > dense_cells();                           // beyond the dense limit: sort + run-length encode, like the reference
+    P->n_counters = P->sparse ? 0 : cells;
     P->max_mm1 = mismatches;
     P->use_first = use_first != 0;
     return P;
@@ -461,11 +484,9 @@ std::unique_ptr<scg_plan> compile_dual(const char* constant1, int reverse1, int 
         P->first1 = firsts(exp1, n_uid1);
         P->first2 = firsts(exp2, n_uid2);
         int64_t cells = static_cast<int64_t>(n_uid1) * static_cast<int64_t>(n_uid2);
-        if (cells > (int64_t(1) << 28)) {
-            throw Error(SCG_ERR_UNSUPPORTED, "include.invalid=TRUE needs n_unique1 x n_unique2 <= 2^28 cells in this engine");
-        }
+        P->sparse = cells > dense_cells();
         P->diagnostics = 1;
-        P->n_counters = static_cast<int64_t>(n_pool) + 2 + cells;
+        P->n_counters = static_cast<int64_t>(n_pool) + 2 + (P->sparse ? 0 : cells);
     }
     P->max_mm1 = mismatches1; P->max_mm2 = mismatches2;
     P->rev1 = reverse1 != 0; P->rev2 = reverse2 != 0;
@@ -505,11 +526,9 @@ std::unique_ptr<scg_plan> compile_dual_single_end_diag(const char* constant, int
     P->first1 = firsts(exp0, n_uid0);
     P->first2 = firsts(exp1, n_uid1);
     int64_t cells = static_cast<int64_t>(n_uid0) * static_cast<int64_t>(n_uid1);
-    if (cells > (int64_t(1) << 28)) {
-        throw Error(SCG_ERR_UNSUPPORTED, "include.invalid=TRUE needs n_unique1 x n_unique2 <= 2^28 cells in this engine");
-    }
+    P->sparse = cells > dense_cells();
     P->n_pool[1] = P->n_pool[0];
-    P->n_counters = static_cast<int64_t>(P->n_pool[0]) + 2 + cells;
+    P->n_counters = static_cast<int64_t>(P->n_pool[0]) + 2 + (P->sparse ? 0 : cells);
     return P;
 }
 
@@ -540,14 +559,14 @@ std::unique_ptr<scg_plan> compile_paired_combo(const char* constant1, int revers
     P->scan1 = scg::build_scan(P->ht1.t, mismatches1);
     P->scan2 = scg::build_scan(P->ht2.t, mismatches2);
     int64_t cells = static_cast<int64_t>(n1) * static_cast<int64_t>(n2);
-    if (cells > (int64_t(1) << 28)) throw Error(SCG_ERR_UNSUPPORTED, "paired combinations need n_pool1 x n_pool2 <= 2^28 cells in this engine");
+    P->sparse = cells > dense_cells();
     P->first1.resize(n1);
     P->first2.resize(n2);
     for (int32_t i = 0; i < n1; ++i) P->first1[i] = i;
     for (int32_t i = 0; i < n2; ++i) P->first2[i] = i;
     P->n_pool[0] = P->n_pool[1] = 0;                           // no list of valid pairs
     P->diagnostics = 2;
-    P->n_counters = 2 + cells;                                 // [barcode1-only][barcode2-only][n1 x n2]
+    P->n_counters = 2 + (P->sparse ? 0 : cells);               // [barcode1-only][barcode2-only][n1 x n2]
     P->max_mm1 = mismatches1; P->max_mm2 = mismatches2;
     P->rev1 = reverse1 != 0; P->rev2 = reverse2 != 0;
     P->randomized = randomized != 0;
@@ -565,8 +584,59 @@ ScgCounters plan_counters(const scg_plan* P) {
         c.base = P->counters; c.replica_mask = 0; c.replica_shift = 0;
     }
     c.unit_index = nullptr;
+    c.unit_pair = nullptr;
     c.hot = P->hot.p ? P->hot.as<int32_t>() : nullptr;
     return c;
+}
+
+// ---- sparse mode: combination streams ----
+
+// The runs of the batch last counted on `stream` -> the plan's map.
+void retire_pairs(scg_plan* P, hipStream_t stream, scg_plan::PairStream& ps) {
+    if (!ps.pending) return;
+    uint32_t runs = 0;
+    HIP_CHECK(hipEventSynchronize(ps.done));
+    HIP_CHECK(hipMemcpy(&runs, ps.runs.p, sizeof(runs), hipMemcpyDeviceToHost));
+    std::vector<uint64_t> keys(runs);
+    std::vector<uint32_t> counts(runs);
+    if (runs) {
+        HIP_CHECK(hipMemcpy(keys.data(), ps.unique.p, sizeof(uint64_t) * runs, hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(counts.data(), ps.counts.p, sizeof(uint32_t) * runs, hipMemcpyDeviceToHost));
+    }
+    for (uint32_t i = 0; i < runs; ++i) {
+        if (keys[i] != ~uint64_t(0)) P->sparse_counts[keys[i]] += counts[i];
+    }
+    ps.pending = 0;
+}
+
+// A stream of n keys for the next batch on `stream`, every slot "none" (kernels that skip a read leave it so).
+uint64_t* begin_pairs(scg_plan* P, hipStream_t stream, int64_t n) {
+    scg_plan::PairStream& ps = P->pair_stream[stream];
+    retire_pairs(P, stream, ps);
+    const size_t m = static_cast<size_t>(std::max<int64_t>(n, 1));
+    ps.keys.ensure(m * sizeof(uint64_t));
+    ps.sorted.ensure(m * sizeof(uint64_t));
+    ps.unique.ensure(m * sizeof(uint64_t));
+    ps.counts.ensure(m * sizeof(uint32_t));
+    if (!ps.runs.p) ps.runs.alloc(sizeof(uint32_t));
+    ps.scratch.ensure(scg::sort_rle_scratch_bytes(m));
+    HIP_CHECK(hipMemsetAsync(ps.keys.p, 0xFF, m * sizeof(uint64_t), stream));
+    return ps.keys.as<uint64_t>();
+}
+
+// Behind the counting kernels of the batch: sort + run-length encode, still asynchronous.
+void finish_pairs(scg_plan* P, hipStream_t stream, int64_t n) {
+    scg_plan::PairStream& ps = P->pair_stream[stream];
+    HIP_CHECK(scg::launch_sort_rle(ps.keys.as<uint64_t>(), ps.sorted.as<uint64_t>(), static_cast<size_t>(n), ps.unique.as<uint64_t>(),
+                                   ps.counts.as<uint32_t>(), ps.runs.as<uint32_t>(), ps.scratch.p, ps.scratch.bytes, stream));
+    if (!ps.done) HIP_CHECK(hipEventCreateWithFlags(&ps.done, hipEventDisableTiming));
+    HIP_CHECK(hipEventRecord(ps.done, stream));
+    ps.pending = n;
+}
+
+void retire_all_pairs(scg_plan* P) {
+    DeviceGuard g(P->device);
+    for (auto& kv : P->pair_stream) retire_pairs(P, kv.first, kv.second);
 }
 
 // Tally mode pays off when the library is large enough that block-level aggregation finds no repeats
@@ -599,7 +669,7 @@ void launch_batch_se_diag(scg_plan* P, const ScgReads& R, int64_t n, hipStream_t
     sp.max_mm = P->max_mm1; sp.use_first = P->use_first;
     sp.fwd = P->ht1.fwd; sp.rev = P->ht1.rev;
     ScgCounters c1;
-    c1.base = P->counters; c1.replica_mask = 0; c1.replica_shift = 0; c1.hot = nullptr;
+    c1.base = P->counters; c1.replica_mask = 0; c1.replica_shift = 0; c1.hot = nullptr; c1.unit_pair = nullptr;
     c1.unit_index = buf.as<int32_t>();
     HIP_CHECK(scg::launch_single(sp, P->ht1.t.len, R, n, c1, P->error_flag.as<int32_t>(), stream));
     HIP_CHECK(scg::launch_tally(c1.unit_index, n, P->counters, P->n_pool[0], stream));
@@ -613,8 +683,10 @@ void launch_batch_se_diag(scg_plan* P, const ScgReads& R, int64_t n, hipStream_t
     cp.only_if_negative = c1.unit_index; cp.keep_first = 1; cp.pad = 0;
     ScgCounters c2;
     c2.base = P->counters + P->n_pool[0] + 2; c2.replica_mask = 0; c2.replica_shift = 0; c2.unit_index = nullptr; c2.hot = nullptr;
+    c2.unit_pair = P->sparse ? begin_pairs(P, stream, n) : nullptr;
     HIP_CHECK(scg::launch_combo(cp, P->ht1.t.len, R, n, c2, P->error_flag.as<int32_t>(), stream));
     timer.stop();
+    if (P->sparse) finish_pairs(P, stream, n);
     P->total += n;
 }
 
@@ -652,6 +724,14 @@ void launch_batch(scg_plan* P, const ScgReads& R, int64_t n, hipStream_t stream)
         cp.fwd = P->ht1.fwd; cp.rev = P->ht1.rev;
         cp.only_if_negative = nullptr; cp.keep_first = 0; cp.pad = 0;
         ScgCounters counts = plan_counters(P);
+        if (P->sparse) {
+            counts.unit_pair = begin_pairs(P, stream, n);
+            HIP_CHECK(scg::launch_combo(cp, P->ht1.t.len, R, n, counts, P->error_flag.as<int32_t>(), stream));
+            timer.stop();
+            finish_pairs(P, stream, n);
+            P->total += n;
+            return;
+        }
         const bool tally = use_tally(P, n) && R.max_len > 0 && R.max_len <= 320 && !scg::force_general();
         if (tally) {
             DevBuf& buf = P->unit_index[stream];
@@ -700,9 +780,16 @@ void launch_batch_paired(scg_plan* P, const ScgReads& R1, const ScgReads& R2, in
     dp.diagnostics = P->diagnostics; dp.n_pool = P->diagnostics == 2 ? 0 : P->n_pool[0]; dp.n_uid2 = static_cast<int32_t>(P->first2.size());
     dp.keep_first = P->diagnostics == 1; dp.only_if_negative = nullptr;
     ScgCounters counts = plan_counters(P);
+    if (P->sparse) counts.unit_pair = begin_pairs(P, stream, n);      // (the invalid / all combinations of the diagnostics passes)
     const int lo_len = std::min(R1.max_len, R2.max_len), hi_len = std::max(R1.max_len, R2.max_len);
     const bool staged = lo_len > 0 && hi_len <= 320 && !scg::force_general();
     const int tmpl_len = std::max(P->ht1.t.len, P->ht2.t.len);
+    dp.overflow = nullptr;
+    if (staged && P->diagnostics != 2 && n < INT32_MAX) {
+        DevBuf& buf = P->overflow[stream];
+        buf.ensure((static_cast<size_t>(n) + 1) * sizeof(int32_t));
+        dp.overflow = buf.as<int32_t>();
+    }
     if (P->diagnostics == 1 && staged) {
         // include.invalid=TRUE in two lean passes: valid pairs as an index stream (tallied), then the mate-by-mate
         // search on the pairs that found none
@@ -710,6 +797,7 @@ void launch_batch_paired(scg_plan* P, const ScgReads& R1, const ScgReads& R2, in
         buf.ensure(static_cast<size_t>(n) * sizeof(int32_t));
         ScgCounters c1 = counts;
         c1.unit_index = buf.as<int32_t>();
+        c1.unit_pair = nullptr;
         dp.diagnostics = 0;
         HIP_CHECK(scg::launch_dual(dp, tmpl_len, R1, R2, n, c1, P->error_flag.as<int32_t>(), stream));
         HIP_CHECK(scg::launch_tally(c1.unit_index, n, P->counters, P->n_pool[0], stream));
@@ -717,6 +805,7 @@ void launch_batch_paired(scg_plan* P, const ScgReads& R1, const ScgReads& R2, in
         dp.only_if_negative = c1.unit_index;
         HIP_CHECK(scg::launch_dual(dp, tmpl_len, R1, R2, n, counts, P->error_flag.as<int32_t>(), stream));
         timer.stop();
+        if (P->sparse) finish_pairs(P, stream, n);
         fold_replicas(P, stream);
         HIP_CHECK(scg::launch_hot_fold(P->hot.as<int32_t>(), P->counters + P->n_pool[0], stream));
         P->total += n;
@@ -730,6 +819,7 @@ void launch_batch_paired(scg_plan* P, const ScgReads& R1, const ScgReads& R2, in
     }
     HIP_CHECK(scg::launch_dual(dp, tmpl_len, R1, R2, n, counts, P->error_flag.as<int32_t>(), stream));
     timer.stop();
+    if (P->sparse) finish_pairs(P, stream, n);
     if (tally) HIP_CHECK(scg::launch_tally(counts.unit_index, n, P->counters, P->n_counters, stream));
     else fold_replicas(P, stream);
     if (P->hot.p) HIP_CHECK(scg::launch_hot_fold(P->hot.as<int32_t>(), P->counters + (P->diagnostics == 2 ? 0 : P->n_pool[0]), stream));
@@ -953,6 +1043,7 @@ uint32_t enqueue_gather(ScanSlot& s, const scg::ParsedWindow& w) {
         G.off_src[i] = s.h_offsets.as<uint32_t>() + g.off_at;
         G.seq_at[i] = at;
         G.first[i] = rec;
+        G.off_base[i] = 0;
         rec += g.n_records;
         at += g.seq_bytes;
     }
@@ -1218,20 +1309,42 @@ scg::TextScanResult inflate_window_records(const ScanSlot& s) {
     return r;
 }
 
+// Kernels of one device read another device's memory (the previous window's tail, when the windows of a BGZF file go
+// round-robin over the devices of a call): peer access, once per ordered pair.  False if the hardware does not offer it.
+bool enable_peer_access(const std::vector<int>& devices) {
+    for (int a : devices) {
+        for (int b : devices) {
+            if (a == b) continue;
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, a, b) != hipSuccess || !can) return false;
+            DeviceGuard g(a);
+            const hipError_t e = hipDeviceEnablePeerAccess(b, 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { (void)hipGetLastError(); return false; }
+            (void)hipGetLastError();
+        }
+    }
+    return true;
+}
+
 // The single-end pipeline for BGZF input with the members inflated on the device (scg_inflate.hip).  Per window, on
 // the slot's stream: compressed members + their table -> HBM; inflate + CRC check into the text buffer behind a gap of
 // GAP bytes; then -- once the previous window has been scanned -- the gap receives that window's partial last record
-// (launch_carry_tail), the text is scanned for records (allow_tail) and the result comes back.  The inflate kernels of
-// up to three windows overlap; only the carry chains the windows.  One device.
+// (launch_carry_tail), the text is scanned for records (allow_tail) and the result comes back.  The windows go round-robin
+// over the devices of the call, three slots each: the inflate kernels -- the expensive part -- of all of them overlap;
+// only the carry chains the windows, and where the previous window lies on another device the carry kernel reads its
+// tail (<= 1 MB) and its scan result over xGMI (peer access; the streams wait on each other's events).
 class InflatePipeline {
 public:
-    InflatePipeline(scg::TextSource& source, int dev) : src(source), device(dev) {
+    InflatePipeline(scg::TextSource& source, const std::vector<int>& devs) : src(source), devices(devs) {
+        if (devices.size() > 1 && !enable_peer_access(devices)) devices.resize(1);
         cap_text = inflate_window_text(source.size_hint());
         window = inflate_window_slot(cap_text);
         cap_in = inflate_window_staging(cap_text);
         for (int k = 0; k < 3; ++k) {
-            slots.push_back(slot_pool().take(device, window, cap_in));
-            slots.back()->ensure_inflate();
+            for (int d : devices) {
+                slots.push_back(slot_pool().take(d, window, cap_in));
+                slots.back()->ensure_inflate();
+            }
         }
         tr.mark("  scan slots (pinned + HBM)");
     }
@@ -1244,12 +1357,14 @@ public:
             if (ok) slot_pool().give(std::move(s));
         }
     }
+    size_t n_devices() const { return devices.size(); }
 
     void start() { if (!ended && filled == 0) fill_next(); }
 
-    void run(scg_plan* plan) {
-        for (auto& s : slots) s->plan = plan;
-        const size_t lag = 2;
+    // plans[i] counts what device i of the list was given (fewer plans than devices: the list was cut down at construction)
+    void run(const std::vector<scg_plan*>& plans) {
+        for (size_t i = 0; i < slots.size(); ++i) slots[i]->plan = plans[(i % devices.size()) % plans.size()];
+        const size_t lag = std::min(2 * devices.size(), slots.size() - 1);
         while (!ended) {
             fill_next();
             if (filled > lag && finished < filled - lag) finish_next();
@@ -1262,15 +1377,15 @@ public:
         }
         ok = true;
         if (tr.on) {
-            std::fprintf(stderr, "[scg]   windows of %zu MB (device inflate): host fill %.2f ms, waiting for the device %.2f ms, for free slots %.2f ms\n",
-                         cap_text >> 20, t_fill, t_finish, t_busy);
+            std::fprintf(stderr, "[scg]   windows of %zu MB (device inflate, %zu device(s)): host fill %.2f ms, waiting for the device %.2f ms, for free slots %.2f ms\n",
+                         cap_text >> 20, devices.size(), t_fill, t_finish, t_busy);
         }
         tr.mark("  windows");
     }
 
 private:
     scg::TextSource& src;
-    int device;
+    std::vector<int> devices;
     size_t cap_text = 0, window = 0, cap_in = 0;
     std::vector<std::unique_ptr<ScanSlot> > slots;
     std::vector<scg::CompressedMember> members;
@@ -1281,7 +1396,7 @@ private:
 
     void fill_next() {
         ScanSlot& s = *slots[filled % slots.size()];
-        DeviceGuard g(device);
+        DeviceGuard g(s.plan_device);
         if (s.pending) finish_next();
         const auto b0 = std::chrono::steady_clock::now();
         if (s.busy) { HIP_CHECK(hipStreamSynchronize(s.stream)); s.busy = false; }
@@ -1299,7 +1414,7 @@ private:
     void finish_next() {
         ScanSlot& s = *slots[finished % slots.size()];
         const auto f1 = std::chrono::steady_clock::now();
-        DeviceGuard g(device);
+        DeviceGuard g(s.plan_device);
         HIP_CHECK(hipStreamSynchronize(s.stream));
         t_finish += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - f1).count();
         s.pending = false;
@@ -1505,10 +1620,183 @@ private:
     }
 };
 
+// -------------------------------------------------------------------------------------------------
+// Paired plain files over SEVERAL devices.  Pair i needs read i of both files, so the work is handed out by record
+// index: the host threads scan each mate's file in windows as they do for one device (PlainSource::next_parsed: sequences
+// and offsets in pinned memory) and keep a cursor into each mate's current window; a round takes the
+// min(remaining, remaining) pairs the two cursors have in common, and ONE device -- round-robin -- gathers exactly those
+// records of both mates over its own PCIe link and counts them.  Every record crosses a link once, the devices work on
+// different rounds at the same time, the per-device counters are summed at the end (PlanSet::read).  Replaces
+// kaori::process_paired_end_data (process_data.hpp:224-340) for calls with more than one device; compressed mates keep
+// the one-device pipeline above (their text exists only in one device's memory).
+// -------------------------------------------------------------------------------------------------
+class PairedRounds {
+public:
+    PairedRounds(const std::vector<int>& devs, scg::TextSource& src1, scg::TextSource& src2)
+        : devices(devs), window(std::max(scan_window_bytes(src1.size_hint()), scan_window_bytes(src2.size_hint()))) {
+        mate[0].src = &src1; mate[1].src = &src2;
+        cap_lines = window / 16 + 1024;
+        cap_records = cap_lines / 4 + 1;
+        cap_seq = window / 2 + 64;
+        for (auto& m : mate) {
+            for (auto& hw : m.win) {
+                hw.text.ensure(window);
+                hw.offs.ensure((cap_records + 1) * sizeof(uint32_t));
+            }
+        }
+        for (size_t i = 0; i < devices.size() * 2; ++i) {
+            rounds.emplace_back(new Round);
+            Round& R = *rounds.back();
+            R.device = devices[i / 2];
+            DeviceGuard g(R.device);
+            HIP_CHECK(hipStreamCreateWithFlags(&R.stream, hipStreamNonBlocking));
+            HIP_CHECK(hipEventCreateWithFlags(&R.done, hipEventDisableTiming));
+            for (int k = 0; k < 2; ++k) {
+                R.seqs[k].alloc(cap_seq + 64);
+                R.offs[k].alloc((cap_records + 1) * sizeof(uint32_t));
+            }
+        }
+        tr.mark("  round buffers (pinned + HBM)");
+    }
+    ~PairedRounds() {
+        for (auto& rp : rounds) {
+            Round& R = *rp;
+            int prev = -1;
+            if (hipGetDevice(&prev) == hipSuccess && prev != R.device) (void)hipSetDevice(R.device); else prev = -1;
+            if (R.stream) { (void)hipStreamSynchronize(R.stream); (void)hipStreamDestroy(R.stream); }
+            if (R.done) (void)hipEventDestroy(R.done);
+            R.seqs[0].release(); R.seqs[1].release(); R.offs[0].release(); R.offs[1].release();
+            if (prev >= 0) (void)hipSetDevice(prev);
+        }
+    }
+
+    // plans[d] belongs to devices[d]
+    void run(const std::vector<scg_plan*>& plans) {
+        const size_t D = devices.size();
+        for (size_t r = 0;; ++r) {
+            for (auto& m : mate) advance(m);
+            const uint64_t rem0 = remaining(mate[0]), rem1 = remaining(mate[1]);
+            if (rem0 == 0 && rem1 == 0) break;                                  // both files used up
+            if (rem0 == 0 || rem1 == 0) throw Error(SCG_ERR_IO, "different number of reads in paired FASTQ files");   // process_data.hpp:284-285
+            const uint64_t np = std::min(rem0, rem1);
+            Round& R = *rounds[(r % D) * 2 + (r / D) % 2];
+            DeviceGuard g(R.device);
+            if (R.busy) { HIP_CHECK(hipStreamSynchronize(R.stream)); R.busy = false; }
+            ScgReads reads[2];
+            uint32_t max_len = 0;
+            for (int i = 0; i < 2; ++i) {
+                HostWindow& hw = mate[i].win[mate[i].cur];
+                enqueue_range(R, i, hw, mate[i].k, np);
+                max_len = std::max(max_len, hw.w.max_len);
+            }
+            for (int i = 0; i < 2; ++i) {
+                reads[i] = make_reads(R.seqs[i].as<char>(), R.offs[i].as<uint32_t>(), 0, static_cast<int32_t>(std::min<uint32_t>(max_len, 1u << 30)));
+            }
+            launch_batch_paired(plans[r % D], reads[0], reads[1], static_cast<int64_t>(np), R.stream);
+            HIP_CHECK(hipEventRecord(R.done, R.stream));
+            R.busy = true;
+            for (auto& m : mate) {
+                m.win[m.cur].readers.push_back(std::make_pair(R.device, R.done));
+                m.k += np;
+            }
+            ++n_rounds;
+        }
+        for (auto& rp : rounds) {
+            DeviceGuard g(rp->device);
+            HIP_CHECK(hipStreamSynchronize(rp->stream));
+            rp->busy = false;
+        }
+        if (tr.on) std::fprintf(stderr, "[scg]   paired rounds over %zu device(s): %zu rounds of <= %zu MB windows, host scan %.2f ms\n", D, n_rounds, window >> 20, t_fill);
+        tr.mark("  rounds");
+    }
+
+private:
+    struct HostWindow {
+        PinnedBuf text, offs;
+        scg::ParsedWindow w;
+        std::vector<std::pair<int, hipEvent_t> > readers;      // rounds whose gathers read this window
+    };
+    struct Mate {
+        scg::TextSource* src = nullptr;
+        HostWindow win[3];
+        int cur = -1;
+        uint64_t k = 0;              // records of the current window that have been paired
+        bool done = false;
+    };
+    struct Round {
+        int device = 0;
+        hipStream_t stream = nullptr;
+        hipEvent_t done = nullptr;
+        DevBuf seqs[2], offs[2];
+        bool busy = false;
+    };
+    std::vector<int> devices;
+    size_t window, cap_lines = 0, cap_records = 0, cap_seq = 0, n_rounds = 0;
+    Mate mate[2];
+    std::vector<std::unique_ptr<Round> > rounds;
+    Trace tr;
+    double t_fill = 0;
+
+    static uint64_t remaining(const Mate& m) { return m.cur < 0 ? 0 : m.win[m.cur].w.n_records - m.k; }
+
+    // A mate whose window is used up takes its next one (into the buffer whose readers have long finished).
+    void advance(Mate& m) {
+        if (m.done || remaining(m) > 0) return;
+        const int next = (m.cur + 1) % 3;
+        HostWindow& hw = m.win[next];
+        for (auto& rd : hw.readers) {
+            DeviceGuard g(rd.first);
+            HIP_CHECK(hipEventSynchronize(rd.second));
+        }
+        hw.readers.clear();
+        const auto f0 = std::chrono::steady_clock::now();
+        const size_t bytes = m.src->next_parsed(hw.text.as<char>(), window, hw.offs.as<uint32_t>(), cap_records + 1, hw.w);
+        t_fill += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - f0).count();
+        if (m.src->unusual()) throw UnusualInput();
+        if (bytes == 0) { m.done = true; m.cur = -1; return; }
+        if (hw.w.seq_bytes > cap_seq || hw.w.n_records > cap_records) throw UnusualInput();
+        m.cur = next;
+        m.k = 0;
+    }
+
+    // Records [k, k + n) of a parsed window -> the round's device buffers of mate i.
+    void enqueue_range(Round& R, int i, const HostWindow& hw, uint64_t k, uint64_t n) {
+        scg::GatherSegments G;
+        G.n = 0;
+        uint32_t rec = 0, at = 0;
+        uint64_t base = 0;
+        const uint32_t* offs = hw.offs.as<uint32_t>();
+        for (int sgm = 0; sgm < hw.w.n_segs && base < k + n; ++sgm) {
+            const scg::ParsedSegment& g = hw.w.seg[sgm];
+            const uint64_t lo = std::max<uint64_t>(k, base), hi = std::min<uint64_t>(k + n, base + g.n_records);
+            if (hi > lo) {
+                const uint32_t j0 = static_cast<uint32_t>(lo - base), j1 = static_cast<uint32_t>(hi - base);
+                const uint32_t* so = offs + g.off_at;
+                G.seq_src[G.n] = hw.text.as<char>() + g.seq_at + so[j0];
+                G.off_src[G.n] = so + j0;
+                G.off_base[G.n] = so[j0];
+                G.seq_at[G.n] = at;
+                G.first[G.n] = rec;
+                at += so[j1] - so[j0];
+                rec += j1 - j0;
+                ++G.n;
+            }
+            base += g.n_records;
+        }
+        G.seq_at[G.n] = at;
+        G.first[G.n] = rec;
+        HIP_CHECK(scg::launch_gather_segments(R.seqs[i].as<char>(), R.offs[i].as<uint32_t>(), G, R.stream));
+    }
+};
+
 void reset_plan(scg_plan* P) {
     DeviceGuard g(P->device);
     if (P->n_counters) HIP_CHECK(hipMemset(P->counters, 0, static_cast<size_t>(P->n_counters) * sizeof(int32_t)));
     if (P->replica_shift > 0) HIP_CHECK(hipMemset(P->replicas.p, 0, P->replicas.bytes));
+    for (auto& kv : P->pair_stream) {                       // (sparse mode: batches in flight are let finish and dropped)
+        if (kv.second.pending) { HIP_CHECK(hipEventSynchronize(kv.second.done)); kv.second.pending = 0; }
+    }
+    P->sparse_counts.clear();
     P->total = 0;
 }
 
@@ -1532,8 +1820,10 @@ void count_single_end(const std::vector<scg_plan*>& plans, const char* path, scg
             try {
                 std::unique_ptr<scg::TextSource> src = scg::TextSource::open(path, scg::default_host_threads(nthreads));
                 if (src->has_members()) {
-                    InflatePipeline pipe(*src, plans[0]->device);
-                    pipe.run(plans[0]);
+                    std::vector<int> devs;
+                    for (scg_plan* P : plans) devs.push_back(P->device);
+                    InflatePipeline pipe(*src, devs);
+                    pipe.run(plans);
                     done = true;
                 }
             } catch (const UnusualInput&) {
@@ -1660,6 +1950,7 @@ std::unique_ptr<scg_plan> clone_compiled(const scg_plan& a) {
     b->diagnostics = a.diagnostics;
     b->first1 = a.first1; b->first2 = a.first2;
     b->n_counters = a.n_counters;
+    b->sparse = a.sparse;
     return b;
 }
 
@@ -1707,6 +1998,16 @@ struct PlanSet {
         }
     }
     void reset() const { for (auto& p : plans) reset_plan(p.get()); }
+    // Sparse mode: the combinations of all devices (every batch's runs merged).
+    std::unordered_map<uint64_t, int64_t> sparse_merged() const {
+        std::unordered_map<uint64_t, int64_t> all;
+        for (auto& p : plans) {
+            retire_all_pairs(p.get());
+            if (all.empty()) all = p->sparse_counts;
+            else for (auto& kv : p->sparse_counts) all[kv.first] += kv.second;
+        }
+        return all;
+    }
 };
 
 // Files over devices inside one call (the matrixOf* functions: R/countSingleBarcodes.R:112-126, R/countComboBarcodes.R:149-164,
@@ -1766,8 +2067,8 @@ std::unique_ptr<PlanSet> compile_and_count_single_end(const char* path, scg::Fas
         if (device_scan_enabled()) {
             src = scg::TextSource::open(path, scg::default_host_threads(nthreads, static_cast<int>(devices.size())));
             if (src->has_members() && device_inflate_enabled()) {
-                devices.resize(1);                     // the windows of a BGZF file are chained by their partial records
-                inflate.reset(new InflatePipeline(*src, devices[0]));
+                inflate.reset(new InflatePipeline(*src, devices));
+                devices.resize(inflate->n_devices());  // (one device when the others cannot be reached over xGMI)
                 inflate->start();
             } else {
                 pipe.reset(new TextPipeline(*src, devices));
@@ -1795,7 +2096,7 @@ std::unique_ptr<PlanSet> compile_and_count_single_end(const char* path, scg::Fas
         if (inflate_declined_early && device_inflate_strict()) inflate_declined();
         if (inflate) {
             try {
-                inflate->run(set->first());
+                inflate->run(set->all());
                 done = true;
             } catch (const UnusualInput&) {
                 if (device_inflate_strict()) inflate_declined();
@@ -1867,10 +2168,29 @@ void combo_compact(const int32_t* cells, int32_t n0, int32_t n1, int32_t** indic
     *indices_out = idx; *freq_out = freq; *k_out = k;
 }
 
+// Sparse mode: (first << 32 | second) -> count, as the reference's sorted run-length form (src/utils.h:14-45).
+void combos_from_sparse(const std::unordered_map<uint64_t, int64_t>& m, int32_t** indices_out, int32_t** freq_out, int64_t* k_out) {
+    std::vector<std::pair<uint64_t, int64_t> > rows(m.begin(), m.end());
+    std::sort(rows.begin(), rows.end());                    // key order = (first, second) order
+    const size_t k = rows.size();
+    int32_t* idx = static_cast<int32_t*>(std::malloc(sizeof(int32_t) * (2 * k + 1)));
+    int32_t* freq = static_cast<int32_t*>(std::malloc(sizeof(int32_t) * (k + 1)));
+    if (!idx || !freq) { std::free(idx); std::free(freq); throw std::bad_alloc(); }
+    for (size_t j = 0; j < k; ++j) {
+        if (rows[j].second > static_cast<int64_t>(INT32_MAX)) { std::free(idx); std::free(freq); throw Error(SCG_ERR_INVALID, "a count exceeds the 32-bit range of the count vectors"); }
+        idx[2 * j] = static_cast<int32_t>(rows[j].first >> 32);
+        idx[2 * j + 1] = static_cast<int32_t>(rows[j].first & 0xFFFFFFFFu);
+        freq[j] = static_cast<int32_t>(rows[j].second);
+    }
+    *indices_out = idx; *freq_out = freq; *k_out = static_cast<int64_t>(k);
+}
+
 // [n_pool valid][b1][b2][uid1 x uid2] -> the reference's outputs: invalid combinations by first pool
 // index, merged (several uids of one IUPAC barcode share an index), sorted by (first, second).
+// (sparse: the plan is in sparse mode and these are its combinations by sequence uid, in place of the dense cells)
 void diagnostics_from_counters(const scg_plan* P, const std::vector<int32_t>& all, int32_t* counts_out,
-                               int32_t** idx_out, int32_t** freq_out, int64_t* k_out, int32_t* b1, int32_t* b2) {
+                               int32_t** idx_out, int32_t** freq_out, int64_t* k_out, int32_t* b1, int32_t* b2,
+                               const std::unordered_map<uint64_t, int64_t>* sparse = nullptr) {
     const int32_t n_pool = P->n_pool[0];
     if (counts_out) std::copy(all.begin(), all.begin() + n_pool, counts_out);
     *b1 = all[n_pool];
@@ -1878,10 +2198,19 @@ void diagnostics_from_counters(const scg_plan* P, const std::vector<int32_t>& al
     const int32_t* cells = all.data() + n_pool + 2;
     const size_t nu1 = P->first1.size(), nu2 = P->first2.size();
     std::vector<std::pair<std::pair<int32_t, int32_t>, int32_t> > found;
-    for (size_t u1 = 0; u1 < nu1; ++u1) {
-        for (size_t u2 = 0; u2 < nu2; ++u2) {
-            int32_t c = cells[u1 * nu2 + u2];
-            if (c) found.push_back(std::make_pair(std::make_pair(P->first1[u1], P->first2[u2]), c));
+    if (sparse) {
+        for (auto& kv : *sparse) {
+            const size_t u1 = static_cast<size_t>(kv.first >> 32), u2 = static_cast<size_t>(kv.first & 0xFFFFFFFFu);
+            if (u1 >= nu1 || u2 >= nu2) throw Error(SCG_ERR_DEVICE, "internal: combination out of range");
+            if (kv.second > static_cast<int64_t>(INT32_MAX)) throw Error(SCG_ERR_INVALID, "a count exceeds the 32-bit range of the count vectors");
+            found.push_back(std::make_pair(std::make_pair(P->first1[u1], P->first2[u2]), static_cast<int32_t>(kv.second)));
+        }
+    } else {
+        for (size_t u1 = 0; u1 < nu1; ++u1) {
+            for (size_t u2 = 0; u2 < nu2; ++u2) {
+                int32_t c = cells[u1 * nu2 + u2];
+                if (c) found.push_back(std::make_pair(std::make_pair(P->first1[u1], P->first2[u2]), c));
+            }
         }
     }
     std::sort(found.begin(), found.end());
@@ -2025,54 +2354,77 @@ void count_paired_files(scg_plan* P, const char* path1, const char* path2, scg::
 }
 
 // One pair of files, one call: as compile_and_count_single_end, the templates and libraries are compiled on a second
-// thread while the first window of each file is read and sent on its way.
+// thread while the first window of each file is read and sent on its way.  Plain mates and more than one device: the
+// pairs go round-robin over all of them (PairedRounds); otherwise one device.
 template<class Compile>
-std::unique_ptr<scg_plan> compile_and_count_paired(const char* path1, const char* path2, scg::FastqStream& fq1, scg::FastqStream& fq2, int nthreads,
-                                                   Compile compile) {
+std::unique_ptr<PlanSet> compile_and_count_paired(const char* path1, const char* path2, scg::FastqStream& fq1, scg::FastqStream& fq2, int nthreads,
+                                                  Compile compile) {
     Trace tr;
     std::unique_ptr<scg_plan> P;
     std::exception_ptr compile_err, early;
     std::thread th([&] {
         try { P = compile(); } catch (...) { compile_err = std::current_exception(); }
     });
-    int device = -1;
+    std::vector<int> devices;
     std::unique_ptr<scg::TextSource> s1, s2;
     std::unique_ptr<PairedPipeline> pipe;
+    std::unique_ptr<PairedRounds> rounds;
     bool gzip_parallel = false, gzip_declined = false;
     try {
-        device = resolve_device(-1);
+        devices = devices_for_input(text_bytes_hint(path1) + text_bytes_hint(path2));
         if (device_scan_enabled()) {
-            const int threads = scg::default_host_threads(nthreads);
+            const int threads = scg::default_host_threads(nthreads, static_cast<int>(devices.size()));
             s1 = scg::TextSource::open(path1, threads, true, std::max(2, threads / 2));
             s2 = scg::TextSource::open(path2, threads, true, std::max(2, threads / 2));
             gzip_parallel = is_parallel_gzip(s1.get()) || is_parallel_gzip(s2.get());
-            pipe.reset(new PairedPipeline(device, *s1, *s2, true));
-            pipe->start();
+            if (devices.size() > 1 && s1->parses() && s2->parses() && host_scan_enabled()) {
+                rounds.reset(new PairedRounds(devices, *s1, *s2));
+            } else {
+                devices.resize(1);
+                pipe.reset(new PairedPipeline(devices[0], *s1, *s2, true));
+                pipe->start();
+            }
+        } else {
+            devices.resize(1);
         }
     } catch (const UnusualInput&) {
         pipe.reset();
+        rounds.reset();
         gzip_declined = gzip_parallel;
+        if (!devices.empty()) devices.resize(1);
     } catch (...) {
         early = std::current_exception();
         pipe.reset();
+        rounds.reset();
     }
     th.join();
     if (compile_err) std::rethrow_exception(compile_err);
     if (early) std::rethrow_exception(early);
     tr.mark("compile + first windows");
-    P->to_device(device);
-    DeviceGuard g(P->device);
-    tr.mark("upload to device");
+    std::unique_ptr<PlanSet> set(new PlanSet(std::move(P), devices));
+    scg_plan* const first = set->first();
+    DeviceGuard g(first->device);
+    tr.mark("upload to device(s)");
     bool done = false, inflate_declined_it = false;
+    if (rounds) {
+        try {
+            rounds->run(set->all());
+            done = true;
+        } catch (const UnusualInput&) {
+            rounds.reset();                        // (its kernels have finished before the counters are cleared)
+            set->reset();
+        }
+        rounds.reset();
+    }
     if (pipe) {
         try {
-            pipe->run(P.get());
+            pipe->run(first);
             done = true;
         } catch (const UnusualInput&) {
             inflate_declined_it = pipe->inflates();
             if (inflate_declined_it && device_inflate_strict()) inflate_declined();
             pipe.reset();                          // (its kernels have finished before the counters are cleared)
-            reset_plan(P.get());
+            set->reset();
             gzip_declined = gzip_parallel;
         }
         pipe.reset();
@@ -2080,11 +2432,11 @@ std::unique_ptr<scg_plan> compile_and_count_paired(const char* path1, const char
     if (!done) {
         // a BGZF mate the device handed back gets the host threads' zlib next, a gzip mate the parallel decoder handed back
         // one inflate stream; everything else the host readers
-        if (inflate_declined_it || gzip_declined) count_paired_files(P.get(), path1, path2, fq1, fq2, nthreads, !inflate_declined_it, !gzip_declined);
-        else count_paired_host(P.get(), path1, path2, fq1, fq2, nthreads);
+        if (inflate_declined_it || gzip_declined) count_paired_files(first, path1, path2, fq1, fq2, nthreads, !inflate_declined_it, !gzip_declined);
+        else count_paired_host(first, path1, path2, fq1, fq2, nthreads);
     }
     tr.mark("count files");
-    return P;
+    return set;
 }
 
 } // namespace
@@ -2105,7 +2457,10 @@ int scg_device_count(void) {
 
 void scg_free(void* p) { std::free(p); }
 
-void scg_release_buffers(void) { slot_pool().clear(); }
+void scg_release_buffers(void) {
+    slot_pool().clear();
+    scg::ParallelGunzip::release_cached();
+}
 
 int scg_parse_fastq(const char* path, char** seqs_out, uint64_t** offsets_out, int64_t* n_reads_out, char* err, size_t errcap) {
     return guarded(err, errcap, [&] {
@@ -2349,6 +2704,10 @@ int scg_plan_reset(scg_plan* plan, void* stream, char* err, size_t errcap) {
         DeviceGuard g(plan->device);
         HIP_CHECK(hipMemsetAsync(plan->counters, 0, static_cast<size_t>(plan->n_counters) * sizeof(int32_t), static_cast<hipStream_t>(stream)));
         HIP_CHECK(hipMemsetAsync(plan->error_flag.p, 0, sizeof(int32_t), static_cast<hipStream_t>(stream)));
+        for (auto& kv : plan->pair_stream) {
+            if (kv.second.pending) { HIP_CHECK(hipEventSynchronize(kv.second.done)); kv.second.pending = 0; }
+        }
+        plan->sparse_counts.clear();
         plan->total = 0;
     });
 }
@@ -2384,6 +2743,21 @@ int scg_plan_read(scg_plan* plan, int32_t* counts_out, int64_t* total_out, void*
         DeviceGuard g(plan->device);
         HIP_CHECK(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
         read_counters(plan, counts_out);
+        if (total_out) *total_out = plan->total;
+    });
+}
+
+int scg_plan_read_combinations(scg_plan* plan, int32_t** indices_out, int32_t** freq_out, int64_t* k_out, int64_t* total_out,
+                               void* stream, char* err, size_t errcap) {
+    return guarded(err, errcap, [&] {
+        if (!plan || !indices_out || !freq_out || !k_out) throw Error(SCG_ERR_INVALID, "null argument");
+        if (plan->kind != scg_plan::COMBO) throw Error(SCG_ERR_INVALID, "not a combination plan");
+        DeviceGuard g(plan->device);
+        HIP_CHECK(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+        std::vector<int32_t> cells(static_cast<size_t>(plan->n_counters) + 1);
+        read_counters(plan, cells.data());
+        if (plan->sparse) { retire_all_pairs(plan); combos_from_sparse(plan->sparse_counts, indices_out, freq_out, k_out); }
+        else combo_compact(cells.data(), plan->n_pool[0], plan->n_pool[1], indices_out, freq_out, k_out);
         if (total_out) *total_out = plan->total;
     });
 }
@@ -2455,7 +2829,8 @@ int scg_count_combo_barcodes_single(const char* path, const char* constant, int 
         std::vector<int32_t> cells(static_cast<size_t>(set->first()->n_counters) + 1);
         set->read(cells.data());
         const int32_t total = narrow_total(set->total());
-        combo_compact(cells.data(), n_pool0, n_pool1, indices_out, freq_out, k_out);
+        if (set->first()->sparse) combos_from_sparse(set->sparse_merged(), indices_out, freq_out, k_out);
+        else combo_compact(cells.data(), n_pool0, n_pool1, indices_out, freq_out, k_out);
         *total_out = total;
     });
 }
@@ -2471,12 +2846,11 @@ int scg_count_dual_barcodes(const char* path1, const char* constant1, int revers
         if (diagnostics) {
             throw Error(SCG_ERR_INVALID, "diagnostics requested: call scg_count_dual_barcodes_diagnostics, which returns the extra outputs");
         }
-        auto P = compile_and_count_paired(path1, path2, fq1, fq2, nthreads, [&] {
+        auto set = compile_and_count_paired(path1, path2, fq1, fq2, nthreads, [&] {
             return compile_dual(constant1, reverse1, mismatches1, pool1, constant2, reverse2, mismatches2, pool2, n_pool, randomized, use_first);
         });
-        DeviceGuard g(P->device);
-        read_counters(P.get(), counts_out);
-        *total_out = narrow_total(P->total);
+        set->read(counts_out);
+        *total_out = narrow_total(set->total());
     });
 }
 
@@ -2493,14 +2867,15 @@ int scg_count_dual_barcodes_diagnostics(const char* path1, const char* constant1
         }
         scg::FastqStream fq1(path1);
         scg::FastqStream fq2(path2);
-        auto P = compile_and_count_paired(path1, path2, fq1, fq2, nthreads, [&] {
+        auto set = compile_and_count_paired(path1, path2, fq1, fq2, nthreads, [&] {
             return compile_dual(constant1, reverse1, mismatches1, pool1, constant2, reverse2, mismatches2, pool2, n_pool, randomized, use_first, 1);
         });
-        DeviceGuard g(P->device);
-        std::vector<int32_t> all(static_cast<size_t>(P->n_counters) + 1);
-        read_counters(P.get(), all.data());
-        diagnostics_from_counters(P.get(), all, counts_out, invalid_indices_out, invalid_freq_out, k_out, barcode1_only_out, barcode2_only_out);
-        *total_out = narrow_total(P->total);
+        std::vector<int32_t> all(static_cast<size_t>(set->first()->n_counters) + 1);
+        set->read(all.data());
+        const auto sparse = set->first()->sparse ? set->sparse_merged() : std::unordered_map<uint64_t, int64_t>();
+        diagnostics_from_counters(set->first(), all, counts_out, invalid_indices_out, invalid_freq_out, k_out, barcode1_only_out, barcode2_only_out,
+                                  set->first()->sparse ? &sparse : nullptr);
+        *total_out = narrow_total(set->total());
     });
 }
 
@@ -2626,7 +3001,8 @@ int scg_count_dual_barcodes_single_end_diagnostics(const char* path, const char*
         set->read(all.data());
         const int32_t total = narrow_total(set->total());
         int32_t b1 = 0, b2 = 0;
-        diagnostics_from_counters(set->first(), all, counts_out, invalid_indices_out, invalid_freq_out, k_out, &b1, &b2);
+        const auto sparse = set->first()->sparse ? set->sparse_merged() : std::unordered_map<uint64_t, int64_t>();
+        diagnostics_from_counters(set->first(), all, counts_out, invalid_indices_out, invalid_freq_out, k_out, &b1, &b2, set->first()->sparse ? &sparse : nullptr);
         *total_out = total;
     });
 }
@@ -2645,15 +3021,16 @@ int scg_count_combo_barcodes_paired(const char* path1, const char* constant1, in
         }
         scg::FastqStream fq1(path1);                           // src/count_combo_barcodes_paired.cpp:75-79: readers first
         scg::FastqStream fq2(path2);
-        auto P = compile_and_count_paired(path1, path2, fq1, fq2, nthreads, [&] {
+        auto set = compile_and_count_paired(path1, path2, fq1, fq2, nthreads, [&] {
             return compile_paired_combo(constant1, reverse1, mismatches1, pool1, n_pool1, constant2, reverse2, mismatches2, pool2, n_pool2,
                                         randomized, use_first);
         });
-        DeviceGuard g(P->device);
-        std::vector<int32_t> all(static_cast<size_t>(P->n_counters) + 1);
-        read_counters(P.get(), all.data());
-        diagnostics_from_counters(P.get(), all, nullptr, indices_out, freq_out, k_out, barcode1_only_out, barcode2_only_out);
-        *total_out = narrow_total(P->total);
+        std::vector<int32_t> all(static_cast<size_t>(set->first()->n_counters) + 1);
+        set->read(all.data());
+        const auto sparse = set->first()->sparse ? set->sparse_merged() : std::unordered_map<uint64_t, int64_t>();
+        diagnostics_from_counters(set->first(), all, nullptr, indices_out, freq_out, k_out, barcode1_only_out, barcode2_only_out,
+                                  set->first()->sparse ? &sparse : nullptr);
+        *total_out = narrow_total(set->total());
     });
 }
 
@@ -2712,7 +3089,8 @@ int scg_count_combo_barcodes_single_files(const char* const* paths, int32_t n_fi
                 std::vector<int32_t> dense(cells + 1);
                 read_counters(P, dense.data());
                 totals_out[f] = narrow_total(P->total);
-                combo_compact(dense.data(), n_pool0, n_pool1, &indices_out[f], &freq_out[f], &k_out[f]);
+                if (P->sparse) { retire_all_pairs(P); combos_from_sparse(P->sparse_counts, &indices_out[f], &freq_out[f], &k_out[f]); }
+                else combo_compact(dense.data(), n_pool0, n_pool1, &indices_out[f], &freq_out[f], &k_out[f]);
             });
         } catch (...) {
             for (int32_t f = 0; f < n_files; ++f) { std::free(indices_out[f]); std::free(freq_out[f]); indices_out[f] = nullptr; freq_out[f] = nullptr; k_out[f] = 0; }
@@ -2757,7 +3135,9 @@ int scg_plan_read_diagnostics(scg_plan* plan, int32_t* counts_out, int32_t** inv
         HIP_CHECK(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
         std::vector<int32_t> all(static_cast<size_t>(plan->n_counters) + 1);
         read_counters(plan, all.data());
-        diagnostics_from_counters(plan, all, counts_out, invalid_indices_out, invalid_freq_out, k_out, barcode1_only_out, barcode2_only_out);
+        if (plan->sparse) retire_all_pairs(plan);
+        diagnostics_from_counters(plan, all, counts_out, invalid_indices_out, invalid_freq_out, k_out, barcode1_only_out, barcode2_only_out,
+                                  plan->sparse ? &plan->sparse_counts : nullptr);
         if (total_out) *total_out = plan->total;
     });
 }

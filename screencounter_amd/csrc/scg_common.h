@@ -155,6 +155,9 @@ struct ScgCounters {
     // mapped read the kernel stores the barcode index of read r (or -1) in unit_index[r], and
     // tally_kernel turns the index stream into counts through LDS histograms (scg_kernels.hip).
     int32_t* unit_index;        // nullptr: count with atomics
+    // Sparse mode (combination spaces beyond the dense limit: scg_sparse.hip): the combination of read / pair r, or ~0
+    // for none, goes to unit_pair[r] as (first << 32) | second; nothing is added to `base` for it.
+    uint64_t* unit_pair;        // nullptr: dense cells
     // Diagnostics paths: partial sums of the two single-address tallies (barcode1-only, barcode2-only), one slot
     // per wavefront modulo SCG_HOT_SLOTS, folded into their counters after the launch (hot_fold_kernel).  Even one
     // atomic per wavefront on a single address serialises (measured: 5 ms per 20 M pairs).
@@ -216,6 +219,10 @@ struct ScgDualParams {
     int32_t n_uid2;
     int32_t keep_first;                  // mate searches: ties go to the first barcode (DuplicateAction::FIRST) instead of being ambiguous
     const int32_t* only_if_negative;     // diagnostics == 2 as a second pass: search only pairs whose entry is < 0
+    // The staged pair search keeps ONE verified template hit per mate and template (dual_passes_kernel); a pair with more
+    // is left to the byte-wise search of a second, small launch: overflow[0] counts such pairs, overflow[1..] lists them.
+    // Room for every pair of the batch; the launcher clears the count.
+    int32_t* overflow;
 };
 
 static inline

@@ -329,7 +329,10 @@ __device__ __forceinline__ void pair_match(const ScgIndex& X1, const ScgIndex& X
         // The neighbourhoods of the two halves are gathered once each (they hold one or two
         // sequences in practice) and crossed; only a pathological library overflows the small
         // arrays, in which case the halves are searched nested.
-        constexpr int K = 4;
+#ifndef SCG_PAIR_K
+#define SCG_PAIR_K 4
+#endif
+        constexpr int K = SCG_PAIR_K;
         int v1[K], d1[K], n1, v2[K], d2[K], n2;
         const bool ok1 = index_neighbours<K, W>(X1, q1, cap1, v1, d1, n1);
         if (ok1 && n1 == 0) return;

@@ -14,6 +14,8 @@
 // real line is checked like every other, and the counting kernels simply skip record 0.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "scg_inflate.h"
 #include "scg_textscan.h"
 
@@ -62,6 +64,274 @@ __global__ __launch_bounds__(INFLATE_BLOCK) void inflate_members_kernel(const ui
     if (m >= n) return;
     const scg::InflateMember M = members[m];
     const int rc = scginf::inflate_member(in + M.in_off, M.in_len, text + M.out_off, M.out_len, tables, WaveLanes{threadIdx.x});
+    if (rc != scginf::INFLATE_OK && threadIdx.x == 0) atomicOr(status, scg::INFLATE_STATUS_BAD);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The lane-parallel decoder (default).  One wavefront per member as before, but the symbols of a block are no longer
+// decoded one after the other by the wavefront as a whole -- 60 scalar instructions a symbol, and a CU issues one
+// scalar instruction per cycle for all its wavefronts -- but 64 bit offsets at a time:
+//
+//   1. lane i decodes the literal/length code (and, for a length, the distance code) that WOULD start at bit
+//      `bitpos + i` of the stream: two look-ups in the LDS tables and some vector arithmetic, the same for every lane;
+//      most of these offsets are no code starts and their results are thrown away;
+//   2. the true code starts are the chain 0 -> next(0) -> next(next(0)) ...: one v_readlane per symbol walks it, and on
+//      the way every symbol's place in the text is fixed (v_writelane) -- ~8 scalar-side instructions a symbol;
+//   3. all literals of the batch are stored at once, one byte per lane; the matches follow in order, each copied by
+//      the 64 lanes together (their sources may be the literals just stored, never anything stored later).
+//
+// Codes longer than the primary tables, an end-of-block or an invalid pattern stop the chain; that one symbol is
+// decoded the old way (scginf::decode_symbol: canonical bit-by-bit decoding) and the batches go on behind it.
+// Block headers (once per ~30 KB of text) are read by the wavefront as a whole, as before.  Accept / reject rules are
+// scg_inflate.h's; what this decoder gets wrong on a corrupt stream the CRC kernel catches, and zlib judges the file.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int LANES_LIT_BITS = 10, LANES_DIST_BITS = 8;
+struct WaveTables {                   // 3.3 KB of LDS per wavefront
+    uint16_t lit[1 << LANES_LIT_BITS];
+    uint16_t dtab[1 << LANES_DIST_BITS];
+    uint16_t lsym[288];
+    uint16_t dsym[32];
+    uint16_t lcount[16];
+    uint16_t dcount[16];
+    uint16_t offs[16];
+};
+
+__device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lane); }
+
+// n bytes to out[at ...) from dist bytes back, by all lanes (n <= 258 for a match; any n for a stored block: from == nullptr
+// means "from the text itself").
+__device__ __forceinline__ void wave_copy(uint8_t* out, uint32_t at, const uint8_t* src, uint32_t n, uint32_t dist, uint32_t lane) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (uint32_t j = lane; j < n; j += INFLATE_BLOCK) {
+        const uint32_t k = dist >= n ? j : (dist == 1 ? 0u : j % dist);
+        out[at + j] = src[k];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+}
+
+__device__ __forceinline__ int inflate_member_lanes(const uint8_t* __restrict__ in, uint32_t in_len, uint8_t* out, uint32_t out_len,
+                                                    WaveTables& T, const uint32_t lane) {
+    using namespace scginf;
+    uint8_t* const lens = reinterpret_cast<uint8_t*>(T.lit);             // 320 + 19 code lengths fit the 2 KiB of T.lit
+    uint32_t bitpos = 0, op = 0;
+    const uint32_t in_bits = in_len * 8u;
+    uint32_t last;
+    do {
+        if (bitpos > in_bits) return INFLATE_BAD_DATA;
+        // ---- block header: the wavefront as a whole ----
+        BitReader br;
+        br.open(in, in_len);
+        br.seek(bitpos >> 3);
+        br.refill();
+        br.bits(bitpos & 7u);
+        br.refill();
+        last = br.bits(1);
+        const uint32_t type = br.bits(2);
+        if (type == 0) {
+            br.bits(br.cnt & 7u);
+            br.refill();
+            br.refill();
+            const uint32_t n = br.bits(16), nn = br.bits(16);
+            if ((n ^ 0xFFFFu) != nn) return INFLATE_BAD_DATA;
+            if (n > out_len - op) return INFLATE_BAD_SIZE;
+            const uint32_t from = br.pos - (br.cnt >> 3);                // byte position of the next unread byte
+            if (from > in_len || n > in_len - from) return INFLATE_BAD_DATA;
+            wave_copy(out, op, in + from, n, n ? n : 1u, lane);
+            op += n;
+            bitpos = (from + n) * 8u;
+            continue;
+        }
+        if (type == 3) return INFLATE_BAD_DATA;
+        int nlen, ndist;
+        if (type == 1) {
+            nlen = 288; ndist = 32;
+            for (int s = 0; s < 144; ++s) lens[s] = 8;
+            for (int s = 144; s < 256; ++s) lens[s] = 9;
+            for (int s = 256; s < 280; ++s) lens[s] = 7;
+            for (int s = 280; s < 288; ++s) lens[s] = 8;
+            for (int s = 0; s < 32; ++s) lens[288 + s] = 5;
+        } else {
+            nlen = static_cast<int>(br.bits(5)) + 257;
+            ndist = static_cast<int>(br.bits(5)) + 1;
+            const int ncode = static_cast<int>(br.bits(4)) + 4;
+            if (nlen > 286 || ndist > 30) return INFLATE_BAD_DATA;
+            uint8_t* const cl = lens + 320;
+            const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+            for (int i = 0; i < 19; ++i) cl[i] = 0;
+            for (int i = 0; i < ncode; ++i) {
+                br.refill();
+                cl[order[i]] = static_cast<uint8_t>(br.bits(3));
+            }
+            if (!build_code(cl, 19, 0, T.dtab, 7, T.dcount, T.dsym, T.offs)) return INFLATE_BAD_DATA;
+            int have = 0;
+            while (have < nlen + ndist) {
+                if (br.overrun()) return INFLATE_BAD_DATA;
+                br.refill();
+                const int s = decode_symbol(br, T.dtab, 7, T.dcount, T.dsym);
+                if (s < 0) return INFLATE_BAD_DATA;
+                if (s < 16) { lens[have++] = static_cast<uint8_t>(s); continue; }
+                uint8_t fill = 0;
+                int rep;
+                if (s == 16) {
+                    if (have == 0) return INFLATE_BAD_DATA;
+                    fill = lens[have - 1];
+                    rep = 3 + static_cast<int>(br.bits(2));
+                } else if (s == 17) {
+                    rep = 3 + static_cast<int>(br.bits(3));
+                } else {
+                    rep = 11 + static_cast<int>(br.bits(7));
+                }
+                if (have + rep > nlen + ndist) return INFLATE_BAD_DATA;
+                while (rep--) lens[have++] = fill;
+            }
+            if (lens[256] == 0) return INFLATE_BAD_DATA;
+        }
+        if (!build_code(lens + nlen, ndist, 1, T.dtab, LANES_DIST_BITS, T.dcount, T.dsym, T.offs)) return INFLATE_BAD_DATA;
+        if (!build_code(lens, nlen, 1, T.lit, LANES_LIT_BITS, T.lcount, T.lsym, T.offs)) return INFLATE_BAD_DATA;
+        bitpos = (br.pos * 8u) - br.cnt;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // the tables, written through one lane's eyes, are read per lane below
+
+        // ---- the block's symbols, 64 bit offsets at a time ----
+        bool block_done = false;
+        while (!block_done) {
+            if (bitpos > in_bits) return INFLATE_BAD_DATA;
+            const uint32_t b = bitpos + lane;
+            uint64_t w;
+            __builtin_memcpy(&w, in + (b >> 3), 8);                     // (IN_SLACK bytes are readable behind the payload)
+            w >>= (b & 7u);                                             // >= 57 bits
+            // kind: 0 literal, 1 match, 2 end of block, 3 "not decodable here" (long code / invalid: the chain stops)
+            uint32_t kind, adv, outlen = 0, n = 0, dist = 0, sym;
+            {
+                const uint32_t e = T.lit[static_cast<uint32_t>(w) & ((1u << LANES_LIT_BITS) - 1u)];
+                const uint32_t l = e >> 12;
+                sym = e & 0xFFFu;
+                adv = l;
+                if (e == 0) kind = 3;
+                else if (sym < 256) { kind = 0; outlen = 1; }
+                else if (sym == 256) kind = 2;
+                else if (sym > 285) kind = 3;
+                else {
+                    const uint32_t t = sym - 257;
+                    uint32_t eb, base;
+                    if (t < 8) { eb = 0; base = t + 3; }
+                    else if (t == 28) { eb = 0; base = 258; }
+                    else { eb = (t - 4) >> 2; base = ((4u + (t & 3u)) << eb) + 3u; }
+                    uint64_t w2 = w >> l;
+                    n = base + (static_cast<uint32_t>(w2) & ((1u << eb) - 1u));
+                    w2 >>= eb;
+                    const uint32_t de = T.dtab[static_cast<uint32_t>(w2) & ((1u << LANES_DIST_BITS) - 1u)];
+                    const uint32_t dl = de >> 12, ds = de & 0xFFFu;
+                    if (de == 0 || ds >= 30) kind = 3;
+                    else {
+                        const uint32_t deb = ds < 4 ? 0u : (ds >> 1) - 1u;
+                        const uint32_t dbase = ds < 4 ? ds + 1u : ((2u + (ds & 1u)) << deb) + 1u;
+                        w2 >>= dl;
+                        dist = dbase + (static_cast<uint32_t>(w2) & ((1u << deb) - 1u));
+                        adv = l + eb + dl + deb;
+                        outlen = n;
+                        kind = 1;
+                    }
+                }
+            }
+            // next position (<= 63 + 36), kind, output length (<= 258) in one register: one v_readlane per symbol
+            const uint32_t info = (lane + adv) | (kind << 8) | (outlen << 10);
+            uint32_t outpos = 0;
+            uint32_t pos = 0, stop = 0;                                  // stop: 0 none, 2 end of block, 3 undecodable here
+            uint64_t literals = 0, matches = 0;
+            while (pos < INFLATE_BLOCK) {
+                const uint32_t inf = rdlane(info, pos);
+                const uint32_t k = (inf >> 8) & 3u;
+                if (k >= 2) { stop = k; break; }
+                const uint32_t ol = inf >> 10;
+                if (ol > out_len - op) return INFLATE_BAD_SIZE;
+                outpos = lane == pos ? op : outpos;                      // (v_writelane needs its lane number in m0 on gfx9: two plain vector instructions instead)
+                if (k == 1) {
+                    if (rdlane(dist, pos) > op) return INFLATE_BAD_DATA;        // "invalid distance too far back"
+                    matches |= 1ull << pos;
+                } else {
+                    literals |= 1ull << pos;
+                }
+                op += ol;
+                pos = inf & 0xFFu;
+            }
+            // literals: one byte per lane, all at once
+            if ((literals >> lane) & 1ull) out[outpos] = static_cast<uint8_t>(sym);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            // matches in order, each by all lanes
+            // (tried: the loads of up to four matches whose sources lie before the batch issued back to back and stored
+            // together -- one latency for all -- with the kernel held to 64 VGPRs for 8 wavefronts per SIMD: 15 % SLOWER
+            // end to end; the bookkeeping is scalar work, and scalar issue, not latency, is what bounds this kernel:
+            // profiles/r3_bgzf_pmc.txt)
+            while (matches) {
+                const uint32_t m = static_cast<uint32_t>(__builtin_ctzll(matches));
+                matches &= matches - 1;
+                const uint32_t at = rdlane(outpos, m), len = rdlane(n, m), d = rdlane(dist, m);
+                wave_copy(out, at, out + at - d, len, d, lane);
+            }
+            if (stop == 0) {
+                bitpos += pos;
+                continue;
+            }
+            bitpos += pos;                                               // the symbol at `pos` was not consumed
+            if (stop == 2) {
+                bitpos += rdlane(adv, pos);                              // the end-of-block code itself
+                block_done = true;
+                continue;
+            }
+            // one symbol the old way: a code longer than the primary tables, or an error to be named
+            BitReader sr;
+            sr.open(in, in_len);
+            sr.seek(bitpos >> 3);
+            sr.refill();
+            sr.bits(bitpos & 7u);
+            sr.refill();
+            int s = decode_symbol(sr, T.lit, LANES_LIT_BITS, T.lcount, T.lsym);
+            if (s < 0) return INFLATE_BAD_DATA;
+            if (s < 256) {
+                if (op >= out_len) return INFLATE_BAD_SIZE;
+                if (lane == 0) out[op] = static_cast<uint8_t>(s);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                ++op;
+            } else if (s == 256) {
+                block_done = true;
+            } else {
+                if (s > 285) return INFLATE_BAD_DATA;
+                s -= 257;
+                uint32_t len;
+                if (s < 8) len = static_cast<uint32_t>(s) + 3u;
+                else if (s == 28) len = 258;
+                else {
+                    const uint32_t eb = static_cast<uint32_t>(s - 4) >> 2;
+                    len = ((4u + (static_cast<uint32_t>(s) & 3u)) << eb) + 3u + sr.bits(eb);
+                }
+                sr.refill();
+                const int dcode = decode_symbol(sr, T.dtab, LANES_DIST_BITS, T.dcount, T.dsym);
+                if (dcode < 0 || dcode >= 30) return INFLATE_BAD_DATA;
+                uint32_t d;
+                if (dcode < 4) d = static_cast<uint32_t>(dcode) + 1u;
+                else {
+                    const uint32_t eb = (static_cast<uint32_t>(dcode) >> 1) - 1u;
+                    d = ((2u + (static_cast<uint32_t>(dcode) & 1u)) << eb) + 1u + sr.bits(eb);
+                }
+                if (d > op) return INFLATE_BAD_DATA;
+                if (len > out_len - op) return INFLATE_BAD_SIZE;
+                wave_copy(out, op, out + op - d, len, d, lane);
+                op += len;
+            }
+            bitpos = (sr.pos * 8u) - sr.cnt;
+        }
+    } while (!last);
+    if (((bitpos + 7u) >> 3) != in_len || op != out_len) return INFLATE_BAD_SIZE;
+    return INFLATE_OK;
+}
+
+__global__ __launch_bounds__(INFLATE_BLOCK) void inflate_members_lanes_kernel(const uint8_t* __restrict__ in, const scg::InflateMember* __restrict__ members,
+                                                                              uint32_t n, uint8_t* text, uint32_t* __restrict__ status) {
+    __shared__ WaveTables tables;
+    const uint32_t m = blockIdx.x;
+    if (m >= n) return;
+    const scg::InflateMember M = members[m];
+    const int rc = inflate_member_lanes(in + M.in_off, M.in_len, text + M.out_off, M.out_len, tables, threadIdx.x);
     if (rc != scginf::INFLATE_OK && threadIdx.x == 0) atomicOr(status, scg::INFLATE_STATUS_BAD);
 }
 
@@ -184,8 +454,15 @@ const CrcPowers& crc_powers() {
 
 hipError_t launch_inflate_members(const uint8_t* d_in, const InflateMember* d_members, uint32_t n, char* d_text, uint32_t* d_status, hipStream_t stream) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(inflate_members_kernel, dim3(n), dim3(INFLATE_BLOCK), 0, stream, d_in, d_members, n,
-                       reinterpret_cast<uint8_t*>(d_text), d_status);
+    // SCG_INFLATE_LANES=0: the decoder that walks every symbol with the whole wavefront (measurement / test aid)
+    const char* old_decoder = std::getenv("SCG_INFLATE_LANES");
+    if (old_decoder && *old_decoder == '0') {
+        hipLaunchKernelGGL(inflate_members_kernel, dim3(n), dim3(INFLATE_BLOCK), 0, stream, d_in, d_members, n,
+                           reinterpret_cast<uint8_t*>(d_text), d_status);
+    } else {
+        hipLaunchKernelGGL(inflate_members_lanes_kernel, dim3(n), dim3(INFLATE_BLOCK), 0, stream, d_in, d_members, n,
+                           reinterpret_cast<uint8_t*>(d_text), d_status);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(crc_members_kernel, dim3(n < 4096 ? n : 4096), dim3(CRC_BLOCK), 0, stream, reinterpret_cast<const uint8_t*>(d_text), d_members, n,

@@ -13,6 +13,7 @@
 // Per-handler vector<int> counters + serial reduce() become device atomics on one int32 array.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdlib>
 #include <mutex>
 
@@ -197,7 +198,9 @@ __global__ __launch_bounds__(BLOCK) void combo_kernel(ScgComboParams P, ScgReads
     if (P.only_if_negative && P.only_if_negative[i] >= 0) return;      // second pass of the single-end dual diagnostics
     Read rd = get_read(R, i);
     int best_id[SCG_COMBO_REGIONS] = {0, 0};
-    if (combo_read<W>(P, rd, best_id)) count_one(cells, (int64_t)best_id[0] * P.n_pool[1] + best_id[1]);
+    const bool found = combo_read<W>(P, rd, best_id) != 0;
+    if (cells.unit_pair) cells.unit_pair[i] = found ? (((uint64_t)(uint32_t)best_id[0] << 32) | (uint32_t)best_id[1]) : ~0ull;
+    else if (found) count_one(cells, (int64_t)best_id[0] * P.n_pool[1] + best_id[1]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -290,7 +293,11 @@ __device__ __forceinline__ bool mate_search(const ScgTemplate* T, const ScgIndex
 template<class M>
 __device__ __forceinline__ void diagnose_pair(const ScgDualParams& P, const M& m, const ScgCounters& counters) {
     const int64_t b1_only = P.n_pool, b2_only = b1_only + 1, cells = b2_only + 1;
-    auto emit = [&](int u1, int u2) { count_one(counters, cells + (int64_t)u1 * P.n_uid2 + u2); };
+    // (sparse mode: the combination goes to the pair's slot of the stream, which the host has filled with ~0 beforehand)
+    auto emit = [&](int u1, int u2) {
+        if (counters.unit_pair) counters.unit_pair[(int64_t)blockIdx.x * blockDim.x + threadIdx.x] = ((uint64_t)(uint32_t)u1 << 32) | (uint32_t)u2;
+        else count_one(counters, cells + (int64_t)u1 * P.n_uid2 + u2);
+    };
     // Each of the four searches appears exactly once, in straight-line order: when the same search sits in
     // several divergent branches the compiler merges the copies and selects the template per lane, which
     // forces the whole argument struct into scratch.
@@ -596,6 +603,7 @@ __global__ __launch_bounds__(STAGE_BLOCK, SCG_COMBO_WAVES) __attribute__((amdgpu
         }
     }
     if (cells.unit_index) cells.unit_index[r0 + threadIdx.x] = found ? best_id[0] * P.n_pool[1] + best_id[1] : -1;     // tally mode
+    else if (cells.unit_pair) cells.unit_pair[r0 + threadIdx.x] = found ? (((uint64_t)(uint32_t)best_id[0] << 32) | (uint32_t)best_id[1]) : ~0ull;   // sparse mode
     else if (found) count_one(cells, (int64_t)best_id[0] * P.n_pool[1] + best_id[1]);
 }
 
@@ -683,27 +691,198 @@ __device__ __forceinline__ void dual_orientation_staged(const ScgDualParams& P, 
     }
 }
 
-// The two mate searches of diagnose_pair on staged tiles.
-template<int NW, int NT, int NC, class W>
-struct StagedMates {
-    const Tile<NW>& tile1;
-    const Tile<NW>& tile2;
-    StagedRead sa, sb;
-    __device__ __forceinline__ bool search1(const ScgDualParams& P, int which, int& index, int& mism) const {
-        return mate_search_staged<NW, NT, NC, W>(which ? tile2 : tile1, which ? sb : sa, P.scan1, P.index1, P.rev1 != 0,
-                                              P.max_mm1, P.use_first != 0, P.keep_first != 0, index, mism);
-    }
-    __device__ __forceinline__ bool search2(const ScgDualParams& P, int which, int& index, int& mism) const {
-        return mate_search_staged<NW, NT, NC, W>(which ? tile2 : tile1, which ? sb : sa, P.scan2, P.index2, P.rev2 != 0,
-                                              P.max_mm2, P.use_first != 0, P.keep_first != 0, index, mism);
-    }
+// ---------------------------------------------------------------------------------------------
+// Pairs in two passes over ONE tile.  Two tiles (both mates' planes resident) cost 31 KB of LDS per workgroup: 5
+// workgroups = 20 waves per CU, and the search is latency-bound (profiles/r3_occupancy.txt: taking 16 KB more LDS from
+// each workgroup slows every staged kernel by 40 %).  Here mate 1 is staged, searched and reduced to a few registers,
+// then mate 2 takes the same tile: 15.5 KB, 8 workgroups = 32 waves per CU.
+//
+// What a mate leaves behind, per template searched on it: the FIRST window that passes the constant bases (its variable
+// region and its mismatches) and the number of windows that pass.  With at most one per mate the nested loops of
+// DualBarcodesPairedEnd.hpp:264-276 / :310-347 have one iteration; a pair with more goes to the overflow list
+// (ScgDualParams::overflow) and is searched byte-wise by dual_overflow_kernel right after.
+// ---------------------------------------------------------------------------------------------
+template<class W>
+struct MateHits {
+    QueryT<W> q;
+    int m;
+    int count;
 };
 
-// MATES_ONLY: no search for valid pairs, only the mate-by-mate search of diagnose_pair -- countPairedComboBarcodes,
-// and the second pass of include.invalid=TRUE over the pairs the plain kernel rejected
-// (ScgDualParams::only_if_negative).  Two lean kernels instead of one: the nested pair search next to four
-// inlined mate searches needed 256 VGPRs plus a scratch copy of the arguments and ran 8 x slower.
-template<int NW, int NT, int NC, bool MATES_ONLY, class W>
+template<int NW, int NT, int NC, class W>
+__device__ __forceinline__ void collect_hits(const Tile<NW>& tile, const StagedRead& sr, const ScgScan& T, int key_len, bool reverse,
+                                             int max_mm, MateHits<W>& h) {
+    uint32_t cand[NC], unused[NC];
+    scan_read<NW, NC>(tile, sr, T, true, false, cand, unused);
+    const int last = last_position(sr.n, T.len);
+    h.count = 0; h.m = 0;
+    h.q = QueryT<W>{};
+    for (;;) {
+        int p = first_bit<NC>(cand);
+        if (p > last) break;
+        clear_bit<NC>(cand, p);
+        int m = window_mismatches<NW, NT>(tile, sr.bit + p, T, false);
+        if (m > max_mm) continue;
+        if (h.count == 0) {
+            h.q = region_query<NW, W>(tile, sr.bit + p + T.fstart[0], key_len, reverse);
+            h.m = m;
+        }
+        ++h.count;
+    }
+}
+
+// One orientation from what the passes kept: template 1's hit `x`, template 2's hit `y`.
+template<class W>
+__device__ __forceinline__ void dual_orientation_hits(const ScgDualParams& P, const bool BEST, const MateHits<W>& x, const MateHits<W>& y,
+                                                      int& chosen, int& best) {
+    chosen = -1;
+    best = P.max_mm1 + P.max_mm2 + 1;
+    if (x.count == 0 || y.count == 0) return;
+    int idx, tot;
+    pair_match<W>(P.index1, P.index2, P.pairs, x.q, P.max_mm1 - x.m, y.q, P.max_mm2 - y.m, idx, tot);
+    if (idx >= 0) { chosen = idx; best = tot + x.m + y.m; }
+}
+
+// The four mate searches of diagnose_pair, done while each mate was staged.
+struct SearchedMates {
+    int index[4], mism[4];       // [2 * mate + template]
+    bool found[4];
+    __device__ __forceinline__ bool search1(const ScgDualParams&, int which, int& i, int& m) const { i = index[2 * which]; m = mism[2 * which]; return found[2 * which]; }
+    __device__ __forceinline__ bool search2(const ScgDualParams&, int which, int& i, int& m) const { i = index[2 * which + 1]; m = mism[2 * which + 1]; return found[2 * which + 1]; }
+};
+
+// What the passes leave in registers.
+template<class W>
+struct PairState {
+    MateHits<W> h1a, h2a, h1b, h2b;          // template 1 / 2 on mate a / b
+    SearchedMates sm;
+    bool bad;
+};
+
+// One pass: mate `pass` of the workgroup's pairs staged and searched.  Template 1 belongs on mate a, template 2 on mate b;
+// the other two searches are the swapped orientation of randomized designs.
+template<int NW, int NT, int NC, bool MATES_ONLY, bool RANDOMIZED, class W>
+__device__ __forceinline__ void dual_pass(const int pass, const ScgDualParams& P, const ScgReads& R1, const ScgReads& R2, int64_t n_pairs,
+                                          int64_t r0, int nr, bool fits, bool wanted, Tile<NW>& tile, PairState<W>& S) {
+    ScgReads R;                              // (selected field by field: wave-uniform scalars)
+    R.seqs = pass ? R2.seqs : R1.seqs; R.offsets = pass ? R2.offsets : R1.offsets;
+    R.fixed_len = pass ? R2.fixed_len : R1.fixed_len; R.max_len = pass ? R2.max_len : R1.max_len;
+    int64_t span = 0;
+    if (pass) __syncthreads();               // every lane is done with mate 1's planes
+    const bool ok = fits && stage_reads<NW>(R, n_pairs, r0, nr, tile, span);
+    __syncthreads();
+    S.bad = S.bad || !ok;
+    if (!ok || !wanted) return;
+    Read rd = get_read(R, r0 + threadIdx.x);
+    if (rd.n > 32 * NW) { S.bad = true; return; }
+    StagedRead sr;
+    sr.bit = (int)((int64_t)(rd.p - R.seqs) - span); sr.n = rd.n;
+    bool do1 = pass == 0 || RANDOMIZED, do2 = pass == 1 || RANDOMIZED;
+    if (MATES_ONLY) {
+        SearchedMates& sm = S.sm;
+        // (as in diagnose_pair: the swapped orientation is not consulted when the first match found both; mate a's
+        // search of template 2 comes before that is known)
+        if (RANDOMIZED && pass == 1 && P.use_first && sm.found[0]) {
+            int i2, m2;
+            const bool f2 = mate_search_staged<NW, NT, NC, W>(tile, sr, P.scan2, P.index2, P.rev2 != 0, P.max_mm2, P.use_first != 0, P.keep_first != 0, i2, m2);
+            sm.found[3] = f2; sm.index[3] = i2; sm.mism[3] = m2;
+            do2 = false;
+            do1 = !f2;
+        }
+        int i1 = -1, m1 = 0, i2 = -1, m2 = 0;
+        bool f1 = false, f2 = false;
+        if (do1) f1 = mate_search_staged<NW, NT, NC, W>(tile, sr, P.scan1, P.index1, P.rev1 != 0, P.max_mm1, P.use_first != 0, P.keep_first != 0, i1, m1);
+        if (do2) f2 = mate_search_staged<NW, NT, NC, W>(tile, sr, P.scan2, P.index2, P.rev2 != 0, P.max_mm2, P.use_first != 0, P.keep_first != 0, i2, m2);
+        if (pass == 0) { sm.found[0] = f1; sm.index[0] = i1; sm.mism[0] = m1; sm.found[1] = f2; sm.index[1] = i2; sm.mism[1] = m2; }
+        else {
+            sm.found[2] = f1; sm.index[2] = i1; sm.mism[2] = m1;
+            if (do2) { sm.found[3] = f2; sm.index[3] = i2; sm.mism[3] = m2; }
+        }
+    } else {
+        MateHits<W> t1, t2;
+        t1.count = t2.count = 0; t1.m = t2.m = 0;
+        t1.q = t2.q = QueryT<W>{};
+        if (do1) collect_hits<NW, NT, NC, W>(tile, sr, P.scan1, P.index1.len, P.rev1 != 0, P.max_mm1, t1);
+        if (do2) collect_hits<NW, NT, NC, W>(tile, sr, P.scan2, P.index2.len, P.rev2 != 0, P.max_mm2, t2);
+        if (pass == 0) { S.h1a = t1; S.h2a = t2; } else { S.h1b = t1; S.h2b = t2; }
+    }
+}
+
+// RANDOMIZED (both orientations: four searches): the two passes are ONE loop body, not unrolled, so that each template's
+// search exists once in the code.  Two copies of a search (one per mate) get merged by the compiler into one that selects
+// the template per lane, which moves the whole argument struct (2 KB) to scratch -- see diagnose_pair.  Otherwise each
+// template is searched on its own mate only and the passes are straight-line code (20 registers fewer).
+template<int NW, int NT, int NC, bool MATES_ONLY, bool RANDOMIZED, class W>
+__global__ __launch_bounds__(STAGE_BLOCK) void dual_passes_kernel(ScgDualParams P, ScgReads R1, ScgReads R2, int64_t n_pairs,
+                                                                 ScgCounters counts, int32_t* __restrict__ error_flag) {
+    __shared__ Tile<NW> tile;
+    const int64_t r0 = (int64_t)blockIdx.x * STAGE_BLOCK;
+    const int nr = (int)((n_pairs - r0) < STAGE_BLOCK ? (n_pairs - r0) : STAGE_BLOCK);
+    const bool fits = P.scan1.len <= 32 * NT && P.scan2.len <= 32 * NT;
+    const bool lane = (int)threadIdx.x < nr;
+    // (second pass of include.invalid=TRUE: a valid pair was counted by the first)
+    const bool wanted = lane && !(MATES_ONLY && P.only_if_negative && P.only_if_negative[r0 + threadIdx.x] >= 0);
+    PairState<W> S;
+    S.bad = !fits;
+    S.h1a.count = S.h2a.count = S.h1b.count = S.h2b.count = 0;
+    S.h1a.m = S.h2a.m = S.h1b.m = S.h2b.m = 0;
+    S.h1a.q = S.h2a.q = S.h1b.q = S.h2b.q = QueryT<W>{};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { S.sm.index[k] = -1; S.sm.mism[k] = 0; S.sm.found[k] = false; }
+
+    if (RANDOMIZED) {
+#pragma unroll 1
+        for (int pass = 0; pass < 2; ++pass) dual_pass<NW, NT, NC, MATES_ONLY, RANDOMIZED, W>(pass, P, R1, R2, n_pairs, r0, nr, fits, wanted, tile, S);
+    } else {
+        dual_pass<NW, NT, NC, MATES_ONLY, RANDOMIZED, W>(0, P, R1, R2, n_pairs, r0, nr, fits, wanted, tile, S);
+        dual_pass<NW, NT, NC, MATES_ONLY, RANDOMIZED, W>(1, P, R1, R2, n_pairs, r0, nr, fits, wanted, tile, S);
+    }
+    if (!lane) return;
+    if (S.bad) { *error_flag = 1; return; }
+    if (!wanted) return;
+    if (MATES_ONLY) {
+        diagnose_pair(P, S.sm, counts);
+        return;
+    }
+    int idx = -1;
+    if (S.h1a.count > 1 || S.h2b.count > 1 || S.h1b.count > 1 || S.h2a.count > 1) {
+        const int slot = atomicAdd(P.overflow, 1);
+        P.overflow[1 + slot] = (int32_t)(r0 + threadIdx.x);          // (batches are below 2^31 pairs)
+        if (counts.unit_index) counts.unit_index[r0 + threadIdx.x] = -1;
+        return;
+    }
+    // One body for both orientations and both policies: DualBarcodesPairedEnd.hpp:353-381.
+    const bool best_mode = !P.use_first;
+    int best;
+    dual_orientation_hits<W>(P, best_mode, S.h1a, S.h2b, idx, best);
+    if (RANDOMIZED && (best_mode || idx < 0)) {                      // :356-360, :363-371
+        int ci, cb;
+        dual_orientation_hits<W>(P, best_mode, S.h1b, S.h2a, ci, cb);
+        if (!best_mode) idx = ci;
+        else if (idx < 0 || best > cb) { idx = ci; best = cb; }
+        else if (best == cb && idx != ci) { idx = -1; }
+    }
+    if (counts.unit_index) counts.unit_index[r0 + threadIdx.x] = idx;       // index stream (ScgCounters::unit_index)
+    else if (idx >= 0) count_one(counts, idx);
+}
+
+// The pairs dual_passes_kernel listed, searched byte-wise like the general kernel does.  A fixed, small grid: the list is
+// short (or empty) for any template with enough constant bases to be found by.
+template<class W>
+__global__ __launch_bounds__(BLOCK) void dual_overflow_kernel(ScgDualParams P, ScgReads R1, ScgReads R2, ScgCounters counts) {
+    const int n = P.overflow[0];
+    for (int k = blockIdx.x * BLOCK + threadIdx.x; k < n; k += gridDim.x * BLOCK) {
+        const int64_t i = P.overflow[1 + k];
+        Read a = get_read(R1, i), b = get_read(R2, i);
+        const int idx = dual_pair<W>(P, a, b);
+        if (counts.unit_index) counts.unit_index[i] = idx;
+        else if (idx >= 0) count_one(counts, idx);
+    }
+}
+
+// Both mates' tiles resident: for templates that pass their constant bases at many windows of a read (short flanks), where
+// dual_passes_kernel would hand most pairs to the byte-wise search.
+template<int NW, int NT, int NC, class W>
 __global__ __launch_bounds__(STAGE_BLOCK) void dual_staged_kernel(ScgDualParams P, ScgReads R1, ScgReads R2, int64_t n_pairs,
                                                                  ScgCounters counts, int32_t* __restrict__ error_flag) {
     __shared__ Tile<NW> tile1;
@@ -717,43 +896,35 @@ __global__ __launch_bounds__(STAGE_BLOCK) void dual_staged_kernel(ScgDualParams 
     __syncthreads();
     if ((int)threadIdx.x >= nr) return;
     Read a = get_read(R1, r0 + threadIdx.x), b = get_read(R2, r0 + threadIdx.x);
-    int idx;
     if (!ok2 || a.n > 32 * NW || b.n > 32 * NW) {
         *error_flag = 1;
         return;
     }
-    {
-        StagedRead sa, sb;
-        sa.bit = (int)((int64_t)(a.p - R1.seqs) - span1); sa.n = a.n;
-        sb.bit = (int)((int64_t)(b.p - R2.seqs) - span2); sb.n = b.n;
-        // One body for both orientations (template 1 on mate 1 / on mate 2 when randomized) and
-        // both policies: DualBarcodesPairedEnd.hpp:353-381.
-        const bool best_mode = !P.use_first;
-        if (MATES_ONLY && P.only_if_negative && P.only_if_negative[r0 + threadIdx.x] >= 0) return;   // a valid pair was counted by the first pass
-        const int norient = MATES_ONLY ? 0 : (P.randomized ? 2 : 1);
-        int best = 0;
-        idx = -1;
-        for (int o = 0; o < norient; ++o) {
-            const Tile<NW>* ta = o ? &tile2 : &tile1;
-            const Tile<NW>* tb = o ? &tile1 : &tile2;
-            const StagedRead ra = o ? sb : sa, rb = o ? sa : sb;
-            int ci, cb;
-            dual_orientation_staged<NW, NT, NC, W>(P, best_mode, *ta, ra, *tb, rb, ci, cb);
-            if (!best_mode) {
-                idx = ci;
-                if (ci >= 0) break;                      // :356-360
-            } else if (o == 0) {
-                idx = ci; best = cb;
-            } else {                                     // :363-371
-                if (idx < 0 || best > cb) { idx = ci; best = cb; }
-                else if (best == cb && idx != ci) { idx = -1; }
-            }
-        }
-        if (MATES_ONLY) {
-            diagnose_pair(P, StagedMates<NW, NT, NC, W>{tile1, tile2, sa, sb}, counts);
+    StagedRead sa, sb;
+    sa.bit = (int)((int64_t)(a.p - R1.seqs) - span1); sa.n = a.n;
+    sb.bit = (int)((int64_t)(b.p - R2.seqs) - span2); sb.n = b.n;
+    // One body for both orientations (template 1 on mate 1 / on mate 2 when randomized) and
+    // both policies: DualBarcodesPairedEnd.hpp:353-381.
+    const bool best_mode = !P.use_first;
+    const int norient = P.randomized ? 2 : 1;
+    int best = 0, idx = -1;
+    for (int o = 0; o < norient; ++o) {
+        const Tile<NW>* ta = o ? &tile2 : &tile1;
+        const Tile<NW>* tb = o ? &tile1 : &tile2;
+        const StagedRead ra = o ? sb : sa, rb = o ? sa : sb;
+        int ci, cb;
+        dual_orientation_staged<NW, NT, NC, W>(P, best_mode, *ta, ra, *tb, rb, ci, cb);
+        if (!best_mode) {
+            idx = ci;
+            if (ci >= 0) break;                      // :356-360
+        } else if (o == 0) {
+            idx = ci; best = cb;
+        } else {                                     // :363-371
+            if (idx < 0 || best > cb) { idx = ci; best = cb; }
+            else if (best == cb && idx != ci) { idx = -1; }
         }
     }
-    if (!MATES_ONLY && counts.unit_index) counts.unit_index[r0 + threadIdx.x] = idx;       // index stream (ScgCounters::unit_index)
+    if (counts.unit_index) counts.unit_index[r0 + threadIdx.x] = idx;       // index stream (ScgCounters::unit_index)
     else if (idx >= 0) count_one(counts, idx);
 }
 
@@ -845,6 +1016,12 @@ __global__ __launch_bounds__(BLOCK) void synth_kernel(scg_synth_spec S, char* __
     }
 }
 
+// Measurement aid ($SCG_EXTRA_LDS_KB, tools/abx.sh): unused dynamic LDS per workgroup, to see what a kernel loses when fewer
+// workgroups fit a CU.  No effect on results.
+inline size_t extra_lds() {
+    static const size_t kb = [] { const char* e = std::getenv("SCG_EXTRA_LDS_KB"); return e ? (size_t)std::atoi(e) : (size_t)0; }();
+    return kb << 10;
+}
 inline unsigned grid_for(int64_t n) { return (unsigned)((n + BLOCK - 1) / BLOCK); }
 inline unsigned staged_grid(int64_t n) { return (unsigned)((n + STAGE_BLOCK - 1) / STAGE_BLOCK); }
 
@@ -875,12 +1052,12 @@ template<int NW, int NT> struct LaunchSingle {
         // compact variant: all candidate positions (0 .. max_len - T) fit 3 words of a 5-word read
         const bool compact = NW == 5 && P.scan.compact_ok && R.max_len - P.scan.len + 1 <= 96;
         if (P.index.wide || P.scan.nreg != 1) {          // wide / concatenated keys
-            if (compact) hipLaunchKernelGGL((single_staged_kernel<NW, NT, (NW == 5 ? 3 : NW), uint64_t>), dim3(staged_grid(n)), dim3(STAGE_BLOCK), 0, stream, P, R, n, counts, flag);
-            else hipLaunchKernelGGL((single_staged_kernel<NW, NT, NW, uint64_t>), dim3(staged_grid(n)), dim3(STAGE_BLOCK), 0, stream, P, R, n, counts, flag);
+            if (compact) hipLaunchKernelGGL((single_staged_kernel<NW, NT, (NW == 5 ? 3 : NW), uint64_t>), dim3(staged_grid(n)), dim3(STAGE_BLOCK), extra_lds(), stream, P, R, n, counts, flag);
+            else hipLaunchKernelGGL((single_staged_kernel<NW, NT, NW, uint64_t>), dim3(staged_grid(n)), dim3(STAGE_BLOCK), extra_lds(), stream, P, R, n, counts, flag);
         } else if (compact) {
-            hipLaunchKernelGGL((single_staged_kernel<NW, NT, (NW == 5 ? 3 : NW), uint32_t>), dim3(staged_grid(n)), dim3(STAGE_BLOCK), 0, stream, P, R, n, counts, flag);
+            hipLaunchKernelGGL((single_staged_kernel<NW, NT, (NW == 5 ? 3 : NW), uint32_t>), dim3(staged_grid(n)), dim3(STAGE_BLOCK), extra_lds(), stream, P, R, n, counts, flag);
         } else {
-            hipLaunchKernelGGL((single_staged_kernel<NW, NT, NW, uint32_t>), dim3(staged_grid(n)), dim3(STAGE_BLOCK), 0, stream, P, R, n, counts, flag);
+            hipLaunchKernelGGL((single_staged_kernel<NW, NT, NW, uint32_t>), dim3(staged_grid(n)), dim3(STAGE_BLOCK), extra_lds(), stream, P, R, n, counts, flag);
         }
         return hipGetLastError();
     }
@@ -888,8 +1065,8 @@ template<int NW, int NT> struct LaunchSingle {
 template<int NW, int NT> struct LaunchCombo {
     template<int NC, class W>
     static void run(const ScgComboParams& P, const ScgReads& R, int64_t n, const ScgCounters& cells, int32_t* flag, hipStream_t stream) {
-        if (P.only_if_negative) hipLaunchKernelGGL((combo_staged_kernel<NW, NT, NC, true, W>), dim3(staged_grid(n)), dim3(STAGE_BLOCK), 0, stream, P, R, n, cells, flag);
-        else hipLaunchKernelGGL((combo_staged_kernel<NW, NT, NC, false, W>), dim3(staged_grid(n)), dim3(STAGE_BLOCK), 0, stream, P, R, n, cells, flag);
+        if (P.only_if_negative) hipLaunchKernelGGL((combo_staged_kernel<NW, NT, NC, true, W>), dim3(staged_grid(n)), dim3(STAGE_BLOCK), extra_lds(), stream, P, R, n, cells, flag);
+        else hipLaunchKernelGGL((combo_staged_kernel<NW, NT, NC, false, W>), dim3(staged_grid(n)), dim3(STAGE_BLOCK), extra_lds(), stream, P, R, n, cells, flag);
     }
     static hipError_t go(const ScgComboParams& P, const ScgReads& R, int64_t n, const ScgCounters& cells, int32_t* flag, hipStream_t stream) {
         const bool compact = NW == 5 && P.scan.compact_ok && R.max_len - P.scan.len + 1 <= 96;
@@ -900,11 +1077,39 @@ template<int NW, int NT> struct LaunchCombo {
         return hipGetLastError();
     }
 };
+// Expected number of windows of a random read that pass a template's constant bases: with few, the pair search keeps
+// one hit per mate (dual_passes_kernel); a template that is found all over the place keeps both mates' tiles resident.
+static double expected_chance_hits(const ScgScan& T, int max_mm, int read_len) {
+    int c = 0;
+    for (int w = 0; w < SCG_MAX_TEMPLATE / 32; ++w) c += __builtin_popcount(T.fmask[w]);
+    double ways = 0, choose = 1, pow3 = 1;
+    for (int k = 0; k <= max_mm && k <= c; ++k) {
+        ways += choose * pow3;
+        choose = choose * (c - k) / (k + 1);
+        pow3 *= 3;
+    }
+    return (double)(read_len > T.len ? read_len - T.len + 1 : 1) * ways / std::pow(4.0, c);
+}
+
+static int two_tiles() {           // $SCG_DUAL_TWO_TILES=1 / 0 forces one or the other
+    static const int v = [] { const char* e = getenv("SCG_DUAL_TWO_TILES"); return e && *e ? atoi(e) : -1; }();
+    return v;
+}
+
 template<int NW, int NT> struct LaunchDual {
     template<int NC, class W>
-    static void run(const ScgDualParams& P, const ScgReads& R1, const ScgReads& R2, int64_t n, const ScgCounters& counts, int32_t* flag, hipStream_t stream) {
-        if (P.diagnostics) hipLaunchKernelGGL((dual_staged_kernel<NW, NT, NC, true, W>), dim3(staged_grid(n)), dim3(STAGE_BLOCK), 0, stream, P, R1, R2, n, counts, flag);   // 2 (mates only)
-        else hipLaunchKernelGGL((dual_staged_kernel<NW, NT, NC, false, W>), dim3(staged_grid(n)), dim3(STAGE_BLOCK), 0, stream, P, R1, R2, n, counts, flag);
+    static void run(const ScgDualParams& P, const ScgReads& R1, const ScgReads& R2, int64_t n, const ScgCounters& counts, int32_t* flag, hipStream_t stream, bool passes) {
+        if (P.diagnostics) {                             // 2 (mates only): independent searches of the two mates
+            if (P.randomized) hipLaunchKernelGGL((dual_passes_kernel<NW, NT, NC, true, true, W>), dim3(staged_grid(n)), dim3(STAGE_BLOCK), extra_lds(), stream, P, R1, R2, n, counts, flag);
+            else hipLaunchKernelGGL((dual_passes_kernel<NW, NT, NC, true, false, W>), dim3(staged_grid(n)), dim3(STAGE_BLOCK), extra_lds(), stream, P, R1, R2, n, counts, flag);
+        } else if (passes) {
+            (void)hipMemsetAsync(P.overflow, 0, sizeof(int32_t), stream);
+            if (P.randomized) hipLaunchKernelGGL((dual_passes_kernel<NW, NT, NC, false, true, W>), dim3(staged_grid(n)), dim3(STAGE_BLOCK), extra_lds(), stream, P, R1, R2, n, counts, flag);
+            else hipLaunchKernelGGL((dual_passes_kernel<NW, NT, NC, false, false, W>), dim3(staged_grid(n)), dim3(STAGE_BLOCK), extra_lds(), stream, P, R1, R2, n, counts, flag);
+            hipLaunchKernelGGL((dual_overflow_kernel<W>), dim3(256), dim3(BLOCK), 0, stream, P, R1, R2, counts);
+        } else {
+            hipLaunchKernelGGL((dual_staged_kernel<NW, NT, NC, W>), dim3(staged_grid(n)), dim3(STAGE_BLOCK), extra_lds(), stream, P, R1, R2, n, counts, flag);
+        }
     }
     static hipError_t go(const ScgDualParams& P, const ScgReads& R1, const ScgReads& R2, int64_t n, const ScgCounters& counts, int32_t* flag, hipStream_t stream) {
         const int max_len = R1.max_len > R2.max_len ? R1.max_len : R2.max_len;
@@ -913,8 +1118,11 @@ template<int NW, int NT> struct LaunchDual {
         constexpr int NCC = NW == 5 ? 3 : NW;
         if (P.diagnostics == 1) return hipErrorInvalidValue;   // the host runs include.invalid=TRUE as a plain pass followed by a masked pass of 2
         const bool wide = P.index1.wide != 0;            // barcodes of 33..64 bases on either mate (both indexes are then built wide)
-        if (compact) { if (wide) run<NCC, uint64_t>(P, R1, R2, n, counts, flag, stream); else run<NCC, uint32_t>(P, R1, R2, n, counts, flag, stream); }
-        else { if (wide) run<NW, uint64_t>(P, R1, R2, n, counts, flag, stream); else run<NW, uint32_t>(P, R1, R2, n, counts, flag, stream); }
+        const int forced = two_tiles();
+        const bool passes = P.overflow && (forced >= 0 ? forced == 0
+                                           : expected_chance_hits(P.scan1, P.max_mm1, max_len) + expected_chance_hits(P.scan2, P.max_mm2, max_len) < 0.01);
+        if (compact) { if (wide) run<NCC, uint64_t>(P, R1, R2, n, counts, flag, stream, passes); else run<NCC, uint32_t>(P, R1, R2, n, counts, flag, stream, passes); }
+        else { if (wide) run<NW, uint64_t>(P, R1, R2, n, counts, flag, stream, passes); else run<NW, uint32_t>(P, R1, R2, n, counts, flag, stream, passes); }
         return hipGetLastError();
     }
 };
@@ -938,9 +1146,9 @@ hipError_t launch_single(const ScgSingleParams& P, int tmpl_len, const ScgReads&
 template<int NW, int NT> struct LaunchRandom {
     static hipError_t go(const ScgSingleParams& P, const ScgReads& R, int64_t n, int32_t* hits, int32_t* flag, hipStream_t stream) {
         if (NW == 5 && P.scan.compact_ok && R.max_len - P.scan.len + 1 <= 96) {
-            hipLaunchKernelGGL((random_staged_kernel<NW, NT, (NW == 5 ? 3 : NW)>), dim3(staged_grid(n)), dim3(STAGE_BLOCK), 0, stream, P, R, n, hits, flag);
+            hipLaunchKernelGGL((random_staged_kernel<NW, NT, (NW == 5 ? 3 : NW)>), dim3(staged_grid(n)), dim3(STAGE_BLOCK), extra_lds(), stream, P, R, n, hits, flag);
         } else {
-            hipLaunchKernelGGL((random_staged_kernel<NW, NT, NW>), dim3(staged_grid(n)), dim3(STAGE_BLOCK), 0, stream, P, R, n, hits, flag);
+            hipLaunchKernelGGL((random_staged_kernel<NW, NT, NW>), dim3(staged_grid(n)), dim3(STAGE_BLOCK), extra_lds(), stream, P, R, n, hits, flag);
         }
         return hipGetLastError();
     }

@@ -22,6 +22,11 @@ hipError_t launch_fold(int32_t* replicas, int replica_shift, int64_t n, int32_t*
 hipError_t launch_hot_fold(int32_t* hot, int32_t* pair_of_counters, hipStream_t stream);
 // counters[unit_index[r]] += 1 for every r with unit_index[r] >= 0, through LDS histograms (ScgCounters::unit_index)
 hipError_t launch_tally(const int32_t* unit_index, int64_t n, int32_t* counters, int64_t n_counters, hipStream_t stream);
+// Combination streams (ScgCounters::unit_pair) -> runs of (distinct key, count): scg_sparse.hip.  d_sorted, d_unique: n keys
+// each; d_counts: n; d_runs: 1; scratch of sort_rle_scratch_bytes(n).
+size_t sort_rle_scratch_bytes(size_t n);
+hipError_t launch_sort_rle(const uint64_t* d_keys, uint64_t* d_sorted, size_t n, uint64_t* d_unique, uint32_t* d_counts, uint32_t* d_runs,
+                           void* d_scratch, size_t scratch_bytes, hipStream_t stream);
 hipError_t launch_match(const ScgIndex& tab, const uint8_t* d_seqs, int32_t n, int cap, int reverse,
                         int32_t* d_index, int32_t* d_mm, hipStream_t stream);
 hipError_t launch_synth(const scg_synth_spec& S, char* d_out, int64_t n, hipStream_t stream);

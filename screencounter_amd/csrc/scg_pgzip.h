@@ -238,10 +238,16 @@ inline void fixed_tables(Tables& T) {
     build_table(lens + 288, 32, DIST_BITS, T.dist, DIST_TABLE, true, dist_kind);     // (codes 30, 31 decode to K_INVALID)
 }
 
-// out[0 .. n) = out[-dist .. ), overlapping the way LZ77 means it; may write up to 8 symbols beyond n.
+// out[0 .. n) = out[-dist .. ), overlapping the way LZ77 means it; may write up to 15 symbols beyond n.
 inline void copy_match(uint16_t* out, uint32_t dist, uint32_t n) {
     const uint16_t* src = out - dist;
-    if (dist >= 4) {                                     // 8-byte steps never read what they are about to write
+    if (dist >= 8) {                                     // 16-byte steps never read what they are about to write
+        uint32_t k = 0;
+        do {
+            std::memcpy(out + k, src + k, 16);
+            k += 8;
+        } while (k < n);
+    } else if (dist >= 4) {
         for (uint32_t k = 0; k < n; k += 4) std::memcpy(out + k, src + k, 8);
     } else if (dist == 1) {
         uint64_t v = src[0];
@@ -257,7 +263,9 @@ inline void copy_match(uint16_t* out, uint32_t dist, uint32_t n) {
 //   reach     how far back a match may reach from position op = 0 (WINDOW when the text before the chunk is unknown,
 //             0 at the start of a member: "invalid distance too far back")
 // Returns BLOCK_OK / BLOCK_FINAL (the member's last block) / BLOCK_BAD / BLOCK_FULL.
-inline int decode_block(Bits& br, Tables& T, uint16_t* out, size_t& op, size_t cap, size_t reach, uint8_t* lens) {
+//   COUNT / n_symbols: measurement aid (tools/deflate_symbols.cpp): the number of literal, match and end-of-block symbols
+template<bool COUNT = false>
+inline int decode_block(Bits& br, Tables& T, uint16_t* out, size_t& op, size_t cap, size_t reach, uint8_t* lens, size_t* n_symbols = nullptr) {
     br.refill();
     if (br.overrun()) return BLOCK_BAD;
     const uint32_t last = br.take(1);
@@ -280,58 +288,100 @@ inline int decode_block(Bits& br, Tables& T, uint16_t* out, size_t& op, size_t c
     if (type == 1) fixed_tables(T);
     else if (!read_dynamic_header(br, T, lens)) return BLOCK_BAD;
     const uint32_t lit_mask = (1u << LIT_BITS) - 1u, dist_mask = (1u << DIST_BITS) - 1u;
+    // The reader's state in locals for the loop: the compiler keeps them in registers and the stores of symbols cannot
+    // be taken to alias them.
+    const uint8_t* const in = br.in;
+    const size_t in_limit = br.size + IN_SLACK;
+    size_t pos = br.pos;
+    uint64_t buf = br.buf;
+    uint32_t cnt = br.cnt;
+    size_t o = op;
+    int rc = BLOCK_BAD;
+#define SCG_PGZ_REFILL()                                         \
+    do {                                                          \
+        if (pos + 8 <= in_limit) {                                \
+            buf |= load64(in + pos) << cnt;                       \
+            const uint32_t take_ = (63u - cnt) >> 3;              \
+            pos += take_;                                         \
+            cnt += take_ * 8u;                                    \
+        }                                                         \
+    } while (0)
+#define SCG_PGZ_OVERRUN() (static_cast<uint64_t>(pos) * 8u - cnt > static_cast<uint64_t>(br.size) * 8u)
+    // (tried: a second table giving up to four literals per look-up for the runs of two- and three-bit codes of sequence
+    // lines -- 10 % slower: 16 KB more of tables to rebuild and keep in the L1 for every block)
     for (;;) {
-        br.refill();                                                     // >= 56 bits: a whole length/distance pair (<= 48)
-        uint32_t e = T.lit[static_cast<uint32_t>(br.buf) & lit_mask];
+        SCG_PGZ_REFILL();                                                // >= 56 bits: a whole length/distance pair (<= 48)
+        uint32_t e = T.lit[static_cast<uint32_t>(buf) & lit_mask];
         if (e_kind(e) == K_SUB) {
-            br.drop(LIT_BITS);
-            e = T.lit[e_payload(e) + br.peek(e_extra(e))];
+            buf >>= LIT_BITS; cnt -= LIT_BITS;
+            e = T.lit[e_payload(e) + (static_cast<uint32_t>(buf) & ((1u << e_extra(e)) - 1u))];
         }
-        br.drop(e_bits(e));
+        buf >>= e_bits(e); cnt -= e_bits(e);
         const uint32_t kind = e_kind(e);
         if (kind == K_LITERAL) {
-            if (op >= cap) return BLOCK_FULL;
-            out[op++] = static_cast<uint16_t>(e_payload(e));
-            // a second and third literal from the same refill (literals are at most 15 bits each)
-            e = T.lit[static_cast<uint32_t>(br.buf) & lit_mask];
-            if (e_kind(e) == K_LITERAL && op < cap) {
-                br.drop(e_bits(e));
-                out[op++] = static_cast<uint16_t>(e_payload(e));
-                e = T.lit[static_cast<uint32_t>(br.buf) & lit_mask];
-                if (e_kind(e) == K_LITERAL && op < cap) {
-                    br.drop(e_bits(e));
-                    out[op++] = static_cast<uint16_t>(e_payload(e));
-                }
+            if (o + 4 > cap) {
+                if (o >= cap) { rc = BLOCK_FULL; break; }
+                out[o++] = static_cast<uint16_t>(e_payload(e));
+                if (COUNT) ++*n_symbols;
+                continue;
             }
+            out[o++] = static_cast<uint16_t>(e_payload(e));
+            if (COUNT) ++*n_symbols;
+            // up to three more literals from the same refill (11 primary bits each at most, 56 in the buffer)
+            e = T.lit[static_cast<uint32_t>(buf) & lit_mask];
+            if (e_kind(e) != K_LITERAL) continue;
+            buf >>= e_bits(e); cnt -= e_bits(e);
+            out[o++] = static_cast<uint16_t>(e_payload(e));
+            if (COUNT) ++*n_symbols;
+            e = T.lit[static_cast<uint32_t>(buf) & lit_mask];
+            if (e_kind(e) != K_LITERAL) continue;
+            buf >>= e_bits(e); cnt -= e_bits(e);
+            out[o++] = static_cast<uint16_t>(e_payload(e));
+            if (COUNT) ++*n_symbols;
+            e = T.lit[static_cast<uint32_t>(buf) & lit_mask];
+            if (e_kind(e) != K_LITERAL) continue;
+            buf >>= e_bits(e); cnt -= e_bits(e);
+            out[o++] = static_cast<uint16_t>(e_payload(e));
+            if (COUNT) ++*n_symbols;
             continue;
         }
         if (kind == K_LENGTH) {
-            const uint32_t n = e_payload(e) + br.take(e_extra(e));
-            uint32_t d = T.dist[static_cast<uint32_t>(br.buf) & dist_mask];
+            const uint32_t n = e_payload(e) + (static_cast<uint32_t>(buf) & ((1u << e_extra(e)) - 1u));
+            buf >>= e_extra(e); cnt -= e_extra(e);
+            uint32_t d = T.dist[static_cast<uint32_t>(buf) & dist_mask];
             if (e_kind(d) == K_SUB) {
-                br.drop(DIST_BITS);
-                d = T.dist[e_payload(d) + br.peek(e_extra(d))];
+                buf >>= DIST_BITS; cnt -= DIST_BITS;
+                d = T.dist[e_payload(d) + (static_cast<uint32_t>(buf) & ((1u << e_extra(d)) - 1u))];
             }
-            if (e_kind(d) != K_DIST) return BLOCK_BAD;                   // "invalid distance code"
-            br.drop(e_bits(d));
-            const uint32_t dist = e_payload(d) + br.take(e_extra(d));
-            if (dist > op + reach) return BLOCK_BAD;                     // "invalid distance too far back"
-            if (n + 8 > cap - op) {
-                if (n > cap - op) return BLOCK_FULL;
-                for (uint32_t k = 0; k < n; ++k) out[op + k] = out[op + k - dist];
+            if (e_kind(d) != K_DIST) { rc = BLOCK_BAD; break; }          // "invalid distance code"
+            buf >>= e_bits(d); cnt -= e_bits(d);
+            const uint32_t dist = e_payload(d) + (static_cast<uint32_t>(buf) & ((1u << e_extra(d)) - 1u));
+            buf >>= e_extra(d); cnt -= e_extra(d);
+            if (dist > o + reach) { rc = BLOCK_BAD; break; }             // "invalid distance too far back"
+            if (n + 16 > cap - o) {
+                if (n > cap - o) { rc = BLOCK_FULL; break; }
+                for (uint32_t k = 0; k < n; ++k) out[o + k] = out[o + k - dist];
             } else {
-                copy_match(out + op, dist, n);
+                copy_match(out + o, dist, n);
             }
-            op += n;
-            if (br.overrun()) return BLOCK_BAD;
+            o += n;
+            if (COUNT) ++*n_symbols;
+            if (SCG_PGZ_OVERRUN()) { rc = BLOCK_BAD; break; }
             continue;
         }
         if (kind == K_END) {
-            if (br.overrun()) return BLOCK_BAD;
-            return last ? BLOCK_FINAL : BLOCK_OK;
+            if (COUNT) ++*n_symbols;
+            rc = SCG_PGZ_OVERRUN() ? BLOCK_BAD : (last ? BLOCK_FINAL : BLOCK_OK);
+            break;
         }
-        return BLOCK_BAD;                                                // "invalid literal/length code"
+        rc = BLOCK_BAD;                                                  // "invalid literal/length code"
+        break;
     }
+#undef SCG_PGZ_REFILL
+#undef SCG_PGZ_OVERRUN
+    br.pos = pos; br.buf = buf; br.cnt = cnt;
+    op = o;
+    return rc;
 }
 
 // The first bit position in [from, to) at which a non-final dynamic-Huffman block header parses without error, or

@@ -21,6 +21,9 @@ public:
     bool failed() const;
     // Compressed bytes per chunk that a file of `size` bytes is cut into; 0: too small to bother.
     static size_t chunk_size_for(size_t size, int threads);
+    // Decoders leave their symbol buffers (up to 40 x 32 MB of address space, of which the pages a file's chunks filled
+    // are resident: ~12 MB each) for the next one; this frees them.
+    static void release_cached();
     ParallelGunzip(const ParallelGunzip&) = delete;
     ParallelGunzip& operator=(const ParallelGunzip&) = delete;
 private:

@@ -54,13 +54,16 @@ hipError_t launch_text_scan(const char* d_text, size_t n_bytes, const TextScanBu
 // (zero-copy reads run at link speed, 56 GB/s, where sixteen hipMemcpyAsync calls of 4 MB reach 32-37 GB/s and cost the
 // host 48 us each: tools/ubench/zero_copy.hip) and lays them out back to back:
 //   seqs[seq_at[s] ...) = seq_src[s][0 .. seq_at[s+1] - seq_at[s]),
-//   offsets[first[s] + j] = off_src[s][j] + seq_at[s] for j < first[s+1] - first[s],   offsets[first[n]] = seq_at[n].
+//   offsets[first[s] + j] = off_src[s][j] - off_base[s] + seq_at[s] for j < first[s+1] - first[s],   offsets[first[n]] = seq_at[n].
+// (off_base[s] = off_src[s][0] when a segment is a stretch from the middle of what a host thread parsed: its offsets
+// count from that thread's first sequence)
 struct GatherSegments {
     uint32_t n;                  // segments (<= 64)
     const char* seq_src[64];     // device-visible host pointers
     const uint32_t* off_src[64];
     uint32_t seq_at[65];
     uint32_t first[65];
+    uint32_t off_base[64];
 };
 hipError_t launch_gather_segments(char* seqs, uint32_t* offsets, const GatherSegments& G, hipStream_t stream);
 

@@ -282,7 +282,7 @@ __global__ __launch_bounds__(TS_BLOCK) void gather_segments_kernel(char* __restr
             const uint32_t lo = k * (GATHER_TILE / 4), n = min(GATHER_TILE / 4, count - lo);
             const uint32_t* src = G.off_src[s] + lo;
             uint32_t* dst = offsets + G.first[s] + lo;
-            const uint32_t add = G.seq_at[s];
+            const uint32_t add = G.seq_at[s] - G.off_base[s];
             for (uint32_t j = threadIdx.x; j < n; j += TS_BLOCK) dst[j] = src[j] + add;
         }
     }

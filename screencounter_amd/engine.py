@@ -254,12 +254,23 @@ class Plan:
                     total=int(total.value), barcode1_only=int(b1.value), barcode2_only=int(b2.value))
 
     def read_combo(self, stream=None):
-        """Combo plans: (indices int32[2, K] sorted by (first, second), freq int32[K], total)."""
+        """Combo plans: (indices int32[2, K] sorted by (first, second), freq int32[K], total) -- from the dense histogram or,
+        for combination spaces beyond 2^26 cells, from the sorted, run-length encoded combination streams."""
         if self.kind != "combo":
             raise ValueError("read_combo needs a combo plan")
-        cells, total = self.read(stream)
-        idx, freq = combo_compact(cells, self.n_pool[0], self.n_pool[1])
-        return idx, freq, total
+        idx_p, freq_p = _lib.i32_p(), _lib.i32_p()
+        k, total = C.c_int64(0), C.c_int64(0)
+        err = errbuf()
+        check(self._lib.scg_plan_read_combinations(self._h, C.byref(idx_p), C.byref(freq_p), C.byref(k), C.byref(total),
+                                                   C.c_void_p(_stream_handle(stream)), err, _lib.ERRCAP), err)
+        K = int(k.value)
+        try:
+            idx = np.ctypeslib.as_array(idx_p, shape=(max(2 * K, 1),))[:2 * K].reshape(K, 2).T.copy()
+            freq = np.ctypeslib.as_array(freq_p, shape=(max(K, 1),))[:K].copy()
+        finally:
+            self._lib.scg_free(idx_p)
+            self._lib.scg_free(freq_p)
+        return idx.astype(np.int32), freq.astype(np.int32), int(total.value)
 
     # ---- measurement ----------------------------------------------------------------------------
     def set_profiling(self, enabled: bool) -> None:

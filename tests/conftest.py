@@ -11,6 +11,7 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "real_limit: (test_gpu_sparse.py) keep the dense limit of the combination grids where it is")
 
 
 def _ensure_built():

@@ -18,7 +18,7 @@ from typing import Dict, List, Optional, Sequence
 import numpy as np
 
 from screencounter_amd import _lib
-from screencounter_amd._lib import ScgError
+from screencounter_amd._lib import ScgError, check, errbuf
 from screencounter_amd.api import (  # noqa: F401
     count_single_barcodes, count_combo_barcodes_single, count_dual_barcodes, count_combo_barcodes_paired,
     count_single_barcodes_files, count_combo_barcodes_single_files, count_dual_barcodes_files,

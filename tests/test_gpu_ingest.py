@@ -448,3 +448,51 @@ def test_ordinary_gzip_decoded_by_all_host_threads(sc, oracle, gpu, tmp_path, mo
     with pytest.raises(_lib.ScgError) as e2:
         sc.count_single_barcodes(bad, TEMPLATE, 2, pool, 1, True, 4)
     assert e1.value.code == e2.value.code == _lib.SCG_ERR_IO and str(e1.value) == str(e2.value)
+
+
+def test_paired_plain_files_over_several_devices(sc, oracle, gpu, tmp_path, monkeypatch):
+    """More than one device in the list (an id may repeat): paired plain files go through PairedRounds -- the host threads
+    scan both mates, every round of pairs the two cursors share is gathered and counted by one device, round-robin, and
+    the per-device counters are summed.  The mates' windows hold different numbers of records (names and read lengths
+    differ), so rounds begin and end inside windows all the time; tiny windows make hundreds of them."""
+    from screencounter_amd import _lib
+    rng = random.Random(31)
+    t1, t2 = "ACGTAC" + "-" * 10 + "TGCATG", "GGATCC" + "-" * 8 + "AAGCTT"
+    u1, u2 = gen.make_pool(rng, 12, 10, "ACGT", min_dist=3), gen.make_pool(rng, 10, 8, "ACGT", min_dist=3)
+    pairs = [(a, b) for a in u1 for b in u2]
+    rng.shuffle(pairs)
+    pairs = pairs[:60]
+    pool1, pool2 = [a for a, _ in pairs], [b for _, b in pairs]
+    r1, r2 = [], []
+    for i in range(12000):
+        a, b = rng.choice(pairs) if rng.random() < 0.85 else (rng.choice(u1), rng.choice(u2))
+        x = gen.mutate(rng, gen.fill_template(t1, [a]), 0.02, 0.01, 0.02)
+        y = gen.mutate(rng, gen.fill_template(t2, [b]), 0.02, 0.01, 0.02)
+        r1.append(gen.rand_seq(rng, rng.randint(0, 60)) + x + gen.rand_seq(rng, rng.randint(0, 10)))
+        r2.append(gen.rand_seq(rng, rng.randint(0, 5)) + y)
+    p1, p2 = str(tmp_path / "m1.fastq"), str(tmp_path / "m2.fastq")
+    open(p1, "wb").write(gen.fastq_text(r1, name_prefix="a_rather_long_read_name_"))
+    open(p2, "wb").write(gen.fastq_text(r2, trailing_newline=False))
+    exp, total = oracle.count_dual(r1, r2, t1, False, 1, pool1, t2, False, 1, pool2, False, True)
+    expb, _ = oracle.count_dual(r1, r2, t1, False, 1, pool1, t2, False, 1, pool2, True, False)
+    d = oracle.count_dual_diag(r1, r2, t1, False, 1, pool1, t2, False, 1, pool2, True, True)
+    for kb in (None, 16):
+        if kb:
+            monkeypatch.setenv("SCG_WINDOW_KB", str(kb))
+        for devices in ("0,0", "0,0,0"):
+            monkeypatch.setenv("SCG_DEVICES", devices)
+            got, n = sc.count_dual_barcodes(p1, t1, False, 1, pool1, p2, t2, False, 1, pool2, False, True, False, 4)
+            assert n == total == len(r1) and np.array_equal(got, exp), (kb, devices)
+            got, n = sc.count_dual_barcodes(p1, t1, False, 1, pool1, p2, t2, False, 1, pool2, True, False, False, 4)
+            assert n == total and np.array_equal(got, expb), (kb, devices, "best, randomized")
+        # include.invalid = TRUE: the diagnostics counters are summed over the devices as well
+        counts, (idx, freq), tot, b1, b2 = sc.count_dual_barcodes(p1, t1, False, 1, pool1, p2, t2, False, 1, pool2, True, True, True, 4)
+        assert tot == d["total"] and np.array_equal(counts, d["counts"]) and np.array_equal(idx, d["indices"]) and np.array_equal(freq, d["freq"])
+        assert (b1, b2) == (d["barcode1_only"], d["barcode2_only"])
+    # unequal numbers of reads: the reference's error, whichever file is the longer one
+    short = str(tmp_path / "short.fastq")
+    open(short, "wb").write(gen.fastq_text(r2[:-7]))
+    for a, b, ta, tb, pa, pb in ((p1, short, t1, t2, pool1, pool2), (short, p1, t2, t1, pool2, pool1)):
+        with pytest.raises(_lib.ScgError) as e:
+            sc.count_dual_barcodes(a, ta, False, 1, pa, b, tb, False, 1, pb, False, True, False, 4)
+        assert e.value.code == _lib.SCG_ERR_IO and "different number of reads" in str(e.value)

@@ -17,7 +17,7 @@ from collections import defaultdict
 
 tag = sys.argv[1]
 cfg = int(sys.argv[2]) if len(sys.argv) > 2 else 2
-kernel_sub = {2: "single_staged", 5: "single_staged", 3: "combo_staged", 4: "dual_staged"}[cfg]
+kernel_sub = {2: "single_staged", 5: "single_staged", 3: "combo_staged", 4: "dual_passes"}[cfg]
 root = os.path.join("gpurun_out", f"profiles_{tag}_config{cfg}")
 os.makedirs("profiles", exist_ok=True)
 
