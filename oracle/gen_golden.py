@@ -268,10 +268,56 @@ def config1_fixture(ref: KaoriRef, tmp: str) -> None:
     print(f"config 1: {int(counts.sum())} of {total} reads mapped")
 
 
+def big_cases(ref: KaoriRef, tmp: str) -> None:
+    """tests/golden/kaori_big.json: barcodes of 65..256 bases (as long as the longest template the reference compiles,
+    src/count_single_barcodes.cpp:37-47) on every entry point; tests/golden/kaori_large_grid.json: countComboBarcodes with
+    2 x 40 000 barcodes, inputs by seed (tests/gen.py::large_grid_case) + digest, outputs in full."""
+    rng = random.Random(20261004)
+    small = (1, 12, 40)
+    out = []
+    for _ in range(24):
+        out.append(run_case(ref, gen.random_single_case(rng, max_vlen=240, sizes=small, min_vlen=65), tmp))
+    for i in range(60):
+        if i % 5 == 0:
+            c = gen.random_combo_case(rng, sizes=small, wide="big")
+        elif i % 5 == 1:
+            c = gen.random_dual_case(rng, hazard_free=True, sizes=small, max_mm=3, wide="big")
+        elif i % 5 == 2:
+            c = gen.random_dual_case(rng, hazard_free=True, sizes=small, max_mm=2, wide="big")
+            c["kind"] = "dual_diag"
+        elif i % 5 == 3:
+            c = gen.random_paired_combo_case(rng, sizes=small, max_mm=2, wide="big")
+        else:
+            c = gen.random_big_match_case(rng)
+        out.append(run_case(ref, c, tmp))
+    for i in range(30):
+        out.append(run_case(ref, gen.random_dual_single_end_case(rng, sizes=small, wide="big", nreg=1 + i % 5), tmp))
+    for i in range(16):
+        c = gen.random_dual_single_end_case(rng, sizes=small, wide="big", diag=True)
+        c["kind"] = "dual_single_end_diag"
+        out.append(run_case(ref, c, tmp))
+    with open(os.path.join(OUT, "kaori_big.json"), "w") as f:
+        json.dump({"generator": "oracle/gen_golden.py::big_cases", "reference": "kaori v1.1.1 (screenCounter 1.5.1)", "seed": 20261004, "cases": out}, f)
+    n_err = sum(1 for c in out if "error" in c["expect"])
+    print(f"big keys: {len(out)} cases ({n_err} expected errors)")
+
+    case = gen.large_grid_case()
+    done = run_case(ref, case, tmp)
+    with open(os.path.join(OUT, "kaori_large_grid.json"), "w") as f:
+        json.dump({"generator": "oracle/gen_golden.py::big_cases", "reference": "kaori v1.1.1 (screenCounter 1.5.1)",
+                   "inputs": "tests/gen.py::large_grid_case()", "inputs_sha256": gen.case_digest(case), "expect": done["expect"]}, f)
+    print(f"large grid: {len(done['expect']['freq'])} combinations of {done['expect']['total']} reads")
+
+
 def main() -> None:
     ref = KaoriRef()
     os.makedirs(OUT, exist_ok=True)
+    if sys.argv[1:] == ["big"]:                     # only the round-3 files (the others stay byte for byte)
+        with tempfile.TemporaryDirectory() as tmp:
+            big_cases(ref, tmp)
+        return
     with tempfile.TemporaryDirectory() as tmp:
+        big_cases(ref, tmp)
         ka = [run_case(ref, c, tmp) for c in known_answers()]
         for c in ka:
             check_r_expect(c)

@@ -163,7 +163,7 @@ struct DevIndex {
     void upload(const scg::HostIndex& h) {
         nodes.upload(h.nodes); tables.upload(h.tables);
         view.nodes = nodes.as<uint4>(); view.tables = tables.as<uint4>();
-        view.wide = h.wide ? 1 : 0; view.slot_mask = h.slot_mask; view.n_entries = h.n_entries; view.len = h.len; view.nseg = h.nseg;
+        view.wide = h.wide; view.slot_mask = h.slot_mask; view.n_entries = h.n_entries; view.len = h.len; view.nseg = h.nseg;
         for (int s = 0; s < SCG_MAX_SEGMENTS; ++s) view.segmask[s] = h.segmask[s];
         for (int c = 0; c < 4; ++c) view.nwalk[c] = h.nwalk[c];
     }
@@ -294,6 +294,25 @@ struct scg_plan {
 };
 
 namespace {
+// Key width classes: 0 = up to 32 bases (2 x 32-bit planes), 1 = up to 64, 2 = up to 256 ("big").  Pools that meet in one
+// kernel (both regions of a combination, both mates of a pair) are built in the widest class among them.
+int key_class(int len) { return len > SCG_MAX_WIDE_BARCODE ? 2 : (len > SCG_MAX_BARCODE ? 1 : 0); }
+
+scg::HostIndex build_index_class(int cls, const char* const* pool, int32_t n, int32_t len, int max_mm) {
+    if (cls == 2) return scg::build_index_big(pool, n, len, max_mm);
+    return cls == 1 ? scg::build_index_wide(pool, n, len, max_mm) : scg::build_index(pool, n, len, max_mm);
+}
+scg::HostIndex build_uid_index_class(int cls, const char* const* pool, int32_t n, int32_t len, int max_mm,
+                                     std::vector<std::vector<int32_t> >& expansions, size_t& n_uid) {
+    if (cls == 2) return scg::build_uid_index_big(pool, n, len, max_mm, expansions, n_uid);
+    return scg::build_uid_index_wide(pool, n, len, max_mm, expansions, n_uid);
+}
+
+// Big keys have the byte-wise general kernels only.
+bool general_only(const scg_plan* P) {
+    return scg::force_general() || P->tab[0].view.wide == 2 || (P->kind == scg_plan::DUAL_SE_DIAG && P->tab_combined.view.wide == 2);
+}
+
 // 256 MB of int32 cells: beyond that, combinations are sorted and run-length encoded.  $SCG_DENSE_CELLS moves the limit (the
 // tests run every combination case both ways).
 int64_t dense_cells() {
@@ -421,10 +440,11 @@ std::unique_ptr<scg_plan> compile_combo(const char* constant, int strand,
         }
     }
     if (mismatches < 0) throw Error(SCG_ERR_INVALID, "negative number of mismatches");
-    // pools of 33..64 bases take the wide (2 x 64-bit plane) index and kernels; both pools then, one key width per kernel
-    const bool wide = len0 > SCG_MAX_BARCODE || len1 > SCG_MAX_BARCODE;
-    P->htab[0] = wide ? scg::build_index_wide(pool0, n0, len0, mismatches) : scg::build_index(pool0, n0, len0, mismatches);
-    P->htab[1] = wide ? scg::build_index_wide(pool1, n1, len1, mismatches) : scg::build_index(pool1, n1, len1, mismatches);
+    // pools of 33..64 bases take the wide (2 x 64-bit plane) index and kernels, longer ones the big one; both pools then, one
+    // key width per kernel
+    const int cls = std::max(key_class(len0), key_class(len1));
+    P->htab[0] = build_index_class(cls, pool0, n0, len0, mismatches);
+    P->htab[1] = build_index_class(cls, pool1, n1, len1, mismatches);
     P->scan1 = scg::build_scan(P->ht1.t, mismatches);
     P->n_pool[0] = n0; P->n_pool[1] = n1;
     int64_t cells = static_cast<int64_t>(n0) * static_cast<int64_t>(n1);
@@ -459,9 +479,9 @@ std::unique_ptr<scg_plan> compile_dual(const char* constant1, int reverse1, int 
     std::vector<std::vector<int32_t> > exp1, exp2;
     std::vector<uint64_t> uk1, uk2;
     size_t n_uid1 = 0, n_uid2 = 0;
-    if (len1 > SCG_MAX_BARCODE || len2 > SCG_MAX_BARCODE) {     // barcodes of 33..64 bases on either mate: wide indexes and kernels for both
-        P->htab[0] = scg::build_uid_index_wide(pool1, n_pool, len1, mismatches1, exp1, n_uid1);
-        P->htab[1] = scg::build_uid_index_wide(pool2, n_pool, len2, mismatches2, exp2, n_uid2);
+    if (const int cls = std::max(key_class(len1), key_class(len2))) {     // barcodes of more than 32 bases on either mate: wide / big indexes and kernels for both
+        P->htab[0] = build_uid_index_class(cls, pool1, n_pool, len1, mismatches1, exp1, n_uid1);
+        P->htab[1] = build_uid_index_class(cls, pool2, n_pool, len2, mismatches2, exp2, n_uid2);
     } else {
         P->htab[0] = scg::build_uid_index(pool1, n_pool, len1, mismatches1, exp1, uk1);
         P->htab[1] = scg::build_uid_index(pool2, n_pool, len2, mismatches2, exp2, uk2);
@@ -508,9 +528,9 @@ std::unique_ptr<scg_plan> compile_dual_single_end_diag(const char* constant, int
     std::vector<std::vector<int32_t> > exp0, exp1;
     std::vector<uint64_t> uk0, uk1;
     size_t n_uid0 = 0, n_uid1 = 0;
-    if (t.flen[0] > SCG_MAX_BARCODE || t.flen[1] > SCG_MAX_BARCODE) {
-        P->htab[0] = scg::build_uid_index_wide(pools[0], n_pools[0], t.flen[0], mismatches, exp0, n_uid0);
-        P->htab[1] = scg::build_uid_index_wide(pools[1], n_pools[1], t.flen[1], mismatches, exp1, n_uid1);
+    if (const int cls = std::max(key_class(t.flen[0]), key_class(t.flen[1]))) {
+        P->htab[0] = build_uid_index_class(cls, pools[0], n_pools[0], t.flen[0], mismatches, exp0, n_uid0);
+        P->htab[1] = build_uid_index_class(cls, pools[1], n_pools[1], t.flen[1], mismatches, exp1, n_uid1);
     } else {
         P->htab[0] = scg::build_uid_index(pools[0], n_pools[0], t.flen[0], mismatches, exp0, uk0);
         P->htab[1] = scg::build_uid_index(pools[1], n_pools[1], t.flen[1], mismatches, exp1, uk1);
@@ -553,9 +573,9 @@ std::unique_ptr<scg_plan> compile_paired_combo(const char* constant1, int revers
     check(P->ht1, len1);
     check(P->ht2, len2);
     if (mismatches1 < 0 || mismatches2 < 0) throw Error(SCG_ERR_INVALID, "negative number of mismatches");
-    const bool wide = len1 > SCG_MAX_BARCODE || len2 > SCG_MAX_BARCODE;
-    P->htab[0] = wide ? scg::build_index_wide(pool1, n1, len1, mismatches1) : scg::build_index(pool1, n1, len1, mismatches1);     // values = pool indices; duplicates => error
-    P->htab[1] = wide ? scg::build_index_wide(pool2, n2, len2, mismatches2) : scg::build_index(pool2, n2, len2, mismatches2);
+    const int cls = std::max(key_class(len1), key_class(len2));
+    P->htab[0] = build_index_class(cls, pool1, n1, len1, mismatches1);     // values = pool indices; duplicates => error
+    P->htab[1] = build_index_class(cls, pool2, n2, len2, mismatches2);
     P->scan1 = scg::build_scan(P->ht1.t, mismatches1);
     P->scan2 = scg::build_scan(P->ht2.t, mismatches2);
     int64_t cells = static_cast<int64_t>(n1) * static_cast<int64_t>(n2);
@@ -701,7 +721,7 @@ void launch_batch(scg_plan* P, const ScgReads& R, int64_t n, hipStream_t stream)
         sp.max_mm = P->max_mm1; sp.use_first = P->use_first;
         sp.fwd = P->ht1.fwd; sp.rev = P->ht1.rev;
             ScgCounters counts = plan_counters(P);
-        const bool tally = use_tally(P, n) && R.max_len > 0 && R.max_len <= 320 && !scg::force_general();
+        const bool tally = use_tally(P, n) && R.max_len > 0 && R.max_len <= 320 && !general_only(P);
         if (tally) {
             DevBuf& buf = P->unit_index[stream];              // batches on different streams may be in flight together
             buf.ensure(static_cast<size_t>(n) * sizeof(int32_t));
@@ -732,7 +752,7 @@ void launch_batch(scg_plan* P, const ScgReads& R, int64_t n, hipStream_t stream)
             P->total += n;
             return;
         }
-        const bool tally = use_tally(P, n) && R.max_len > 0 && R.max_len <= 320 && !scg::force_general();
+        const bool tally = use_tally(P, n) && R.max_len > 0 && R.max_len <= 320 && !general_only(P);
         if (tally) {
             DevBuf& buf = P->unit_index[stream];
             buf.ensure(static_cast<size_t>(n) * sizeof(int32_t));
@@ -782,7 +802,7 @@ void launch_batch_paired(scg_plan* P, const ScgReads& R1, const ScgReads& R2, in
     ScgCounters counts = plan_counters(P);
     if (P->sparse) counts.unit_pair = begin_pairs(P, stream, n);      // (the invalid / all combinations of the diagnostics passes)
     const int lo_len = std::min(R1.max_len, R2.max_len), hi_len = std::max(R1.max_len, R2.max_len);
-    const bool staged = lo_len > 0 && hi_len <= 320 && !scg::force_general();
+    const bool staged = lo_len > 0 && hi_len <= 320 && !general_only(P);
     const int tmpl_len = std::max(P->ht1.t.len, P->ht2.t.len);
     dp.overflow = nullptr;
     if (staged && P->diagnostics != 2 && n < INT32_MAX) {

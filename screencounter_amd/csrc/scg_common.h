@@ -19,7 +19,9 @@
 #define SCG_MAX_REGIONS 8      // variable regions per template (countDualBarcodesSingleEnd concatenates them: DualBarcodesSingleEnd.hpp:144-163)
 #define SCG_COMBO_REGIONS 2    // pools of countComboBarcodes; reference: src/count_combo_barcodes_single.cpp:44-46
 #define SCG_MAX_BARCODE 32     // bases per key of the narrow (2 x 32-bit plane) engine
-#define SCG_MAX_WIDE_BARCODE 64   // bases per key of the wide (2 x 64-bit plane) single-end engine
+#define SCG_MAX_WIDE_BARCODE 64   // bases per key of the wide (2 x 64-bit plane) engine
+#define SCG_MAX_BIG_BARCODE 256   // bases per key of the big (2 x 256-bit plane) engine: as long as the longest template
+#define SCG_BIG_WORDS 4           // 64-bit words per plane of a big key
 #define SCG_MAX_SEGMENTS 6     // hash tables ("segment groups") of the library index (mismatch budgets <= 3)
 #define SCG_MAX_SEEDS 4        // pigeonhole seeds of the constant-region scan (budgets <= 3)
 #define SCG_SEED_LEN 10        // constant bases per seed (at most)
@@ -121,8 +123,11 @@ struct ScgIndex {
     int32_t n_entries;
     int32_t len;                // bases per key
     int32_t nseg;               // number of tables; 0 => budget too wide: dense scan of `nodes`
-    int32_t wide;               // keys of 33..64 bases: nodes / slots are two uint4 {lo64, hi64}, {value, next, 0, 0},
+    int32_t wide;               // 1: keys of 33..64 bases: nodes / slots are two uint4 {lo64, hi64}, {value, next, 0, 0},
                                 // segmask[s] is a 64-bit position mask applied to both planes
+                                // 2: keys of 65..256 bases ("big"): nodes / slots are five uint4 {lo x 4}{hi x 4}{value, next, 0, 0}
+                                // (as 64-bit words), segmask[s] holds the group as two position ranges [a0, b0) and [a1, b1),
+                                // 16 bits each from the low end (scg_big_group)
     int32_t nwalk[4];           // tables to walk for a query cap of 0..3
     uint64_t segmask[SCG_MAX_SEGMENTS];   // plane-split position mask of table s
 };
@@ -250,6 +255,38 @@ uint32_t scg_hash128(uint64_t lo, uint64_t hi) {
     uint32_t a = scg_hash64(lo), b = scg_hash64(hi);
     uint32_t h = (a ^ ((b << 15) | (b >> 17))) * 0x9E3779B1u;
     return h ^ (h >> 15);
+}
+
+// Hash of a big (2 x 256-bit plane) group key.
+static inline
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+uint32_t scg_hash_big(const uint64_t* lo, const uint64_t* hi) {
+    uint32_t h = scg_hash128(lo[0], hi[0]);
+    for (int k = 1; k < SCG_BIG_WORDS; ++k) {
+        h = (h ^ scg_hash128(lo[k] + k, hi[k])) * 0x85EBCA6Bu;
+        h ^= h >> 13;
+    }
+    return h;
+}
+
+// The position mask of a big index's group (ScgIndex::segmask) as 64-bit words.
+static inline
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+void scg_big_group(uint64_t ranges, uint64_t mask[SCG_BIG_WORDS]) {
+    for (int k = 0; k < SCG_BIG_WORDS; ++k) mask[k] = 0;
+    for (int r = 0; r < 2; ++r) {
+        const int a = (int)((ranges >> (32 * r)) & 0xFFFFu), b = (int)((ranges >> (32 * r + 16)) & 0xFFFFu);
+        for (int k = 0; k < SCG_BIG_WORDS; ++k) {
+            const int lo = a > 64 * k ? a : 64 * k, hi = b < 64 * (k + 1) ? b : 64 * (k + 1);
+            if (hi <= lo) continue;
+            const int n = hi - lo;
+            mask[k] |= (n >= 64 ? ~0ull : ((1ull << n) - 1ull)) << (lo - 64 * k);
+        }
+    }
 }
 
 #endif

@@ -92,6 +92,79 @@ __device__ __forceinline__ int const_mismatches(const ScgTemplate* __restrict__ 
 // W = uint32_t for keys of up to 32 bases (every paired-end and combinatorial path), uint64_t for
 // the wide single-end variants (barcodes of 33-64 bases, concatenated dual barcodes).
 // ---------------------------------------------------------------------------------------------
+// A 256-bit word for the planes of keys of 65..256 bases (ScgIndex::wide == 2): the operations the key code uses, word by
+// word.  Only the byte-wise general kernels are instantiated for it: such barcodes are rare and this is about reach, not
+// speed.
+struct Big {
+    uint64_t w[SCG_BIG_WORDS];
+    __device__ __forceinline__ Big() {}
+    __device__ __forceinline__ Big(uint64_t x) {
+        w[0] = x;
+#pragma unroll
+        for (int k = 1; k < SCG_BIG_WORDS; ++k) w[k] = 0;
+    }
+    __device__ __forceinline__ explicit operator bool() const {
+        uint64_t any = 0;
+#pragma unroll
+        for (int k = 0; k < SCG_BIG_WORDS; ++k) any |= w[k];
+        return any != 0;
+    }
+};
+#define SCG_BIG_BINARY(OP) \
+    __device__ __forceinline__ Big operator OP(const Big& a, const Big& b) { \
+        Big r; \
+        _Pragma("unroll") for (int k = 0; k < SCG_BIG_WORDS; ++k) r.w[k] = a.w[k] OP b.w[k]; \
+        return r; \
+    } \
+    __device__ __forceinline__ Big& operator OP##=(Big& a, const Big& b) { a = a OP b; return a; }
+SCG_BIG_BINARY(&)
+SCG_BIG_BINARY(|)
+SCG_BIG_BINARY(^)
+#undef SCG_BIG_BINARY
+__device__ __forceinline__ Big operator~(const Big& a) {
+    Big r;
+#pragma unroll
+    for (int k = 0; k < SCG_BIG_WORDS; ++k) r.w[k] = ~a.w[k];
+    return r;
+}
+__device__ __forceinline__ bool operator==(const Big& a, const Big& b) {
+    uint64_t d = 0;
+#pragma unroll
+    for (int k = 0; k < SCG_BIG_WORDS; ++k) d |= a.w[k] ^ b.w[k];
+    return d == 0;
+}
+__device__ __forceinline__ bool operator!=(const Big& a, const Big& b) { return !(a == b); }
+__device__ __forceinline__ Big operator<<(const Big& a, int n) {          // 0 <= n < 256
+    Big r;
+    const int q = n >> 6, sh = n & 63;
+#pragma unroll
+    for (int k = 0; k < SCG_BIG_WORDS; ++k) {
+        uint64_t v = 0;
+#pragma unroll
+        for (int j = 0; j < SCG_BIG_WORDS; ++j) {
+            if (j == k - q) v |= a.w[j] << sh;
+            if (j == k - q - 1 && sh) v |= a.w[j] >> (64 - sh);
+        }
+        r.w[k] = v;
+    }
+    return r;
+}
+__device__ __forceinline__ Big operator>>(const Big& a, int n) {          // 0 <= n < 256
+    Big r;
+    const int q = n >> 6, sh = n & 63;
+#pragma unroll
+    for (int k = 0; k < SCG_BIG_WORDS; ++k) {
+        uint64_t v = 0;
+#pragma unroll
+        for (int j = 0; j < SCG_BIG_WORDS; ++j) {
+            if (j == k + q) v |= a.w[j] >> sh;
+            if (j == k + q + 1 && sh) v |= a.w[j] << (64 - sh);
+        }
+        r.w[k] = v;
+    }
+    return r;
+}
+
 template<class W>
 struct QueryT {
     W lo, hi;            // code bit planes
@@ -105,10 +178,32 @@ template<class W> __device__ __forceinline__ W low_mask_w(int len);
 template<> __device__ __forceinline__ uint32_t low_mask_w<uint32_t>(int len) { return low_mask(len); }
 template<> __device__ __forceinline__ uint64_t low_mask_w<uint64_t>(int len) { return len >= 64 ? ~0ull : ((1ull << len) - 1ull); }
 
+template<> __device__ __forceinline__ Big low_mask_w<Big>(int len) {
+    Big r;
+#pragma unroll
+    for (int k = 0; k < SCG_BIG_WORDS; ++k) {
+        const int n = len - 64 * k;
+        r.w[k] = n >= 64 ? ~0ull : (n <= 0 ? 0ull : ((1ull << n) - 1ull));
+    }
+    return r;
+}
+
 __device__ __forceinline__ int popcount_w(uint32_t x) { return __popc(x); }
 __device__ __forceinline__ int popcount_w(uint64_t x) { return __popcll(x); }
 __device__ __forceinline__ uint32_t bitrev_w(uint32_t x) { return __brev(x); }
 __device__ __forceinline__ uint64_t bitrev_w(uint64_t x) { return __brevll(x); }
+__device__ __forceinline__ int popcount_w(const Big& x) {
+    int n = 0;
+#pragma unroll
+    for (int k = 0; k < SCG_BIG_WORDS; ++k) n += __popcll(x.w[k]);
+    return n;
+}
+__device__ __forceinline__ Big bitrev_w(const Big& x) {
+    Big r;
+#pragma unroll
+    for (int k = 0; k < SCG_BIG_WORDS; ++k) r.w[k] = __brevll(x.w[SCG_BIG_WORDS - 1 - k]);
+    return r;
+}
 
 // Reverse complement of a plane-split region: reverse the bit order, complement = code ^ 2
 // (flips plane 1 only).  Equivalent to kaori indexing reverse-complemented barcodes
@@ -167,6 +262,7 @@ __device__ __forceinline__ uint4 load_node(const uint4* p) {
 template<class W> struct KeyOps;
 template<> struct KeyOps<uint32_t> {
     struct Node { uint32_t lo, hi; int val, next; };
+    static constexpr int STRIDE = 1;         // uint4 per node / slot
     static __device__ __forceinline__ Node load(const uint4* base, size_t i) {
         const uint4 v = load_node(base + i);
         return Node{v.x, v.y, (int)v.z, (int)v.w};
@@ -176,12 +272,36 @@ template<> struct KeyOps<uint32_t> {
 };
 template<> struct KeyOps<uint64_t> {
     struct Node { uint64_t lo, hi; int val, next; };
+    static constexpr int STRIDE = 2;
     static __device__ __forceinline__ Node load(const uint4* base, size_t i) {
         const uint4 a = load_node(base + 2 * i), b = load_node(base + 2 * i + 1);
         return Node{((uint64_t)a.y << 32) | a.x, ((uint64_t)a.w << 32) | a.z, (int)b.x, (int)b.y};
     }
     static __device__ __forceinline__ uint64_t plane_mask(uint64_t m, int) { return m; }
     static __device__ __forceinline__ uint32_t hash(uint64_t lo, uint64_t hi) { return scg_hash128(lo, hi); }
+};
+template<> struct KeyOps<Big> {
+    struct Node { Big lo, hi; int val, next; };
+    static constexpr int STRIDE = 5;         // {lo x 4 words}{hi x 4 words}{value, next, 0, 0}
+    static __device__ __forceinline__ Node load(const uint4* base, size_t i) {
+        Node n;
+        const uint4* p = base + 5 * i;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const uint4 a = load_node(p + k), b = load_node(p + 2 + k);
+            n.lo.w[2 * k] = ((uint64_t)a.y << 32) | a.x; n.lo.w[2 * k + 1] = ((uint64_t)a.w << 32) | a.z;
+            n.hi.w[2 * k] = ((uint64_t)b.y << 32) | b.x; n.hi.w[2 * k + 1] = ((uint64_t)b.w << 32) | b.z;
+        }
+        const uint4 c = load_node(p + 4);
+        n.val = (int)c.x; n.next = (int)c.y;
+        return n;
+    }
+    static __device__ __forceinline__ Big plane_mask(uint64_t ranges, int) {
+        Big m;
+        scg_big_group(ranges, m.w);
+        return m;
+    }
+    static __device__ __forceinline__ uint32_t hash(const Big& lo, const Big& hi) { return scg_hash_big(lo.w, hi.w); }
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -222,7 +342,7 @@ __device__ __forceinline__ void index_search(const ScgIndex& X, const QueryT<W>&
         if (q.other & mlo) continue;              // a non-ACGT byte spoils this group
         const W sklo = q.lo & mlo, skhi = q.hi & mhi;
         uint32_t pos = K::hash(sklo, skhi) & X.slot_mask;
-        const uint4* table = X.tables + (size_t)s * nslots * (sizeof(W) / 4);
+        const uint4* table = X.tables + (size_t)s * nslots * K::STRIDE;
         // the slot of a group key holds the head node of its chain: an exact hit is one access
         // (tried: 4-byte slots -- hash tag over head index -- so that the tables of a 100 k-barcode library stay in an
         // XCD's L2, the node fetched behind a matching tag: +12 % on configs 2 and 5; the second, dependent gather costs
@@ -236,7 +356,7 @@ __device__ __forceinline__ void index_search(const ScgIndex& X, const QueryT<W>&
             pos = (pos + 1) & X.slot_mask;
         }
         if (!found) continue;
-        const uint4* nodes = X.nodes + (size_t)s * (size_t)X.n_entries * (sizeof(W) / 4);
+        const uint4* nodes = X.nodes + (size_t)s * (size_t)X.n_entries * K::STRIDE;
         for (;;) {
             int d = query_distance<W>(q, ent.lo, ent.hi, lm);
             if (d <= cap && f(ent.val, d)) return;
@@ -325,7 +445,7 @@ __device__ __forceinline__ void pair_match(const ScgIndex& X1, const ScgIndex& X
         }
     };
     // (wide keys have no dense pair list: their budgets beyond the tables fall through to index_search's dense scans)
-    if (sizeof(W) == 8 || (X1.nseg != 0 && X2.nseg != 0)) {
+    if (sizeof(W) >= 8 || (X1.nseg != 0 && X2.nseg != 0)) {
         // The neighbourhoods of the two halves are gathered once each (they hold one or two
         // sequences in practice) and crossed; only a pathological library overflows the small
         // arrays, in which case the halves are searched nested.

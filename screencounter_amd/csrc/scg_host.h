@@ -38,7 +38,7 @@ struct HostIndex {
     int32_t len = 0;
     int32_t n_entries = 0;
     int32_t nseg = 0;
-    bool wide = false;               // 2 x 64-bit planes: 8 words per node / slot (ScgIndex::wide)
+    int wide = 0;                    // 1: 2 x 64-bit planes, 8 words per node / slot; 2: 2 x 256-bit planes, 20 words (ScgIndex::wide)
     uint32_t slot_mask = 0;
     int32_t nwalk[4] = {0, 0, 0, 0};
     uint64_t segmask[SCG_MAX_SEGMENTS] = {0, 0, 0, 0, 0, 0};
@@ -52,8 +52,13 @@ struct HostIndex {
 // detected (a, b) when constructing the trie").
 HostIndex build_index(const char* const* pool, int32_t n, int32_t len, int max_mm);
 
-// Same for keys of up to 64 bases (wide index; always used for concatenated multi-region keys).
+// Same for keys of up to 64 bases (wide index; always used for concatenated multi-region keys) and, beyond, of up to 256
+// bases (big index) -- the longest a template can be (src/count_single_barcodes.cpp:37-47).
 HostIndex build_index_wide(const char* const* pool, int32_t n, int32_t len, int max_mm);
+// The big index whatever the length (a pool that shares a kernel with a pool of more than 64 bases).
+HostIndex build_index_big(const char* const* pool, int32_t n, int32_t len, int max_mm);
+HostIndex build_uid_index_big(const char* const* pool, int32_t n, int32_t len, int max_mm,
+                              std::vector<std::vector<int32_t> >& expansions, size_t& n_uid);
 
 // value = uid of the concrete sequence (duplicates within the pool merge).  expansions[i] receives
 // the uids of barcode i's concrete expansions, in lexicographic (A,C,G,T) order.

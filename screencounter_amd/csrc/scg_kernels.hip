@@ -1135,8 +1135,9 @@ static bool use_general(int max_len) { return force_general() || max_len <= 0 ||
 
 hipError_t launch_single(const ScgSingleParams& P, int tmpl_len, const ScgReads& R, int64_t n, const ScgCounters& counts, int32_t* flag, hipStream_t stream) {
     if (n <= 0) return hipSuccess;
-    if (use_general(R.max_len)) {
-        if (P.index.wide || P.scan.nreg != 1) hipLaunchKernelGGL(single_kernel<uint64_t>, dim3(grid_for(n)), dim3(BLOCK), 0, stream, P, R, n, counts);
+    if (use_general(R.max_len) || P.index.wide == 2) {
+        if (P.index.wide == 2) hipLaunchKernelGGL(single_kernel<Big>, dim3(grid_for(n)), dim3(BLOCK), 0, stream, P, R, n, counts);     // keys of 65..256 bases
+        else if (P.index.wide || P.scan.nreg != 1) hipLaunchKernelGGL(single_kernel<uint64_t>, dim3(grid_for(n)), dim3(BLOCK), 0, stream, P, R, n, counts);
         else hipLaunchKernelGGL(single_kernel<uint32_t>, dim3(grid_for(n)), dim3(BLOCK), 0, stream, P, R, n, counts);
         return hipGetLastError();
     }
@@ -1165,8 +1166,9 @@ hipError_t launch_random(const ScgSingleParams& P, int tmpl_len, const ScgReads&
 
 hipError_t launch_combo(const ScgComboParams& P, int tmpl_len, const ScgReads& R, int64_t n, const ScgCounters& cells, int32_t* flag, hipStream_t stream) {
     if (n <= 0) return hipSuccess;
-    if (use_general(R.max_len)) {
-        if (P.index[0].wide) hipLaunchKernelGGL(combo_kernel<uint64_t>, dim3(grid_for(n)), dim3(BLOCK), 0, stream, P, R, n, cells);
+    if (use_general(R.max_len) || P.index[0].wide == 2) {
+        if (P.index[0].wide == 2) hipLaunchKernelGGL(combo_kernel<Big>, dim3(grid_for(n)), dim3(BLOCK), 0, stream, P, R, n, cells);
+        else if (P.index[0].wide) hipLaunchKernelGGL(combo_kernel<uint64_t>, dim3(grid_for(n)), dim3(BLOCK), 0, stream, P, R, n, cells);
         else hipLaunchKernelGGL(combo_kernel<uint32_t>, dim3(grid_for(n)), dim3(BLOCK), 0, stream, P, R, n, cells);
         return hipGetLastError();
     }
@@ -1176,8 +1178,9 @@ hipError_t launch_combo(const ScgComboParams& P, int tmpl_len, const ScgReads& R
 hipError_t launch_dual(const ScgDualParams& P, int tmpl_len, const ScgReads& R1, const ScgReads& R2, int64_t n, const ScgCounters& counts, int32_t* flag, hipStream_t stream) {
     if (n <= 0) return hipSuccess;
     const int lo_len = R1.max_len < R2.max_len ? R1.max_len : R2.max_len;
-    if (use_general(lo_len) || use_general(R1.max_len > R2.max_len ? R1.max_len : R2.max_len)) {
-        if (P.index1.wide) hipLaunchKernelGGL(dual_kernel<uint64_t>, dim3(grid_for(n)), dim3(BLOCK), 0, stream, P, R1, R2, n, counts);
+    if (use_general(lo_len) || use_general(R1.max_len > R2.max_len ? R1.max_len : R2.max_len) || P.index1.wide == 2) {
+        if (P.index1.wide == 2) hipLaunchKernelGGL(dual_kernel<Big>, dim3(grid_for(n)), dim3(BLOCK), 0, stream, P, R1, R2, n, counts);
+        else if (P.index1.wide) hipLaunchKernelGGL(dual_kernel<uint64_t>, dim3(grid_for(n)), dim3(BLOCK), 0, stream, P, R1, R2, n, counts);
         else hipLaunchKernelGGL(dual_kernel<uint32_t>, dim3(grid_for(n)), dim3(BLOCK), 0, stream, P, R1, R2, n, counts);
         return hipGetLastError();
     }
@@ -1340,7 +1343,8 @@ hipError_t launch_fold(int32_t* replicas, int shift, int64_t n, int32_t* counter
 hipError_t launch_match(const ScgIndex& tab, const uint8_t* d_seqs, int32_t n, int cap, int reverse,
                         int32_t* d_index, int32_t* d_mm, hipStream_t stream) {
     if (n <= 0) return hipSuccess;
-    if (tab.wide) hipLaunchKernelGGL(match_kernel<uint64_t>, dim3(grid_for(n)), dim3(BLOCK), 0, stream, tab, d_seqs, n, cap, reverse, d_index, d_mm);
+    if (tab.wide == 2) hipLaunchKernelGGL(match_kernel<Big>, dim3(grid_for(n)), dim3(BLOCK), 0, stream, tab, d_seqs, n, cap, reverse, d_index, d_mm);
+    else if (tab.wide) hipLaunchKernelGGL(match_kernel<uint64_t>, dim3(grid_for(n)), dim3(BLOCK), 0, stream, tab, d_seqs, n, cap, reverse, d_index, d_mm);
     else hipLaunchKernelGGL(match_kernel<uint32_t>, dim3(grid_for(n)), dim3(BLOCK), 0, stream, tab, d_seqs, n, cap, reverse, d_index, d_mm);
     return hipGetLastError();
 }

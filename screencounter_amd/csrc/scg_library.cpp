@@ -4,6 +4,7 @@
 #include "scg_host.h"
 
 #include <algorithm>
+#include <array>
 #include <cstdlib>
 #include <cstring>
 #include <exception>
@@ -379,31 +380,50 @@ HostIndex build_index(const char* const* pool, int32_t n, int32_t len, int max_m
 }
 
 // ---------------------------------------------------------------------------------------------
-// Wide keys (33..64 bases, or several regions concatenated): same index, 2 x 64-bit planes.
+// Wide keys (33..64 bases, or several regions concatenated: N = 1 word of 64 bits per plane) and big keys (65..256
+// bases: N = SCG_BIG_WORDS): the same index.  A node / slot is {lo words}{hi words}{value, next}, padded to whole uint4:
+// 8 and 20 32-bit words.
 // ---------------------------------------------------------------------------------------------
 namespace {
 
-struct WideKey {
-    uint64_t lo, hi;
-    bool operator==(const WideKey& o) const { return lo == o.lo && hi == o.hi; }
+template<int N>
+struct KeyN {
+    uint64_t lo[N], hi[N];
+    bool operator==(const KeyN& o) const {
+        for (int k = 0; k < N; ++k) if (lo[k] != o.lo[k] || hi[k] != o.hi[k]) return false;
+        return true;
+    }
 };
-struct WideKeyHash {
-    size_t operator()(const WideKey& k) const { return (static_cast<size_t>(scg_hash64(k.lo)) << 32) ^ scg_hash64(k.hi) ^ (k.lo * 0x9E3779B97F4A7C15ull); }
+template<int N>
+struct KeyNHash {
+    size_t operator()(const KeyN<N>& k) const {
+        size_t h = 0;
+        for (int w = 0; w < N; ++w) {
+            h = h * 0x9E3779B97F4A7C15ull + ((static_cast<size_t>(scg_hash64(k.lo[w])) << 32) ^ scg_hash64(k.hi[w]) ^ (k.lo[w] * 0x9E3779B97F4A7C15ull));
+        }
+        return h;
+    }
 };
+template<int N> constexpr int node_words() { return N == 1 ? 8 : 20; }
+template<int N> uint32_t group_hash(const KeyN<N>& k);
+template<> uint32_t group_hash<1>(const KeyN<1>& k) { return scg_hash128(k.lo[0], k.hi[0]); }
+template<> uint32_t group_hash<SCG_BIG_WORDS>(const KeyN<SCG_BIG_WORDS>& k) { return scg_hash_big(k.lo, k.hi); }
 
-template<class F>
-void for_each_expansion_wide(const char* s, int len, F f) {
-    int cnt[SCG_MAX_WIDE_BARCODE], codes[SCG_MAX_WIDE_BARCODE][4], choice[SCG_MAX_WIDE_BARCODE];
+template<int N, class F>
+void for_each_expansion_n(const char* s, int len, F f) {
+    constexpr int MAXLEN = 64 * N;
+    int cnt[MAXLEN], codes[MAXLEN][4], choice[MAXLEN];
     for (int p = 0; p < len; ++p) {
         cnt[p] = iupac_codes(s[p], codes[p]);
         choice[p] = 0;
     }
     for (;;) {
-        WideKey key{0, 0};
+        KeyN<N> key;
+        std::memset(&key, 0, sizeof(key));
         for (int p = 0; p < len; ++p) {
             uint64_t c = static_cast<uint64_t>(codes[p][choice[p]]);
-            key.lo |= (c & 1) << p;
-            key.hi |= (c >> 1) << p;
+            key.lo[p >> 6] |= (c & 1) << (p & 63);
+            key.hi[p >> 6] |= (c >> 1) << (p & 63);
         }
         f(key);
         int p = len - 1;
@@ -415,75 +435,105 @@ void for_each_expansion_wide(const char* s, int len, F f) {
     }
 }
 
-void put_node(uint32_t* node, const WideKey& k, uint32_t val, uint32_t next) {
-    node[0] = static_cast<uint32_t>(k.lo); node[1] = static_cast<uint32_t>(k.lo >> 32);
-    node[2] = static_cast<uint32_t>(k.hi); node[3] = static_cast<uint32_t>(k.hi >> 32);
-    node[4] = val; node[5] = next; node[6] = 0; node[7] = 0;
+template<int N>
+void put_node(uint32_t* node, const KeyN<N>& k, uint32_t val, uint32_t next) {
+    for (int w = 0; w < N; ++w) {
+        node[2 * w] = static_cast<uint32_t>(k.lo[w]); node[2 * w + 1] = static_cast<uint32_t>(k.lo[w] >> 32);
+        node[2 * N + 2 * w] = static_cast<uint32_t>(k.hi[w]); node[2 * N + 2 * w + 1] = static_cast<uint32_t>(k.hi[w] >> 32);
+    }
+    node[4 * N] = val; node[4 * N + 1] = next;
+    for (int w = 4 * N + 2; w < node_words<N>(); ++w) node[w] = 0;
 }
 
-} // namespace
-
-static void check_wide_len(int len) {
-    if (len > SCG_MAX_WIDE_BARCODE) {
-        throw Error(SCG_ERR_UNSUPPORTED, "variable regions longer than 64 bp in total are not supported by this engine (got " + std::to_string(len) + ")");
+template<int N>
+void check_len_n(int len) {
+    if (len > 64 * N) {
+        throw Error(SCG_ERR_UNSUPPORTED, "variable regions longer than " + std::to_string(64 * N) + " bp in total are not supported by this engine (got " +
+                                         std::to_string(len) + ")");
     }
 }
 
-// Tables and node copies of a wide (2 x 64-bit plane) index over concrete keys with their values.
-static void finish_index_wide(HostIndex& X, const std::vector<WideKey>& keys, const std::vector<int32_t>& vals, int32_t len, int max_mm) {
-    X.wide = true;
+// A group of key positions: up to two ranges [a, b).
+struct Group { int a0, b0, a1, b1; };
+
+template<int N>
+KeyN<N> masked(const KeyN<N>& k, const uint64_t mask[N]) {
+    KeyN<N> r;
+    for (int w = 0; w < N; ++w) { r.lo[w] = k.lo[w] & mask[w]; r.hi[w] = k.hi[w] & mask[w]; }
+    return r;
+}
+
+// Tables and node copies of a wide / big index over concrete keys with their values.
+template<int N>
+void finish_index_n(HostIndex& X, const std::vector<KeyN<N> >& keys, const std::vector<int32_t>& vals, int32_t len, int max_mm) {
+    constexpr int NW = node_words<N>();
+    X.wide = N == 1 ? 1 : 2;
     X.len = len;
     const size_t cnt = keys.size();
     X.n_entries = static_cast<int32_t>(cnt);
-    auto slice = [&](int part, int parts) -> uint64_t {
-        int a = static_cast<int>(static_cast<int64_t>(part) * len / parts);
-        int b = static_cast<int>(static_cast<int64_t>(part + 1) * len / parts);
-        return (b - a >= 64) ? ~0ull : (((1ull << (b - a)) - 1ull) << a);
+    auto slice = [&](int part, int parts, int& a, int& b) {
+        a = static_cast<int>(static_cast<int64_t>(part) * len / parts);
+        b = static_cast<int>(static_cast<int64_t>(part + 1) * len / parts);
     };
-    std::vector<uint64_t> groups;           // same position groups as finish_index, as 64-bit position masks
+    std::vector<Group> groups;              // same position groups as finish_index
+    auto one = [&](int part, int parts) { Group g{0, 0, 0, 0}; slice(part, parts, g.a0, g.b0); groups.push_back(g); };
     if (max_mm == 0) {
-        groups.push_back(slice(0, 1));
+        one(0, 1);
         X.nwalk[0] = X.nwalk[1] = X.nwalk[2] = X.nwalk[3] = 1;
     } else if (max_mm == 1) {
-        groups.push_back(slice(0, 2));
-        groups.push_back(slice(1, 2));
+        one(0, 2);
+        one(1, 2);
         X.nwalk[0] = 1; X.nwalk[1] = X.nwalk[2] = X.nwalk[3] = 2;
     } else if (max_mm == 2) {
         static const int pairs[6][2] = {{0, 1}, {2, 3}, {0, 2}, {1, 3}, {0, 3}, {1, 2}};
-        for (auto& pr : pairs) groups.push_back(slice(pr[0], 4) | slice(pr[1], 4));
+        for (auto& pr : pairs) {
+            Group g;
+            slice(pr[0], 4, g.a0, g.b0);
+            slice(pr[1], 4, g.a1, g.b1);
+            groups.push_back(g);
+        }
         X.nwalk[0] = 1; X.nwalk[1] = 2; X.nwalk[2] = X.nwalk[3] = 6;
     } else if (max_mm == 3) {
-        for (int q = 0; q < 4; ++q) groups.push_back(slice(q, 4));
+        for (int q = 0; q < 4; ++q) one(q, 4);
         X.nwalk[0] = 1; X.nwalk[1] = 2; X.nwalk[2] = 3; X.nwalk[3] = 4;
     }
     const int nseg = static_cast<int>(groups.size());
     X.nseg = nseg;
     const int ncopies = nseg > 0 ? nseg : 1;
-    X.nodes.resize(static_cast<size_t>(ncopies) * cnt * 8);
+    X.nodes.resize(static_cast<size_t>(ncopies) * cnt * NW);
     for (int c = 0; c < ncopies; ++c) {
-        uint32_t* node = X.nodes.data() + static_cast<size_t>(c) * cnt * 8;
-        for (size_t e = 0; e < cnt; ++e) put_node(node + 8 * e, keys[e], static_cast<uint32_t>(vals[e]), 0xFFFFFFFFu);
+        uint32_t* node = X.nodes.data() + static_cast<size_t>(c) * cnt * NW;
+        for (size_t e = 0; e < cnt; ++e) put_node<N>(node + NW * e, keys[e], static_cast<uint32_t>(vals[e]), 0xFFFFFFFFu);
     }
     if (nseg == 0) return;
     uint32_t cap = 16;
     while (cap < cnt * table_factor(cnt)) cap <<= 1;
     X.slot_mask = cap - 1;
-    X.tables.resize(static_cast<size_t>(nseg) * cap * 8);
-    for (int sgm = 0; sgm < nseg; ++sgm) X.segmask[sgm] = groups[sgm];
+    X.tables.resize(static_cast<size_t>(nseg) * cap * NW);
+    std::vector<std::array<uint64_t, N> > masks(nseg);
+    for (int sgm = 0; sgm < nseg; ++sgm) {
+        const Group& g = groups[sgm];
+        const uint64_t ranges = static_cast<uint64_t>(g.a0) | (static_cast<uint64_t>(g.b0) << 16) | (static_cast<uint64_t>(g.a1) << 32) | (static_cast<uint64_t>(g.b1) << 48);
+        uint64_t m[SCG_BIG_WORDS];
+        scg_big_group(ranges, m);
+        for (int w = 0; w < N; ++w) masks[sgm][w] = m[w];
+        // wide: the 64-bit position mask itself; big: the ranges (ScgIndex::segmask)
+        X.segmask[sgm] = N == 1 ? m[0] : ranges;
+    }
     for_each_group(nseg, [&](int sgm) {             // as finish_index
-        const uint64_t mask = groups[sgm];
+        const uint64_t* mask = masks[sgm].data();
         const uint32_t slot_mask = X.slot_mask;
-        uint32_t* node = X.nodes.data() + static_cast<size_t>(sgm) * cnt * 8;
-        uint32_t* table = X.tables.data() + static_cast<size_t>(sgm) * cap * 8;
+        uint32_t* node = X.nodes.data() + static_cast<size_t>(sgm) * cnt * NW;
+        uint32_t* table = X.tables.data() + static_cast<size_t>(sgm) * cap * NW;
         std::vector<int32_t> placed(cap, -1);
         for (size_t i = cnt; i-- > 0;) {
-            const WideKey sk{keys[i].lo & mask, keys[i].hi & mask};
-            uint32_t pos = scg_hash128(sk.lo, sk.hi) & slot_mask;
+            const KeyN<N> sk = masked<N>(keys[i], mask);
+            uint32_t pos = group_hash<N>(sk) & slot_mask;
             for (;;) {
                 const int32_t e = placed[pos];
                 if (e < 0) { placed[pos] = static_cast<int32_t>(i); break; }
-                if ((keys[e].lo & mask) == sk.lo && (keys[e].hi & mask) == sk.hi) {
-                    node[8 * i + 5] = static_cast<uint32_t>(e);
+                if (masked<N>(keys[e], mask) == sk) {
+                    node[NW * i + 4 * N + 1] = static_cast<uint32_t>(e);
                     placed[pos] = static_cast<int32_t>(i);
                     break;
                 }
@@ -493,23 +543,24 @@ static void finish_index_wide(HostIndex& X, const std::vector<WideKey>& keys, co
         for (uint32_t pos = 0; pos < cap; ++pos) {
             const int32_t e = placed[pos];
             if (e < 0) {
-                for (int w = 0; w < 8; ++w) table[8 * pos + w] = 0;
-                table[8 * pos + 5] = SCG_SLOT_EMPTY;
+                for (int w = 0; w < NW; ++w) table[NW * pos + w] = 0;
+                table[NW * pos + 4 * N + 1] = SCG_SLOT_EMPTY;
             } else {
-                for (int w = 0; w < 8; ++w) table[8 * pos + w] = node[8 * static_cast<size_t>(e) + w];
+                for (int w = 0; w < NW; ++w) table[NW * pos + w] = node[NW * static_cast<size_t>(e) + w];
             }
         }
     });
 }
 
-HostIndex build_index_wide(const char* const* pool, int32_t n, int32_t len, int max_mm) {
-    check_wide_len(len);
+template<int N>
+HostIndex build_index_n(const char* const* pool, int32_t n, int32_t len, int max_mm) {
+    check_len_n<N>(len);
     count_expansions(pool, n, len);
-    std::unordered_map<WideKey, int32_t, WideKeyHash> owner;
-    std::vector<WideKey> keys;
+    std::unordered_map<KeyN<N>, int32_t, KeyNHash<N> > owner;
+    std::vector<KeyN<N> > keys;
     std::vector<int32_t> vals;
     for (int32_t i = 0; i < n; ++i) {
-        for_each_expansion_wide(pool[i], len, [&](const WideKey& key) {
+        for_each_expansion_n<N>(pool[i], len, [&](const KeyN<N>& key) {
             auto ins = owner.emplace(key, i);
             if (!ins.second) throw_duplicate(ins.first->second, i);
             keys.push_back(key);
@@ -517,20 +568,20 @@ HostIndex build_index_wide(const char* const* pool, int32_t n, int32_t len, int 
         });
     }
     HostIndex X;
-    finish_index_wide(X, keys, vals, len, max_mm);
+    finish_index_n<N>(X, keys, vals, len, max_mm);
     return X;
 }
 
-// value = uid of the concrete sequence, wide keys (build_uid_index for pools of 33..64 bases, or paired with one).
-HostIndex build_uid_index_wide(const char* const* pool, int32_t n, int32_t len, int max_mm,
-                               std::vector<std::vector<int32_t> >& expansions, size_t& n_uid) {
-    check_wide_len(len);
+template<int N>
+HostIndex build_uid_index_n(const char* const* pool, int32_t n, int32_t len, int max_mm,
+                            std::vector<std::vector<int32_t> >& expansions, size_t& n_uid) {
+    check_len_n<N>(len);
     count_expansions(pool, n, len);
-    std::unordered_map<WideKey, int32_t, WideKeyHash> uid_of;
-    std::vector<WideKey> keys;
+    std::unordered_map<KeyN<N>, int32_t, KeyNHash<N> > uid_of;
+    std::vector<KeyN<N> > keys;
     expansions.assign(n, std::vector<int32_t>());
     for (int32_t i = 0; i < n; ++i) {
-        for_each_expansion_wide(pool[i], len, [&](const WideKey& key) {
+        for_each_expansion_n<N>(pool[i], len, [&](const KeyN<N>& key) {
             auto ins = uid_of.emplace(key, static_cast<int32_t>(keys.size()));
             if (ins.second) keys.push_back(key);
             expansions[i].push_back(ins.first->second);
@@ -540,8 +591,27 @@ HostIndex build_uid_index_wide(const char* const* pool, int32_t n, int32_t len, 
     for (size_t u = 0; u < keys.size(); ++u) vals[u] = static_cast<int32_t>(u);
     n_uid = keys.size();
     HostIndex X;
-    finish_index_wide(X, keys, vals, len, max_mm);
+    finish_index_n<N>(X, keys, vals, len, max_mm);
     return X;
+}
+
+} // namespace
+
+HostIndex build_index_wide(const char* const* pool, int32_t n, int32_t len, int max_mm) {
+    return len > SCG_MAX_WIDE_BARCODE ? build_index_n<SCG_BIG_WORDS>(pool, n, len, max_mm) : build_index_n<1>(pool, n, len, max_mm);
+}
+
+// value = uid of the concrete sequence, wide keys (build_uid_index for pools of 33..64 bases, or paired with one).
+HostIndex build_uid_index_wide(const char* const* pool, int32_t n, int32_t len, int max_mm,
+                               std::vector<std::vector<int32_t> >& expansions, size_t& n_uid) {
+    return len > SCG_MAX_WIDE_BARCODE ? build_uid_index_n<SCG_BIG_WORDS>(pool, n, len, max_mm, expansions, n_uid)
+                                      : build_uid_index_n<1>(pool, n, len, max_mm, expansions, n_uid);
+}
+
+HostIndex build_index_big(const char* const* pool, int32_t n, int32_t len, int max_mm) { return build_index_n<SCG_BIG_WORDS>(pool, n, len, max_mm); }
+HostIndex build_uid_index_big(const char* const* pool, int32_t n, int32_t len, int max_mm,
+                              std::vector<std::vector<int32_t> >& expansions, size_t& n_uid) {
+    return build_uid_index_n<SCG_BIG_WORDS>(pool, n, len, max_mm, expansions, n_uid);
 }
 
 HostIndex build_uid_index(const char* const* pool, int32_t n, int32_t len, int max_mm,

@@ -105,11 +105,11 @@ def make_reads(rng, template, pools, n, strand, p_sub, p_n, p_lower, p_junk, pad
 # Whole random cases (inputs only) for the three entry points and the matcher.
 # ---------------------------------------------------------------------------------------------
 def random_single_case(rng: random.Random, max_vlen: int = 33, sizes=(1, 30, 200), min_vlen: int = 0) -> dict:
-    vlen = rng.choice([v for v in (3, 4, 6, 8, 10, 20, 33, 40, 57, 64) if min_vlen <= v <= max_vlen])
+    vlen = rng.choice([v for v in (3, 4, 6, 8, 10, 20, 33, 40, 57, 64, 65, 100, 128, 129, 200, 240) if min_vlen <= v <= max_vlen])
     alphabet = rng.choice(["AC", "ACG", BASES, BASES])
     npool = rng.choice([1, 2, 5, 20, 100])
-    pool = make_pool(rng, npool, vlen, alphabet, min_dist=1, iupac_rate=rng.choice([0, 0, 0.05]))
-    template = make_template(rng, 1, [vlen], rng.choice([0, 1, 3]), rng.choice([4, 8, 12, 40]))
+    pool = make_pool(rng, npool, vlen, alphabet, min_dist=1, iupac_rate=rng.choice([0, 0, 0.05 if vlen <= 64 else 0.01]))
+    template = make_template(rng, 1, [vlen], rng.choice([0, 1, 3]), rng.choice([4, 8, 12, 40]) if vlen <= 128 else 8)    # (templates: at most 256)
     strand = rng.choice([0, 1, 2])
     mm = rng.choice([0, 1, 1, 2, 3])
     first = rng.random() < 0.5
@@ -120,11 +120,13 @@ def random_single_case(rng: random.Random, max_vlen: int = 33, sizes=(1, 30, 200
 
 def random_combo_case(rng: random.Random, sizes=(1, 30, 200), wide: bool = False) -> dict:
     v0, v1 = rng.choice([3, 5, 8, 14]), rng.choice([3, 6, 14])
-    if wide:          # a pool of 33..64 bases (wide keys), the other short or long
+    if wide == "big":  # a pool of 65..200 bases (big keys)
+        v0, v1 = rng.choice([(65, 6), (8, 100), (100, 110), (70, 40), (200, 20)])
+    elif wide:        # a pool of 33..64 bases (wide keys), the other short or long
         v0, v1 = rng.choice([(33, 6), (8, 40), (64, 64), (36, 33)])
     alphabet = rng.choice(["AC", BASES, BASES])
-    p0 = make_pool(rng, rng.choice([1, 4, 30]), v0, alphabet, iupac_rate=rng.choice([0, 0, 0.05]))
-    p1 = make_pool(rng, rng.choice([1, 4, 30]), v1, alphabet, iupac_rate=rng.choice([0, 0, 0.05]))
+    p0 = make_pool(rng, rng.choice([1, 4, 30]), v0, alphabet, iupac_rate=rng.choice([0, 0, 0.05 if v0 <= 64 else 0.01]))
+    p1 = make_pool(rng, rng.choice([1, 4, 30]), v1, alphabet, iupac_rate=rng.choice([0, 0, 0.05 if v1 <= 64 else 0.01]))
     template = make_template(rng, 2, [v0, v1], rng.choice([0, 1, 3]), rng.choice([4, 8, 12]))
     strand = rng.choice([0, 1, 2])
     mm = rng.choice([0, 1, 2, 3])
@@ -136,7 +138,9 @@ def random_combo_case(rng: random.Random, sizes=(1, 30, 200), wide: bool = False
 
 def random_dual_case(rng: random.Random, hazard_free: bool = True, sizes=(1, 30, 150), max_mm: int = 2, wide: bool = False) -> dict:
     l1, l2 = rng.choice([4, 6, 9, 12]), rng.choice([4, 7, 12])
-    if wide:          # a barcode of 33..64 bases on either mate (wide keys for both)
+    if wide == "big":  # a barcode of 65..240 bases on either mate (big keys for both)
+        l1, l2 = rng.choice([(65, 7), (9, 100), (128, 129), (70, 34), (240, 240)])
+    elif wide:        # a barcode of 33..64 bases on either mate (wide keys for both)
         l1, l2 = rng.choice([(33, 7), (9, 40), (64, 64), (35, 34)])
     mm1, mm2 = rng.randint(0, max_mm), rng.randint(0, max_mm)
     # pools whose members are >= 2*cap+1 apart cannot trigger the reference's order-dependent
@@ -206,7 +210,10 @@ def random_dual_single_end_case(rng: random.Random, sizes=(1, 30, 150), wide: bo
         nreg = 2 if diag else rng.choice([1, 2, 2])
     if wide is None:
         wide = rng.random() < 0.4
-    if nreg >= 3:
+    if wide == "big":      # a combined key of 65..256 bases
+        lens = rng.choice({1: [[65], [100], [230]], 2: [[40, 40], [20, 100], [100, 100], [70, 5]], 3: [[40, 40, 40], [30, 5, 90]], 4: [[20, 30, 40, 50]],
+                           5: [[30, 30, 30, 30, 30]]}[nreg])
+    elif nreg >= 3:
         lens = rng.choice({3: [[4, 6, 5], [8, 8, 8], [12, 20, 10], [20, 20, 20], [3, 30, 7]], 4: [[4, 4, 4, 4], [10, 10, 10, 10], [16, 16, 16, 16]],
                            5: [[3, 4, 5, 6, 7], [12, 12, 12, 12, 12]]}[nreg])
     elif nreg == 1:
@@ -243,6 +250,53 @@ def random_dual_single_end_case(rng: random.Random, sizes=(1, 30, 150), wide: bo
             read = rc(read)
         reads.append(read)
     return dict(kind="dual_single_end", template=template, strand=strand, pools=pools, mismatches=mm, use_first=first, reads=reads)
+
+
+def random_big_match_case(rng: random.Random) -> dict:
+    """matchBarcodes with choices of 65..256 bases (big keys)."""
+    vlen = rng.choice([65, 100, 128, 200, 256])
+    pool = make_pool(rng, rng.choice([1, 5, 30]), vlen, "ACGT")
+    seqs = [mutate(rng, rng.choice(pool), 0.01, 0.003, 0.1) for _ in range(30)]
+    subs, rev = rng.choice([0, 1, 2, 3]), rng.random() < 0.5
+    if rev:
+        seqs = [rc(s) if set(s.upper()) <= set("ACGT") else s for s in seqs]
+    return dict(kind="match", sequences=seqs, choices=pool, substitutions=subs, reverse=rev)
+
+
+def large_grid_case(seed: int = 77, n_pool: int = 40000, n_reads: int = 21000) -> dict:
+    """countComboBarcodes with 2 x 40 000 barcodes (1.6e9 possible combinations: beyond any dense histogram), the inputs
+    regenerated from a seed wherever they are needed (tests/golden/kaori_large_grid.json holds a digest of them)."""
+    rng = random.Random(seed)
+
+    def pool(length):
+        seen = set()
+        while len(seen) < n_pool:
+            seen.add(rand_seq(rng, length))
+        out = sorted(seen)
+        rng.shuffle(out)
+        return out
+    pool0, pool1 = pool(12), pool(10)
+    template = "ACGT" + "-" * 12 + "GGTACC" + "-" * 10 + "TTGA"
+    pairs = [(rng.randrange(n_pool), rng.randrange(n_pool)) for _ in range(3000)]
+    reads = []
+    for _ in range(n_reads):
+        a, b = rng.choice(pairs) if rng.random() < 0.7 else (rng.randrange(n_pool), rng.randrange(n_pool))
+        s = fill_template(template, [pool0[a], pool1[b]])
+        s = rand_seq(rng, rng.randrange(0, 20)) + s + rand_seq(rng, rng.randrange(0, 20))
+        if rng.random() < 0.3:
+            s = rc(s)
+        reads.append(mutate(rng, s, 0.01, 0.002, 0.0))
+    return dict(kind="combo", template=template, strand=2, pool0=pool0, pool1=pool1, mismatches=1, use_first=True, reads=reads)
+
+
+def case_digest(case: dict) -> str:
+    import hashlib
+    h = hashlib.sha256()
+    for key in sorted(case):
+        v = case[key]
+        h.update(key.encode())
+        h.update(("\n".join(v) if isinstance(v, list) else repr(v)).encode())
+    return h.hexdigest()
 
 
 def random_random_barcode_case(rng: random.Random, sizes=(1, 30, 150)) -> dict:

@@ -90,16 +90,14 @@ def test_plan_argument_checks_precede_device_errors(sc):
     expect_error(sc, INV, "cannot complement unknown base 'X'", P.single, "ACXT----TGCA", 1, ["AAAA"])
     expect_error(sc, INV, "unknown base 'Z' detected when constructing the trie", P.single, "ACGT----TGCA", 2, ["AAZA"])
     expect_error(sc, INV, "longer than 256 bp", P.single, "A" * 250 + "----" + "C" * 10, 2, ["AAAA"])
-    expect_error(sc, UNS, "longer than 64 bp", P.single, "ACGT" + "-" * 65 + "TGCA", 2, ["A" * 65])
-    expect_error(sc, UNS, "longer than 64 bp", P.combo, "ACGT" + "-" * 65 + "TG--CA", 2, ["A" * 65], ["CC"])
-    expect_error(sc, UNS, "longer than 64 bp", P.dual, "ACGT" + "-" * 65 + "TG", False, 0, ["A" * 65], "AC--GT", False, 0, ["CC"])
+    # (keys of up to 256 bases -- the longest template -- have an index; only matchBarcodes, which has no template, can ask for more)
+    expect_error(sc, UNS, "longer than 256 bp", sc.match_barcodes, ["A" * 257], ["A" * 257], 0, False)
     expect_error(sc, INV, "length of 'barcode_pools' should equal the number of variable regions", P.dual_single_end, "ACGT----TG--CA", 2, [["AAAA"]])
     expect_error(sc, INV, "length of variable region 2 \\(2\\) should be the same as its sequences \\(3\\)", P.dual_single_end, "ACGT----TG--CA", 2, [["AAAA"], ["CCC"]])
     expect_error(sc, INV, "all entries of 'barcode_pools' should have the same length", P.dual_single_end, "ACGT----TG--CA", 2, [["AAAA", "CCCC"], ["CC"]])
     expect_error(sc, INV, "duplicate sequences detected \\(1, 2\\)", P.dual_single_end, "ACGT----TG--CA", 2, [["AAAA", "AAAA"], ["CC", "CC"]])
     nine = "AC" + "--GT" * 9
     expect_error(sc, UNS, "1 to 8 variable regions \\(got 9\\)", P.dual_single_end, nine, 2, [["AA"]] * 9)
-    expect_error(sc, UNS, "64", P.dual_single_end, "AC" + ("-" * 30 + "GT") * 3, 2, [["A" * 30]] * 3)      # combined key > 64 bases
     expect_error(sc, INV, "expected 2 variable regions", P.combo, "ACGT----TGCA", 2, ["AAAA"], ["CC"])
     expect_error(sc, INV, "length of variable region 2 \\(3\\) should be the same as its sequences \\(2\\)", P.combo, "ACGT----TG---CA", 2, ["AAAA"], ["CC"])
     expect_error(sc, INV, "both barcode pools should be of the same length", P.dual, "AC--GT", False, 0, ["AA", "CC"], "AC--GT", False, 0, ["AA"])

@@ -70,7 +70,7 @@ def test_single_random(sc, oracle, gpu, seed):
         done += 1
 
 
-@pytest.mark.parametrize("wide", [False, True], ids=["narrow", "wide"])      # wide: pools of 33..64 bases
+@pytest.mark.parametrize("wide", [False, True, "big"], ids=["narrow", "wide", "big"])      # wide: pools of 33..64 bases
 @pytest.mark.parametrize("seed", range(6))
 def test_combo_random(sc, oracle, gpu, seed, wide):
     from oracle.pyoracle import OracleError
@@ -90,7 +90,7 @@ def test_combo_random(sc, oracle, gpu, seed, wide):
         done += 1
 
 
-@pytest.mark.parametrize("wide", [False, True], ids=["narrow", "wide"])      # wide: barcodes of 33..64 bases on a mate
+@pytest.mark.parametrize("wide", [False, True, "big"], ids=["narrow", "wide", "big"])      # wide: barcodes of 33..64 bases on a mate
 @pytest.mark.parametrize("seed", range(6))
 @pytest.mark.parametrize("hazard_free", [True, False])
 def test_dual_random(sc, oracle, gpu, seed, hazard_free, wide):
@@ -286,6 +286,31 @@ def test_dual_single_end_diagnostics_random(sc, oracle, gpu, seed, tmp_path):
 
 
 @pytest.mark.parametrize("seed", range(3))
+def test_big_keys_random(sc, oracle, gpu, seed):
+    """Barcodes of 65..256 bases (2 x 256-bit planes; the general kernels): countSingleBarcodes, matchBarcodes and
+    countDualBarcodesSingleEnd with combined keys of that size, with and without include.invalid."""
+    rng = random.Random(7300 + seed)
+    for _ in range(10):
+        case = gen.random_single_case(rng, max_vlen=240, min_vlen=65)
+        exp = oracle.count_single(case["reads"], case["template"], case["strand"], case["pool"], case["mismatches"], case["use_first"])
+        got = run_single(sc, case, gpu)
+        assert got[1] == exp[1] and np.array_equal(got[0], exp[0]), (case, exp, got)
+    for _ in range(8):
+        c = gen.random_big_match_case(rng)
+        exp = oracle.match_barcodes(c["sequences"], c["choices"], c["substitutions"], c["reverse"])
+        got = sc.match_barcodes(c["sequences"], c["choices"], c["substitutions"], c["reverse"])
+        assert np.array_equal(got[0], exp[0]) and np.array_equal(got[1], exp[1]), c
+    for i in range(10):
+        case = gen.random_dual_single_end_case(rng, wide="big", nreg=1 + i % 5)
+        exp = oracle.count_dual_single_end(case["reads"], case["template"], case["strand"], case["pools"], case["mismatches"], case["use_first"])
+        seqs, offs = sc.upload_reads(case["reads"], gpu)
+        with sc.Plan.dual_single_end(case["template"], case["strand"], case["pools"], case["mismatches"], case["use_first"]) as plan:
+            plan.count(seqs, offs)
+            got = plan.read()
+        assert got[1] == exp[1] and np.array_equal(got[0], exp[0]), (case, exp, got)
+
+
+@pytest.mark.parametrize("seed", range(3))
 def test_wide_single_and_match_random(sc, oracle, gpu, seed):
     """Barcodes of 33..64 bases through the wide-key kernels (countSingleBarcodes, matchBarcodes)."""
     rng = random.Random(6900 + seed)
@@ -311,7 +336,7 @@ def test_wide_single_and_match_random(sc, oracle, gpu, seed):
         assert np.array_equal(got[0], exp[0]) and np.array_equal(got[1], exp[1]), (pool, seqs, subs, rev)
 
 
-@pytest.mark.parametrize("wide", [False, True], ids=["narrow", "wide"])
+@pytest.mark.parametrize("wide", [False, True, "big"], ids=["narrow", "wide", "big"])
 @pytest.mark.parametrize("seed", range(5))
 def test_paired_combo_random(sc, oracle, gpu, seed, wide):
     """countPairedComboBarcodes: combinations of independently matched mates, barcode1/2-only tallies."""
@@ -331,7 +356,7 @@ def test_paired_combo_random(sc, oracle, gpu, seed, wide):
             assert np.array_equal(np.asarray(exp[key]), np.asarray(got[key])), (key, case, exp, got)
 
 
-@pytest.mark.parametrize("wide", [False, True], ids=["narrow", "wide"])
+@pytest.mark.parametrize("wide", [False, True, "big"], ids=["narrow", "wide", "big"])
 @pytest.mark.parametrize("seed", range(5))
 def test_dual_diagnostics_random(sc, oracle, gpu, seed, wide):
     """include.invalid=TRUE: valid-pair counts, invalid combinations, barcode1/2-only tallies."""

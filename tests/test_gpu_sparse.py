@@ -14,6 +14,8 @@ from tests import gen
 from tests import test_gpu_parity as parity
 from tests import test_gpu_golden as golden
 from tests import test_gpu_ingest as ingest
+from tests.test_gpu_parity import engine                           # noqa: F401  (autouse: staged and general kernels)
+from tests.test_gpu_ingest import plain_scan, bgzf_inflate         # noqa: F401
 
 pytestmark = pytest.mark.gpu
 
@@ -49,23 +51,15 @@ def big_pools(rng, n, length):
 
 
 @pytest.mark.real_limit
-def test_grid_of_1_6e9_cells(sc, oracle, gpu, tmp_path, monkeypatch):
+def test_grid_of_1_6e9_cells(sc, gpu, tmp_path, monkeypatch):
     """countComboBarcodes with 2 x 40 000 barcodes: 1.6e9 cells, 6.4 GB as a dense histogram and beyond the 2^30 cells the
-    dense mode is limited to.  Reads, a plan reused over several batches, the file entry and two devices of one call."""
-    rng = random.Random(77)
-    pool0, pool1 = big_pools(rng, 40000, 12), big_pools(rng, 40000, 10)
-    template = "ACGT" + "-" * 12 + "GGTACC" + "-" * 10 + "TTGA"
-    pairs = [(rng.randrange(40000), rng.randrange(40000)) for _ in range(3000)]
-    reads = []
-    for _ in range(21000):
-        a, b = rng.choice(pairs) if rng.random() < 0.7 else (rng.randrange(40000), rng.randrange(40000))
-        s = gen.fill_template(template, [pool0[a], pool1[b]])
-        s = gen.rand_seq(rng, rng.randrange(0, 20)) + s + gen.rand_seq(rng, rng.randrange(0, 20))
-        if rng.random() < 0.3:
-            s = gen.rc(s)
-        reads.append(gen.mutate(rng, s, 0.01, 0.002, 0.0))
-    exp = oracle.count_combo(reads, template, 2, pool0, pool1, 1, True)
-    assert len(exp[1]) > 3000                                  # (oracle: ~0.6 ms per read against pools of this size)
+    dense mode is limited to -- against the outputs of real kaori (tests/golden/kaori_large_grid.json).  Reads, a plan reused
+    over several batches, the file entry and two devices of one call."""
+    from tests import golden_util as G
+    case, expect = G.large_grid()
+    template, pool0, pool1, reads = case["template"], case["pool0"], case["pool1"], case["reads"]
+    exp = (np.asarray(expect["indices"], dtype=np.int32).reshape(2, -1), np.asarray(expect["freq"], dtype=np.int32), expect["total"])
+    assert len(exp[1]) > 3000
     thirds = [reads[0:5000], reads[5000:14001], reads[14001:]]
     with sc.Plan.combo(template, 2, pool0, pool1, 1, True) as plan:
         for part in thirds:
@@ -74,11 +68,10 @@ def test_grid_of_1_6e9_cells(sc, oracle, gpu, tmp_path, monkeypatch):
         got = plan.read_combo()
         assert got[2] == exp[2] and np.array_equal(got[0], exp[0]) and np.array_equal(got[1], exp[1])
         plan.reset()
-        seqs, offs = sc.upload_reads(thirds[0], gpu)
+        seqs, offs = sc.upload_reads(reads, gpu)
         plan.count(seqs, offs)
         again = plan.read_combo()
-    first = oracle.count_combo(thirds[0], template, 2, pool0, pool1, 1, True)
-    assert again[2] == first[2] and np.array_equal(again[0], first[0]) and np.array_equal(again[1], first[1])
+    assert again[2] == exp[2] and np.array_equal(again[0], exp[0]) and np.array_equal(again[1], exp[1])
     path = str(tmp_path / "big.fastq")
     open(path, "wb").write(gen.fastq_text(reads))
     for devices in (None, "0,0"):                             # (one card twice: two plans of one call, their runs merged)
@@ -112,4 +105,4 @@ def test_invalid_pairs_of_a_large_dual_design(sc, oracle, gpu):
         got = plan.read_diagnostics()
     for key in exp:
         assert np.array_equal(np.asarray(exp[key]), np.asarray(got[key])), key
-    assert len(got["invalid_freq"]) > 1000
+    assert len(got["freq"]) > 1000

@@ -102,3 +102,11 @@ def test_oracle_error_messages(oracle):
     # IUPAC overlap is a duplicate too (MismatchTrie.hpp:119-122)
     with pytest.raises(OracleError, match="duplicate sequences detected \\(1, 2\\)"):
         oracle.count_single(["ACGT"], "AC--GT", 0, ["AN", "AC"], 0, True)
+
+
+def test_oracle_matches_kaori_on_a_grid_of_1_6e9_combinations(oracle):
+    """2 x 40 000 barcodes: the reference sorts and run-length encodes the combinations of any number of barcodes
+    (kaori/utils.hpp:173-198, src/utils.h:14-45)."""
+    case, expect = G.large_grid()
+    got = run_oracle(oracle, case)
+    assert got == expect
