@@ -75,11 +75,17 @@ __global__ __launch_bounds__(INFLATE_BLOCK) void inflate_members_kernel(const ui
 //   1. lane i decodes the literal/length code (and, for a length, the distance code) that WOULD start at bit
 //      `bitpos + i` of the stream: two look-ups in the LDS tables and some vector arithmetic, the same for every lane;
 //      most of these offsets are no code starts and their results are thrown away;
-//   2. the true code starts are the chain 0 -> next(0) -> next(next(0)) ...: one v_readlane per symbol walks it, and on
-//      the way every symbol's place in the text is fixed (v_writelane) -- ~8 scalar-side instructions a symbol;
-//   3. all literals of the batch are stored at once, one byte per lane; the matches follow in order, each copied by
-//      the 64 lanes together (their sources may be the literals just stored, never anything stored later).
-//
+//   2. the true code starts are the chain 0 -> next(0) -> next(next(0)) ...: one v_readlane per symbol walks it (8 scalar
+//      instructions a symbol, one loop exit), and on the way every symbol's place in the text is fixed;
+//   3. all literals of the batch are stored at once, one byte per lane; the matches are only NOTED (place, length,
+//      distance, in LDS) and the next batch is decoded at once: the decoder never needs a match's bytes to go on, and
+//      waiting for each copy's load -- a round trip to HBM per match, three matches a batch -- was 70 % of the
+//      wavefront's time.  When 64 or more are noted (and at block ends) resolve_matches copies them, one match per
+//      lane, in rounds: whatever reads only text that is final goes in this round.
+// The compressed bytes come through a 1 KB ring in LDS, fetched 512 bytes at a time one fetch ahead (InRing): the 64
+// overlapping 8-byte reads of a batch were a round trip to HBM / L2 per batch.
+// Measured (profiles/r3_bgzf_pmc.txt; 16 M reads of the benchmark stream, 256 MB windows): 7.6 ms -> 3.9 ms per window,
+// 66 -> 27 scalar and 35 -> 32 vector instructions per symbol; random-sequence reads 13.0 -> 6.8 ms.
 // Codes longer than the primary tables, an end-of-block or an invalid pattern stop the chain; that one symbol is
 // decoded the old way (scginf::decode_symbol: canonical bit-by-bit decoding) and the batches go on behind it.
 // Block headers (once per ~30 KB of text) are read by the wavefront as a whole, as before.  Accept / reject rules are
@@ -96,7 +102,126 @@ struct WaveTables {                   // 3.3 KB of LDS per wavefront
     uint16_t offs[16];
 };
 
+// What a wavefront keeps next to its tables (2 KB): a ring of the compressed bytes around the read position, so that a
+// batch's 64 overlapping 8-byte reads come from LDS and the stream is fetched from HBM 512 bytes at a time, one fetch
+// ahead of its use; and the matches that have been decoded but not copied yet (see resolve_matches).
+constexpr uint32_t RING_BYTES = 1024, RING_HALF = 512, MATCH_SLOTS = 128;
+struct WaveStage {
+    uint32_t ring[RING_BYTES / 4];
+    uint32_t tok_at[MATCH_SLOTS];      // place in the text | length << 16   (a BGZF member holds <= 64 KiB of text)
+    uint32_t tok_dist[MATCH_SLOTS];
+};
+
 __device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lane); }
+__device__ __forceinline__ uint64_t ballot64(bool p) { return __ballot(p); }
+__device__ __forceinline__ uint32_t rank_below(uint64_t m) {      // set bits of m below this lane
+    return __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u));
+}
+
+// The ring of compressed bytes.  [lo, hi) of the member's payload is in LDS (hi - lo == RING_BYTES, both multiples of
+// RING_HALF); `ahead` is this lane's 8 bytes of [hi, hi + RING_HALF), requested when the half before it was committed.
+struct InRing {
+    const uint8_t* in;
+    uint32_t limit;                    // bytes of `in` that may be read (payload + IN_SLACK)
+    uint32_t lo, hi;
+    uint64_t ahead;
+    __device__ __forceinline__ uint64_t fetch(uint32_t at) const {
+        uint64_t w = 0;
+        if (at + 8u <= limit) __builtin_memcpy(&w, in + at, 8);
+        return w;
+    }
+    __device__ __forceinline__ void put(WaveStage& S, uint32_t at, uint64_t w) const {
+        const uint32_t q = (at >> 2) & (RING_BYTES / 4 - 1);
+        S.ring[q] = static_cast<uint32_t>(w);
+        S.ring[q + 1] = static_cast<uint32_t>(w >> 32);
+    }
+    // Ring around byte `at` (the block's first symbol, or wherever the bitwise decoder left off).
+    __device__ __forceinline__ void reset(WaveStage& S, uint32_t at, uint32_t lane) {
+        lo = at & ~(RING_HALF - 1);
+        hi = lo + RING_BYTES;
+        const uint64_t a = fetch(lo + 8 * lane), b = fetch(lo + RING_HALF + 8 * lane);
+        ahead = fetch(hi + 8 * lane);
+        put(S, lo + 8 * lane, a);
+        put(S, lo + RING_HALF + 8 * lane, b);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    }
+    // Bytes [at, at + 20) are in the ring afterwards (a batch reads that far); the position only moves forward.
+    __device__ __forceinline__ void ensure(WaveStage& S, uint32_t at, uint32_t lane) {
+        if (at + 20u <= hi && at >= lo) return;
+        if (at < lo || at + 20u > hi + RING_HALF) { reset(S, at, lane); return; }
+        put(S, hi + 8 * lane, ahead);                          // replaces the half the position has left behind
+        lo += RING_HALF;
+        hi += RING_HALF;
+        ahead = fetch(hi + 8 * lane);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    }
+    // 64 bits of the stream from bit `b` on (>= 57 of them valid).
+    __device__ __forceinline__ uint64_t bits_at(const WaveStage& S, uint32_t b) const {
+        const uint32_t byte = b >> 3, q = byte >> 2;
+        const uint32_t x0 = S.ring[q & (RING_BYTES / 4 - 1)], x1 = S.ring[(q + 1) & (RING_BYTES / 4 - 1)], x2 = S.ring[(q + 2) & (RING_BYTES / 4 - 1)];
+        const uint32_t sh = (byte & 3u) * 8u + (b & 7u);       // < 32
+        const uint64_t low = (static_cast<uint64_t>(x1) << 32) | x0;
+        return sh ? (low >> sh) | (static_cast<uint64_t>(x2) << (64u - sh)) : low;
+    }
+};
+
+// One match, copied by one lane.  A source at least 8 bytes back is moved in 8-byte words (up to four loads in flight);
+// a closer one is a pattern of period `d`, built once in a register and stored over and over.
+__device__ __forceinline__ void copy_match(uint8_t* out, uint32_t at, uint32_t len, uint32_t d) {
+    uint8_t* dst = out + at;
+    const uint8_t* src = dst - d;
+    uint32_t j = 0;
+    uint64_t w;
+    if (d >= 8) {
+        if (d >= 32) {
+            for (; j + 32 <= len; j += 32) {
+                uint64_t x[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) __builtin_memcpy(&x[k], src + j + 8 * k, 8);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) __builtin_memcpy(dst + j + 8 * k, &x[k], 8);
+            }
+        }
+        for (; j + 8 <= len; j += 8) {
+            __builtin_memcpy(&w, src + j, 8);
+            __builtin_memcpy(dst + j, &w, 8);
+        }
+        if (j < len) __builtin_memcpy(&w, src + j, 8);          // (ends at most where this match's own text begins)
+    } else {
+        __builtin_memcpy(&w, src, 8);                           // the d bytes of the pattern and 8 - d that are not text yet
+        w &= ~0ull >> (64u - 8u * d);
+        for (uint32_t have = d; have < 8; have <<= 1) w |= w << (8u * have);
+        const uint32_t step = d == 3 ? 6u : (d >= 5 ? d : 8u);  // the largest multiple of d within a word
+        for (; j + 8 <= len; j += step) __builtin_memcpy(dst + j, &w, 8);
+    }
+    for (uint32_t k = 0; j + k < len; ++k) dst[j + k] = static_cast<uint8_t>(w >> (8u * k));
+}
+
+// Copies the nm matches of S.tok_* in rounds of up to 64, one match per lane.  A match may go when everything it reads
+// is final: the text in front of the earliest match that has not been copied yet (all literals are in place already,
+// and matches before that one are done).  The earliest pending match always goes (it reads only text in front of
+// itself), so every round retires at least one; FASTQ's typical sources -- the record before, or far back -- retire
+// 30 or so per round, i.e. per memory round trip, where copying them one by one took a round trip each.
+__device__ __forceinline__ void resolve_matches(uint8_t* out, const WaveStage& S, uint32_t nm, uint32_t lane) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (uint32_t g = 0; g < nm; g += INFLATE_BLOCK) {
+        const uint32_t idx = g + lane;
+        const bool have = idx < nm;
+        const uint32_t a = have ? S.tok_at[idx] : 0u, d = have ? S.tok_dist[idx] : 1u;
+        const uint32_t at = a & 0xFFFFu, len = a >> 16;
+        const uint32_t src_end = at - d + (len < d ? len : d);
+        uint64_t pending = ballot64(have);
+        while (pending) {
+            const uint32_t first = static_cast<uint32_t>(__builtin_ctzll(pending));
+            const uint32_t final_to = rdlane(at, first);
+            const bool go = ((pending >> lane) & 1ull) && (src_end <= final_to || lane == first);
+            if (go) copy_match(out, at, len, d);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            pending &= ~ballot64(go);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
+}
 
 // n bytes to out[at ...) from dist bytes back, by all lanes (n <= 258 for a match; any n for a stored block: from == nullptr
 // means "from the text itself").
@@ -110,12 +235,16 @@ __device__ __forceinline__ void wave_copy(uint8_t* out, uint32_t at, const uint8
 }
 
 __device__ __forceinline__ int inflate_member_lanes(const uint8_t* __restrict__ in, uint32_t in_len, uint8_t* out, uint32_t out_len,
-                                                    WaveTables& T, const uint32_t lane) {
+                                                    WaveTables& T, WaveStage& S, const uint32_t lane) {
     using namespace scginf;
     uint8_t* const lens = reinterpret_cast<uint8_t*>(T.lit);             // 320 + 19 code lengths fit the 2 KiB of T.lit
     uint32_t bitpos = 0, op = 0;
     const uint32_t in_bits = in_len * 8u;
     uint32_t last;
+    uint32_t nm = 0;                                                     // matches decoded, not copied yet
+    InRing ring;
+    ring.in = in; ring.limit = in_len + IN_SLACK; ring.lo = ring.hi = 0; ring.ahead = 0;
+    if (out_len > 0x10000u) return INFLATE_BAD_SIZE;                     // (not BGZF; S.tok_at packs places into 16 bits)
     do {
         if (bitpos > in_bits) return INFLATE_BAD_DATA;
         // ---- block header: the wavefront as a whole ----
@@ -136,6 +265,8 @@ __device__ __forceinline__ int inflate_member_lanes(const uint8_t* __restrict__ 
             if (n > out_len - op) return INFLATE_BAD_SIZE;
             const uint32_t from = br.pos - (br.cnt >> 3);                // byte position of the next unread byte
             if (from > in_len || n > in_len - from) return INFLATE_BAD_DATA;
+            resolve_matches(out, S, nm, lane);
+            nm = 0;
             wave_copy(out, op, in + from, n, n ? n : 1u, lane);
             op += n;
             bitpos = (from + n) * 8u;
@@ -192,13 +323,12 @@ __device__ __forceinline__ int inflate_member_lanes(const uint8_t* __restrict__ 
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // the tables, written through one lane's eyes, are read per lane below
 
         // ---- the block's symbols, 64 bit offsets at a time ----
+        ring.reset(S, bitpos >> 3, lane);
         bool block_done = false;
         while (!block_done) {
             if (bitpos > in_bits) return INFLATE_BAD_DATA;
-            const uint32_t b = bitpos + lane;
-            uint64_t w;
-            __builtin_memcpy(&w, in + (b >> 3), 8);                     // (IN_SLACK bytes are readable behind the payload)
-            w >>= (b & 7u);                                             // >= 57 bits
+            ring.ensure(S, bitpos >> 3, lane);
+            const uint64_t w = ring.bits_at(S, bitpos + lane);           // >= 57 bits
             // kind: 0 literal, 1 match, 2 end of block, 3 "not decodable here" (long code / invalid: the chain stops)
             uint32_t kind, adv, outlen = 0, n = 0, dist = 0, sym;
             {
@@ -233,46 +363,52 @@ __device__ __forceinline__ int inflate_member_lanes(const uint8_t* __restrict__ 
                     }
                 }
             }
-            // next position (<= 63 + 36), kind, output length (<= 258) in one register: one v_readlane per symbol
-            const uint32_t info = (lane + adv) | (kind << 8) | (outlen << 10);
+            // The chain of code starts 0 -> next(0) -> ...: one v_readlane per symbol.  A lane's word holds the offset of
+            // the code behind its own (< 64 + 48) and its output length; a lane whose successor cannot be walked over (end
+            // of block, undecodable here) points to 128 + that offset instead, so the walk has ONE exit test -- "left the
+            // 64 offsets" -- and no second branch per symbol.
+            const uint32_t nxt = lane + adv;
+            const uint32_t kind_behind = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(static_cast<int>((nxt & 63u) << 2), static_cast<int>(kind)));
+            const bool halts = nxt < INFLATE_BLOCK && kind_behind >= 2;
+            const uint32_t info = (halts ? 128u + nxt : nxt) | (outlen << 8);
             uint32_t outpos = 0;
-            uint32_t pos = 0, stop = 0;                                  // stop: 0 none, 2 end of block, 3 undecodable here
-            uint64_t literals = 0, matches = 0;
+            uint64_t chain = 0;                                          // the offsets that are code starts
+            uint32_t pos = rdlane(kind, 0) >= 2 ? 128u : 0u;             // (the batch may begin with such a code)
             while (pos < INFLATE_BLOCK) {
                 const uint32_t inf = rdlane(info, pos);
-                const uint32_t k = (inf >> 8) & 3u;
-                if (k >= 2) { stop = k; break; }
-                const uint32_t ol = inf >> 10;
-                if (ol > out_len - op) return INFLATE_BAD_SIZE;
                 outpos = lane == pos ? op : outpos;                      // (v_writelane needs its lane number in m0 on gfx9: two plain vector instructions instead)
-                if (k == 1) {
-                    if (rdlane(dist, pos) > op) return INFLATE_BAD_DATA;        // "invalid distance too far back"
-                    matches |= 1ull << pos;
-                } else {
-                    literals |= 1ull << pos;
-                }
-                op += ol;
+                chain |= 1ull << pos;
+                op += inf >> 8;
                 pos = inf & 0xFFu;
             }
+            uint32_t stop = 0;                                           // 0 none, 2 end of block, 3 undecodable here
+            if (pos >= 128u) {
+                pos -= 128u;
+                stop = rdlane(kind, pos);
+            }
+            if (op > out_len) return INFLATE_BAD_SIZE;                   // (nothing of the batch has been written yet)
+            const bool mine = (chain >> lane) & 1ull;
             // literals: one byte per lane, all at once
-            if ((literals >> lane) & 1ull) out[outpos] = static_cast<uint8_t>(sym);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            // matches in order, each by all lanes
-            // (tried: the loads of up to four matches whose sources lie before the batch issued back to back and stored
-            // together -- one latency for all -- with the kernel held to 64 VGPRs for 8 wavefronts per SIMD: 15 % SLOWER
-            // end to end; the bookkeeping is scalar work, and scalar issue, not latency, is what bounds this kernel:
-            // profiles/r3_bgzf_pmc.txt)
-            while (matches) {
-                const uint32_t m = static_cast<uint32_t>(__builtin_ctzll(matches));
-                matches &= matches - 1;
-                const uint32_t at = rdlane(outpos, m), len = rdlane(n, m), d = rdlane(dist, m);
-                wave_copy(out, at, out + at - d, len, d, lane);
+            if (mine && kind == 0) out[outpos] = static_cast<uint8_t>(sym);
+            // matches: noted, copied later -- the decoder does not need their bytes to go on, so it does not wait for them
+            const bool is_match = mine && kind == 1;
+            const uint64_t matches = ballot64(is_match);
+            if (matches) {
+                if (ballot64(is_match && dist > outpos)) return INFLATE_BAD_DATA;       // "invalid distance too far back"
+                if (is_match) {
+                    const uint32_t slot = nm + rank_below(matches);
+                    S.tok_at[slot] = outpos | (n << 16);
+                    S.tok_dist[slot] = dist;
+                }
+                nm += static_cast<uint32_t>(__builtin_popcountll(matches));
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                if (nm > MATCH_SLOTS - INFLATE_BLOCK / 2) {              // (a batch holds at most 32 matches: two bits each at least)
+                    resolve_matches(out, S, nm, lane);
+                    nm = 0;
+                }
             }
-            if (stop == 0) {
-                bitpos += pos;
-                continue;
-            }
-            bitpos += pos;                                               // the symbol at `pos` was not consumed
+            bitpos += pos;                                               // (stop != 0: the symbol at `pos` was not consumed)
+            if (stop == 0) continue;
             if (stop == 2) {
                 bitpos += rdlane(adv, pos);                              // the end-of-block code itself
                 block_done = true;
@@ -315,23 +451,30 @@ __device__ __forceinline__ int inflate_member_lanes(const uint8_t* __restrict__ 
                 }
                 if (d > op) return INFLATE_BAD_DATA;
                 if (len > out_len - op) return INFLATE_BAD_SIZE;
+                resolve_matches(out, S, nm, lane);                       // (its source may be one of them)
+                nm = 0;
                 wave_copy(out, op, out + op - d, len, d, lane);
                 op += len;
             }
             bitpos = (sr.pos * 8u) - sr.cnt;
         }
     } while (!last);
+    resolve_matches(out, S, nm, lane);
     if (((bitpos + 7u) >> 3) != in_len || op != out_len) return INFLATE_BAD_SIZE;
     return INFLATE_OK;
 }
 
-__global__ __launch_bounds__(INFLATE_BLOCK) void inflate_members_lanes_kernel(const uint8_t* __restrict__ in, const scg::InflateMember* __restrict__ members,
+#ifndef SCG_INFLATE_WAVES
+#define SCG_INFLATE_WAVES 8
+#endif
+__global__ __launch_bounds__(INFLATE_BLOCK, SCG_INFLATE_WAVES) void inflate_members_lanes_kernel(const uint8_t* __restrict__ in, const scg::InflateMember* __restrict__ members,
                                                                               uint32_t n, uint8_t* text, uint32_t* __restrict__ status) {
     __shared__ WaveTables tables;
+    __shared__ WaveStage stage;
     const uint32_t m = blockIdx.x;
     if (m >= n) return;
     const scg::InflateMember M = members[m];
-    const int rc = inflate_member_lanes(in + M.in_off, M.in_len, text + M.out_off, M.out_len, tables, threadIdx.x);
+    const int rc = inflate_member_lanes(in + M.in_off, M.in_len, text + M.out_off, M.out_len, tables, stage, threadIdx.x);
     if (rc != scginf::INFLATE_OK && threadIdx.x == 0) atomicOr(status, scg::INFLATE_STATUS_BAD);
 }
 

@@ -453,6 +453,7 @@ public:
         }
         std::vector<size_t> from;          // payload offsets within the file
         size_t in = 0, out = 0;
+        const size_t window_start = off;
         while (off < f.size) {
             BgzfMember m;
             if (!bgzf_member(f.data, f.size, off, m)) { odd = true; return 0; }
@@ -482,8 +483,16 @@ public:
         const int n = static_cast<int>(members.size());
         const int parts = std::min(n, threads * 4);
         pool.run(parts, [&](int i) {
-            for (int k = static_cast<int>(static_cast<int64_t>(n) * i / parts), e = static_cast<int>(static_cast<int64_t>(n) * (i + 1) / parts); k < e; ++k) {
-                std::memcpy(staging + members[k].in_off, f.data + from[k], members[k].in_len);
+            const int k0 = static_cast<int>(static_cast<int64_t>(n) * i / parts), k1 = static_cast<int>(static_cast<int64_t>(n) * (i + 1) / parts);
+            for (int k = k0; k < k1; ++k) std::memcpy(staging + members[k].in_off, f.data + from[k], members[k].in_len);
+            // these members are not read again: their pages lose their entries here, in parallel, instead of in the final
+            // munmap (20 ms per GB, single-threaded, on the caller's way out)
+            if (k1 > k0) {
+                const size_t a = k0 == 0 ? window_start : from[k0], b = k1 == n ? off : from[k1];
+                const uintptr_t page = 4096;
+                const uintptr_t lo = (reinterpret_cast<uintptr_t>(f.data + a) + page - 1) & ~(page - 1);
+                const uintptr_t hi = reinterpret_cast<uintptr_t>(f.data + b) & ~(page - 1);
+                if (hi > lo) (void)::madvise(reinterpret_cast<void*>(lo), hi - lo, MADV_DONTNEED);
             }
         });
         std::memset(staging + in, 0, slack);
