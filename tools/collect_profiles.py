@@ -22,8 +22,12 @@ root = os.path.join("gpurun_out", f"profiles_{tag}_config{cfg}")
 os.makedirs("profiles", exist_ok=True)
 
 stats = glob.glob(os.path.join(root, "stats", "**", "*kernel_stats.csv"), recursive=True)
+rocprof_avg_ms = None
 if stats:
     shutil.copy(stats[0], f"profiles/{tag}_config{cfg}_kernel_stats.csv")
+    for row in csv.DictReader(open(stats[0])):
+        if kernel_sub in row["Name"]:
+            rocprof_avg_ms = float(row["AverageNs"]) / 1e6          # (warm-up launches included: 23 launches of the bench command)
 if os.path.exists(os.path.join(root, "pmc_summary.txt")):
     shutil.copy(os.path.join(root, "pmc_summary.txt"), f"profiles/{tag}_config{cfg}_pmc_summary.txt")
 bench = open(os.path.join(root, "bench_default.log")).read().strip().splitlines()[-1]
@@ -83,13 +87,21 @@ out["traffic"] = {"read_bytes_per_launch": read_bytes, "write_bytes_per_launch":
 tally = {}
 for name in ("FETCH_SIZE", "WRITE_SIZE"):
     tally.update(counters(0, name, "tally_kernel"))
+tally_bytes_per_read = 0.0
 if tally:
     out["tally_kernel"] = {"FETCH_SIZE_KB": tally.get("FETCH_SIZE"), "WRITE_SIZE_KB": tally.get("WRITE_SIZE")}
+    # the tally kernel's one pass over the 4-byte index stream (16-byte loads like the staging loop: same calibration) and its counter updates
+    fetch = (tally.get("FETCH_SIZE") or 0.0) * 1024
+    tally_bytes_per_read = ((fetch / cal if cal else fetch) + (tally.get("WRITE_SIZE") or 0.0) * 1024) / n
+    out["tally_kernel"]["bytes_per_read"] = tally_bytes_per_read
+out["rocprof_avg_kernel_ms"] = rocprof_avg_ms
 json.dump(out, open(f"profiles/{tag}_config{cfg}_traffic.json", "w"), indent=1)
 tj = "profiles/traffic.json"
 cur = json.load(open(tj)) if os.path.exists(tj) else {}
 if out["traffic"]["bytes_per_read"]:
-    cur[str(cfg)] = {"bytes_per_read": out["traffic"]["bytes_per_read"], "source": f"profiles/{tag}_config{cfg}_traffic.json",
+    cur[str(cfg)] = {"bytes_per_read": out["traffic"]["bytes_per_read"], "tally_bytes_per_read": tally_bytes_per_read,
+                     "rocprof_avg_kernel_ms": rocprof_avg_ms, "rocprof_source": f"profiles/{tag}_config{cfg}_kernel_stats.csv",
+                     "source": f"profiles/{tag}_config{cfg}_traffic.json",
                      "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE corrected with the measured streaming-only calibration"}
     json.dump(cur, open(tj, "w"), indent=1)
 print(json.dumps(out["calibration"], indent=1))

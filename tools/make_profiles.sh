@@ -31,5 +31,6 @@ for P in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_
   echo "sq pass$i rc=$?"
   i=$((i+1))
 done
-python3 $GRAFT_REPO_ROOT/tools/pmc_summary.py $OUT/sq staged > $OUT/pmc_summary.txt 2>&1
+KSUB=staged; [ "$CFG" = "4" ] && KSUB=dual_passes      # (the pair search in two passes: dual_passes_kernel)
+python3 $GRAFT_REPO_ROOT/tools/pmc_summary.py $OUT/sq $KSUB > $OUT/pmc_summary.txt 2>&1
 cd $GRAFT_REPO_ROOT && timeout -k 10 900 python bench.py --config $CFG > $OUT/bench_default.log 2>&1; echo "bench rc=$?"; tail -1 $OUT/bench_default.log | cut -c1-400
