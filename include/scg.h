@@ -28,7 +28,9 @@
  *     size is known in advance, otherwise malloc'd by the library and released with scg_free.
  *   - barcode pools are arrays of NUL-terminated strings (R CHARSXPs are NUL-terminated); the
  *     library enforces "all the same length" itself like format_pointers() (src/utils.cpp:5-23).
- *     Barcodes may be up to 64 bases long on every path (SCG_ERR_UNSUPPORTED beyond; the reference has no limit).
+ *     Barcodes may be as long as the longest template, 256 bases (src/count_single_barcodes.cpp:37-47), on every path:
+ *     up to 32 / 64 / 256 bases in key planes of 32 / 64 / 256 bits.  scg_match_barcodes, which has no template, declines
+ *     longer sequences with SCG_ERR_UNSUPPORTED (the reference's trie has no limit).
  *   - FASTQ input may be plain, BGZF (bgzip) or any other gzip; it is detected by its magic bytes like
  *     byteme::SomeFileReader (inst/include/byteme/SomeFileReader.hpp:31-44).
  *   - strand: 0 = forward, 1 = reverse, 2 = both (src/utils.cpp:33-41).
@@ -129,7 +131,7 @@ int scg_count_dual_barcodes(const char* path1, const char* constant1, int revers
  * one read; pools[r][c] over the regions r spells valid combination c.  Replaces
  * src/count_dual_barcodes_single_end.cpp:53-87, non-diagnostic branch (:27-34, kaori::DualBarcodesSingleEnd).
  * pools: n_regions arrays of n_pools[r] strings; counts_out: n_pools[0] entries.  This engine handles 1 to 8
- * regions with at most 64 bases in total.  diagnostics must be 0 here: the include.invalid=TRUE branch returns
+ * regions (the reference: any number).  diagnostics must be 0 here: the include.invalid=TRUE branch returns
  * more outputs and is scg_count_dual_barcodes_single_end_diagnostics below. */
 int scg_count_dual_barcodes_single_end(const char* path, const char* constant,
                                        const char* const* const* pools, const int32_t* n_pools, int32_t n_regions,

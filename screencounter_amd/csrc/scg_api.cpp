@@ -12,7 +12,7 @@
 #pragma GCC visibility push(default)     // the C ABI is the library's whole export list (csrc/Makefile: -fvisibility=hidden)
 extern "C" {
 
-const char* scg_version(void) { return "scg 0.2.0 (gfx950)"; }
+const char* scg_version(void) { return "scg 0.3.0 (gfx950)"; }
 
 int scg_device_count(void) {
     int n = 0;
