@@ -16,4 +16,4 @@ from .api import (  # noqa: F401
 )
 from .engine import Plan, combo_compact, upload_reads  # noqa: F401
 
-__version__ = "0.2.0"
+__version__ = "0.3.0"

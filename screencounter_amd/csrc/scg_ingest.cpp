@@ -288,9 +288,14 @@ public:
             off[n] = static_cast<uint32_t>(at);
             g.n_records = static_cast<uint32_t>(n);
             g.seq_bytes = static_cast<uint32_t>(at);
-            drop(src + lo, src + end);
         });
         if (bad.load()) { odd = true; return 0; }
+        // Only now may the window's pages go: every thread works out its slice's ends from text that lies in its
+        // neighbours' slices, and a page dropped from an ANONYMOUS mapping (a gzip file inflated whole) reads as zeros
+        // afterwards -- a thread that dropped its slice early made a late neighbour find "no boundary here" and stand
+        // back for records nobody then parsed (found by tools/gpu_ingest_fuzz.py, 1 file in 800; file-backed mappings
+        // fault the same bytes in again and never showed it).
+        pool.run(parts, [&](int i) { drop(src + take * i / parts, src + take * (i + 1) / parts); });
         out.n_segs = parts;
         for (int i = 0; i < parts; ++i) {
             ParsedSegment& g = out.seg[i];

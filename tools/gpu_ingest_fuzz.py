@@ -4,6 +4,7 @@ then something the fast paths must hand back (multi-line records, blank lines, m
 a flipped bit in a BGZF member) -- counted through every path:
   plain file   host record scan | device record scan
   BGZF         members inflated on the device | by the host threads
+  gzip         ordinary members (one or several, any level), decoded by the host threads in chunks | by one stream
 with random window sizes; every path must give what the sequential reference-exact reader gives (SCG_DEVICE_SCAN=0):
 the same counts, or the same error.
 usage: python3 tools/gpu_ingest_fuzz.py [seconds] [first_seed]"""
@@ -23,7 +24,7 @@ from tests import gen  # noqa: E402
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 50_000
 TEMPLATE = "ACGTACGA" + "-" * 12 + "TGCATGCA"
-MODE_VARS = ("SCG_DEVICE_SCAN", "SCG_HOST_SCAN", "SCG_DEVICE_INFLATE", "SCG_WINDOW_KB")
+MODE_VARS = ("SCG_DEVICE_SCAN", "SCG_HOST_SCAN", "SCG_DEVICE_INFLATE", "SCG_WINDOW_KB", "SCG_PGZIP", "SCG_PGZIP_CHUNK_KB")
 
 
 def set_mode(**kw):
@@ -149,26 +150,48 @@ with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") els
             raw = bytearray(open(bg, "rb").read())
             raw[rng.randrange(30, len(raw) - 10)] ^= 1 << rng.randrange(8)
             open(bg, "wb").write(bytes(raw))
+        # the same text as ordinary gzip: one member or a few, any level, now and then a flipped bit
+        import zlib
+        gz = os.path.join(tmp, "f.plain.gz")
+        cuts = sorted(rng.sample(range(len(text) + 1), rng.choice([0, 0, 1, 3]))) if text else []
+        parts = [text[a:b] for a, b in zip([0] + cuts, cuts + [len(text)])]
+        raw = b""
+        for part in parts:
+            c = zlib.compressobj(rng.choice([1, 4, 6, 9]), zlib.DEFLATED, 31)
+            raw += c.compress(part) + c.flush()
+        gzflip = rng.random() < 0.15 and len(raw) > 100
+        if gzflip:
+            raw = bytearray(raw)
+            raw[rng.randrange(12, len(raw) - 8)] ^= 1 << rng.randrange(8)
+        open(gz, "wb").write(bytes(raw))
         set_mode(SCG_DEVICE_SCAN=0)
         want = run(plain, pool)
         want_bg = run(bg, pool) if bitflip else want
+        want_gz = run(gz, pool) if gzflip else want
         kb = rng.choice([None, None, 4, 16, 100, 700])
         modes = [("host_scan", plain, dict(SCG_WINDOW_KB=kb)), ("device_scan", plain, dict(SCG_HOST_SCAN=0, SCG_WINDOW_KB=kb)),
-                 ("device_inflate", bg, dict(SCG_WINDOW_KB=kb)), ("host_inflate", bg, dict(SCG_DEVICE_INFLATE=0, SCG_WINDOW_KB=kb))]
+                 ("device_inflate", bg, dict(SCG_WINDOW_KB=kb)), ("host_inflate", bg, dict(SCG_DEVICE_INFLATE=0, SCG_WINDOW_KB=kb)),
+                 ("gzip_parallel", gz, dict(SCG_PGZIP_CHUNK_KB=rng.choice([4, 16, 64]), SCG_WINDOW_KB=kb)), ("gzip_stream", gz, dict(SCG_PGZIP=0, SCG_WINDOW_KB=kb))]
         for name, path, env in modes:
             set_mode(**env)
             if os.environ.get("FUZZ_VERBOSE"):
                 print(f"seed {seed} flaw {flaw} bitflip {bitflip} mode {name} window_kb {kb} bytes {len(text)}", file=sys.stderr, flush=True)
             got = run(path, pool)
-            exp = want_bg if path == bg else want
+            exp = want_bg if path == bg else (want_gz if path == gz else want)
             if got != exp:
-                print(f"MISMATCH seed {seed} flaw {flaw} bitflip {bitflip} mode {name} window_kb {kb}: got {got[:2]} {got[2][:80] if got[0] == 'error' else ''} "
+                print(f"MISMATCH seed {seed} file {it} flaw {flaw} bitflip {bitflip} gzflip {gzflip} mode {name} env {env} window_kb {kb}: got {got[:2]} {got[2][:80] if got[0] == 'error' else ''} "
                       f"want {exp[:2]} {exp[2][:80] if exp[0] == 'error' else ''}", flush=True)
+                again = [run(path, pool)[:2] for _ in range(3)]              # a race, or state left behind by an earlier call?
+                print(f"  the same call three more times: {again}", flush=True)
+                import shutil
+                keep = os.path.join(ROOT, "gpurun_out", f"fuzz_mismatch_{seed}" + os.path.splitext(path)[1])
+                os.makedirs(os.path.dirname(keep), exist_ok=True)
+                shutil.copy(path, keep)
                 sys.exit(1)
-        key = flaw + ("+bitflip" if bitflip else "") + ":" + want[0]
+        key = flaw + ("+bitflip" if bitflip else "") + ("+gzflip" if gzflip else "") + ":" + want[0]
         tally[key] = tally.get(key, 0) + 1
         if time.time() - last > 10:
             last = time.time()
             print(f"{it} files, {time.time() - t0:.0f} s", flush=True)
 set_mode()
-print(f"ingest fuzz: {it} files x 4 paths, no mismatch; {dict(sorted(tally.items()))}")
+print(f"ingest fuzz: {it} files x 6 paths, no mismatch; {dict(sorted(tally.items()))}")
