@@ -234,9 +234,10 @@ int scg_match_barcodes(const char* const* sequences, int32_t n_sequences,
 void scg_free(void* p);
 
 /* The file-level entry points keep the pinned host windows and HBM scratch of their last run for the next call: at most
- * four window slots per device (counts never depend on it).  A slot of the plain / gzip pipelines is 128 MB of pinned
- * memory + ~290 MB of HBM; a slot of the BGZF pipeline (members inflated on the device) ~145 MB pinned + ~0.6 GB of HBM,
- * so up to ~2.4 GB of HBM and ~0.6 GB of pinned memory per device stay allocated between calls.  The parallel gzip decoder
+ * four window slots per device and size class, eight per device (counts never depend on it).  A slot of the plain / gzip
+ * pipelines is 128 MB of pinned memory + ~290 MB of HBM; a slot of the BGZF pipeline (members inflated on the device)
+ * ~145 MB pinned + ~0.6 GB of HBM, so a process that has read both kinds keeps up to ~3.6 GB of HBM and ~1.1 GB of pinned
+ * memory per device between calls.  The parallel gzip decoder
  * likewise keeps its symbol buffers (up to 40, ~12 MB resident each).  This releases all of them; SCG_BUFFER_CACHE=0
  * disables the cache of window slots altogether. */
 void scg_release_buffers(void);
