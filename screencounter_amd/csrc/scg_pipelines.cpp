@@ -268,6 +268,7 @@ public:
         // which time its copy and scan have normally finished: the host thread does not wait on the link.
         // (Windows scanned by the host need no such wait.)
         const size_t lag = host_scan ? 0 : devices.size() * 2 < slots.size() ? devices.size() * 2 : slots.size() - 1;
+        while (finished + lag < filled) finish_next();              // (the windows start() has taken while there was no plan)
         while (!ended) {
             fill_next();
             if (filled > lag && finished < filled - lag) finish_next();
@@ -496,6 +497,7 @@ public:
     void run(const std::vector<scg_plan*>& plans) {
         for (size_t i = 0; i < slots.size(); ++i) slots[i]->plan = plans[(i % devices.size()) % plans.size()];
         const size_t lag = std::min(2 * devices.size(), slots.size() - 1);
+        while (finished + lag < filled) finish_next();              // (the windows start() has taken while there was no plan)
         while (!ended) {
             fill_next();
             if (filled > lag && finished < filled - lag) finish_next();
