@@ -465,7 +465,7 @@ __device__ __forceinline__ int inflate_member_lanes(const uint8_t* __restrict__ 
 }
 
 #ifndef SCG_INFLATE_WAVES
-#define SCG_INFLATE_WAVES 8
+#define SCG_INFLATE_WAVES 7          /* 72 VGPRs, no spills (8 = 64 VGPRs spills 9 dwords; A/B within noise) */
 #endif
 __global__ __launch_bounds__(INFLATE_BLOCK, SCG_INFLATE_WAVES) void inflate_members_lanes_kernel(const uint8_t* __restrict__ in, const scg::InflateMember* __restrict__ members,
                                                                               uint32_t n, uint8_t* text, uint32_t* __restrict__ status) {
