@@ -70,7 +70,7 @@ __global__ __launch_bounds__(INFLATE_BLOCK) void inflate_members_kernel(const ui
 // ---------------------------------------------------------------------------------------------------------------
 // The lane-parallel decoder (default).  One wavefront per member as before, but the symbols of a block are no longer
 // decoded one after the other by the wavefront as a whole -- 60 scalar instructions a symbol, and a CU issues one
-// scalar instruction per cycle for all its wavefronts -- but 64 bit offsets at a time:
+// scalar instruction per cycle for all its wavefronts -- but 128 bit offsets at a time, two per lane:
 //
 //   1. lane i decodes the literal/length code (and, for a length, the distance code) that WOULD start at bit
 //      `bitpos + i` of the stream: two look-ups in the LDS tables and some vector arithmetic, the same for every lane;
@@ -84,8 +84,9 @@ __global__ __launch_bounds__(INFLATE_BLOCK) void inflate_members_kernel(const ui
 //      lane, in rounds: whatever reads only text that is final goes in this round.
 // The compressed bytes come through a 1 KB ring in LDS, fetched 512 bytes at a time one fetch ahead (InRing): the 64
 // overlapping 8-byte reads of a batch were a round trip to HBM / L2 per batch.
-// Measured (profiles/r3_bgzf_pmc.txt; 16 M reads of the benchmark stream, 256 MB windows): 7.6 ms -> 3.9 ms per window,
-// 66 -> 27 scalar and 35 -> 32 vector instructions per symbol; random-sequence reads 13.0 -> 6.8 ms.
+// Measured (profiles/r3_bgzf_pmc.txt; 16 M reads of the benchmark stream, 256 MB windows): 7.6 ms -> 3.7 ms per window,
+// 66 -> 27 scalar and 35 -> 33 vector instructions per symbol; random-sequence reads 13.0 -> 6.7 ms.  (64 offsets a
+// batch: 3.9 / 6.8 ms; the per-symbol work -- one chain step, its share of 14 offsets' decoding -- is what is left.)
 // Codes longer than the primary tables, an end-of-block or an invalid pattern stop the chain; that one symbol is
 // decoded the old way (scginf::decode_symbol: canonical bit-by-bit decoding) and the batches go on behind it.
 // Block headers (once per ~30 KB of text) are read by the wavefront as a whole, as before.  Accept / reject rules are
@@ -145,10 +146,10 @@ struct InRing {
         put(S, lo + RING_HALF + 8 * lane, b);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     }
-    // Bytes [at, at + 20) are in the ring afterwards (a batch reads that far); the position only moves forward.
+    // Bytes [at, at + 28) are in the ring afterwards (a batch of 128 bit offsets reads that far); the position only moves forward.
     __device__ __forceinline__ void ensure(WaveStage& S, uint32_t at, uint32_t lane) {
-        if (at + 20u <= hi && at >= lo) return;
-        if (at < lo || at + 20u > hi + RING_HALF) { reset(S, at, lane); return; }
+        if (at + 28u <= hi && at >= lo) return;
+        if (at < lo || at + 28u > hi + RING_HALF) { reset(S, at, lane); return; }
         put(S, hi + 8 * lane, ahead);                          // replaces the half the position has left behind
         lo += RING_HALF;
         hi += RING_HALF;
@@ -232,6 +233,47 @@ __device__ __forceinline__ void wave_copy(uint8_t* out, uint32_t at, const uint8
         out[at + j] = src[k];
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+}
+
+// What the code starting at the low end of `w` would be (>= 57 valid bits), were it a code start.
+// kind: 0 literal, 1 match, 2 end of block, 3 "not decodable here" (long code / invalid: the chain stops)
+struct LaneCode {
+    uint32_t kind, adv, outlen, n, dist, sym;
+};
+__device__ __forceinline__ LaneCode decode_here(const WaveTables& T, uint64_t w) {
+    LaneCode c;
+    c.outlen = 0; c.n = 0; c.dist = 0;
+    const uint32_t e = T.lit[static_cast<uint32_t>(w) & ((1u << LANES_LIT_BITS) - 1u)];
+    const uint32_t l = e >> 12;
+    c.sym = e & 0xFFFu;
+    c.adv = l;
+    if (e == 0) c.kind = 3;
+    else if (c.sym < 256) { c.kind = 0; c.outlen = 1; }
+    else if (c.sym == 256) c.kind = 2;
+    else if (c.sym > 285) c.kind = 3;
+    else {
+        const uint32_t t = c.sym - 257;
+        uint32_t eb, base;
+        if (t < 8) { eb = 0; base = t + 3; }
+        else if (t == 28) { eb = 0; base = 258; }
+        else { eb = (t - 4) >> 2; base = ((4u + (t & 3u)) << eb) + 3u; }
+        uint64_t w2 = w >> l;
+        c.n = base + (static_cast<uint32_t>(w2) & ((1u << eb) - 1u));
+        w2 >>= eb;
+        const uint32_t de = T.dtab[static_cast<uint32_t>(w2) & ((1u << LANES_DIST_BITS) - 1u)];
+        const uint32_t dl = de >> 12, ds = de & 0xFFFu;
+        if (de == 0 || ds >= 30) c.kind = 3;
+        else {
+            const uint32_t deb = ds < 4 ? 0u : (ds >> 1) - 1u;
+            const uint32_t dbase = ds < 4 ? ds + 1u : ((2u + (ds & 1u)) << deb) + 1u;
+            w2 >>= dl;
+            c.dist = dbase + (static_cast<uint32_t>(w2) & ((1u << deb) - 1u));
+            c.adv = l + eb + dl + deb;
+            c.outlen = c.n;
+            c.kind = 1;
+        }
+    }
+    return c;
 }
 
 __device__ __forceinline__ int inflate_member_lanes(const uint8_t* __restrict__ in, uint32_t in_len, uint8_t* out, uint32_t out_len,
@@ -328,81 +370,71 @@ __device__ __forceinline__ int inflate_member_lanes(const uint8_t* __restrict__ 
         while (!block_done) {
             if (bitpos > in_bits) return INFLATE_BAD_DATA;
             ring.ensure(S, bitpos >> 3, lane);
-            const uint64_t w = ring.bits_at(S, bitpos + lane);           // >= 57 bits
-            // kind: 0 literal, 1 match, 2 end of block, 3 "not decodable here" (long code / invalid: the chain stops)
-            uint32_t kind, adv, outlen = 0, n = 0, dist = 0, sym;
-            {
-                const uint32_t e = T.lit[static_cast<uint32_t>(w) & ((1u << LANES_LIT_BITS) - 1u)];
-                const uint32_t l = e >> 12;
-                sym = e & 0xFFFu;
-                adv = l;
-                if (e == 0) kind = 3;
-                else if (sym < 256) { kind = 0; outlen = 1; }
-                else if (sym == 256) kind = 2;
-                else if (sym > 285) kind = 3;
-                else {
-                    const uint32_t t = sym - 257;
-                    uint32_t eb, base;
-                    if (t < 8) { eb = 0; base = t + 3; }
-                    else if (t == 28) { eb = 0; base = 258; }
-                    else { eb = (t - 4) >> 2; base = ((4u + (t & 3u)) << eb) + 3u; }
-                    uint64_t w2 = w >> l;
-                    n = base + (static_cast<uint32_t>(w2) & ((1u << eb) - 1u));
-                    w2 >>= eb;
-                    const uint32_t de = T.dtab[static_cast<uint32_t>(w2) & ((1u << LANES_DIST_BITS) - 1u)];
-                    const uint32_t dl = de >> 12, ds = de & 0xFFFu;
-                    if (de == 0 || ds >= 30) kind = 3;
-                    else {
-                        const uint32_t deb = ds < 4 ? 0u : (ds >> 1) - 1u;
-                        const uint32_t dbase = ds < 4 ? ds + 1u : ((2u + (ds & 1u)) << deb) + 1u;
-                        w2 >>= dl;
-                        dist = dbase + (static_cast<uint32_t>(w2) & ((1u << deb) - 1u));
-                        adv = l + eb + dl + deb;
-                        outlen = n;
-                        kind = 1;
-                    }
-                }
-            }
+            // 128 bit offsets a batch, two per lane (a batch of 64 holds ~4.5 symbols of FASTQ: the chain walk, the LDS
+            // look-ups' latency and the batch's fixed work are shared by twice as many this way)
+            const LaneCode A = decode_here(T, ring.bits_at(S, bitpos + lane));
+            const LaneCode B = decode_here(T, ring.bits_at(S, bitpos + INFLATE_BLOCK + lane));
             // The chain of code starts 0 -> next(0) -> ...: one v_readlane per symbol.  A lane's word holds the offset of
-            // the code behind its own (< 64 + 48) and its output length; a lane whose successor cannot be walked over (end
-            // of block, undecodable here) points to 128 + that offset instead, so the walk has ONE exit test -- "left the
-            // 64 offsets" -- and no second branch per symbol.
-            const uint32_t nxt = lane + adv;
-            const uint32_t kind_behind = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(static_cast<int>((nxt & 63u) << 2), static_cast<int>(kind)));
-            const bool halts = nxt < INFLATE_BLOCK && kind_behind >= 2;
-            const uint32_t info = (halts ? 128u + nxt : nxt) | (outlen << 8);
-            uint32_t outpos = 0;
-            uint64_t chain = 0;                                          // the offsets that are code starts
-            uint32_t pos = rdlane(kind, 0) >= 2 ? 128u : 0u;             // (the batch may begin with such a code)
+            // the code behind its own (< 128 + 48) and its output length; a lane whose successor cannot be walked over (end
+            // of block, undecodable here) points to 256 + that offset instead, so the walk has ONE exit test per half --
+            // "left these 64 offsets" -- and no second branch per symbol.
+            const uint32_t nxtA = lane + A.adv, nxtB = INFLATE_BLOCK + lane + B.adv;
+            const uint32_t behindA_a = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(static_cast<int>((nxtA & 63u) << 2), static_cast<int>(A.kind)));
+            const uint32_t behindA_b = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(static_cast<int>((nxtA & 63u) << 2), static_cast<int>(B.kind)));
+            const uint32_t behindB_b = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(static_cast<int>((nxtB & 63u) << 2), static_cast<int>(B.kind)));
+            const bool haltsA = (nxtA < INFLATE_BLOCK ? behindA_a : behindA_b) >= 2;          // (nxtA < 128 always)
+            const bool haltsB = nxtB < 2 * INFLATE_BLOCK && behindB_b >= 2;
+            const uint32_t infoA = (haltsA ? 256u + nxtA : nxtA) | (A.outlen << 16);
+            const uint32_t infoB = (haltsB ? 256u + nxtB : nxtB) | (B.outlen << 16);
+            uint32_t outposA = 0, outposB = 0;
+            uint64_t chainA = 0, chainB = 0;                             // the offsets that are code starts
+            uint32_t pos = rdlane(A.kind, 0) >= 2 ? 256u : 0u;           // (the batch may begin with such a code)
             while (pos < INFLATE_BLOCK) {
-                const uint32_t inf = rdlane(info, pos);
-                outpos = lane == pos ? op : outpos;                      // (v_writelane needs its lane number in m0 on gfx9: two plain vector instructions instead)
-                chain |= 1ull << pos;
-                op += inf >> 8;
-                pos = inf & 0xFFu;
+                const uint32_t inf = rdlane(infoA, pos);
+                outposA = lane == pos ? op : outposA;                    // (v_writelane needs its lane number in m0 on gfx9: two plain vector instructions instead)
+                chainA |= 1ull << pos;
+                op += inf >> 16;
+                pos = inf & 0xFFFFu;
+            }
+            while (pos < 2 * INFLATE_BLOCK) {
+                const uint32_t at = pos - INFLATE_BLOCK;
+                const uint32_t inf = rdlane(infoB, at);
+                outposB = lane == at ? op : outposB;
+                chainB |= 1ull << at;
+                op += inf >> 16;
+                pos = inf & 0xFFFFu;
             }
             uint32_t stop = 0;                                           // 0 none, 2 end of block, 3 undecodable here
-            if (pos >= 128u) {
-                pos -= 128u;
-                stop = rdlane(kind, pos);
+            uint32_t stop_adv = 0;
+            if (pos >= 256u) {
+                pos -= 256u;
+                stop = pos < INFLATE_BLOCK ? rdlane(A.kind, pos) : rdlane(B.kind, pos - INFLATE_BLOCK);
+                stop_adv = pos < INFLATE_BLOCK ? rdlane(A.adv, pos) : rdlane(B.adv, pos - INFLATE_BLOCK);
             }
             if (op > out_len) return INFLATE_BAD_SIZE;                   // (nothing of the batch has been written yet)
-            const bool mine = (chain >> lane) & 1ull;
-            // literals: one byte per lane, all at once
-            if (mine && kind == 0) out[outpos] = static_cast<uint8_t>(sym);
+            const bool mineA = (chainA >> lane) & 1ull, mineB = (chainB >> lane) & 1ull;
+            // literals: one byte per lane and half, all at once
+            if (mineA && A.kind == 0) out[outposA] = static_cast<uint8_t>(A.sym);
+            if (mineB && B.kind == 0) out[outposB] = static_cast<uint8_t>(B.sym);
             // matches: noted, copied later -- the decoder does not need their bytes to go on, so it does not wait for them
-            const bool is_match = mine && kind == 1;
-            const uint64_t matches = ballot64(is_match);
-            if (matches) {
-                if (ballot64(is_match && dist > outpos)) return INFLATE_BAD_DATA;       // "invalid distance too far back"
-                if (is_match) {
-                    const uint32_t slot = nm + rank_below(matches);
-                    S.tok_at[slot] = outpos | (n << 16);
-                    S.tok_dist[slot] = dist;
+            const bool matchA = mineA && A.kind == 1, matchB = mineB && B.kind == 1;
+            const uint64_t matchesA = ballot64(matchA), matchesB = ballot64(matchB);
+            if (matchesA | matchesB) {
+                if (ballot64((matchA && A.dist > outposA) || (matchB && B.dist > outposB))) return INFLATE_BAD_DATA;       // "invalid distance too far back"
+                const uint32_t nA = static_cast<uint32_t>(__builtin_popcountll(matchesA));
+                if (matchA) {
+                    const uint32_t slot = nm + rank_below(matchesA);
+                    S.tok_at[slot] = outposA | (A.n << 16);
+                    S.tok_dist[slot] = A.dist;
                 }
-                nm += static_cast<uint32_t>(__builtin_popcountll(matches));
+                if (matchB) {                                            // (behind the first half's: the list stays in text order)
+                    const uint32_t slot = nm + nA + rank_below(matchesB);
+                    S.tok_at[slot] = outposB | (B.n << 16);
+                    S.tok_dist[slot] = B.dist;
+                }
+                nm += nA + static_cast<uint32_t>(__builtin_popcountll(matchesB));
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                if (nm > MATCH_SLOTS - INFLATE_BLOCK / 2) {              // (a batch holds at most 32 matches: two bits each at least)
+                if (nm > MATCH_SLOTS - INFLATE_BLOCK) {                  // (a batch holds at most 64 matches: two bits each at least)
                     resolve_matches(out, S, nm, lane);
                     nm = 0;
                 }
@@ -410,7 +442,7 @@ __device__ __forceinline__ int inflate_member_lanes(const uint8_t* __restrict__ 
             bitpos += pos;                                               // (stop != 0: the symbol at `pos` was not consumed)
             if (stop == 0) continue;
             if (stop == 2) {
-                bitpos += rdlane(adv, pos);                              // the end-of-block code itself
+                bitpos += stop_adv;                                      // the end-of-block code itself
                 block_done = true;
                 continue;
             }
