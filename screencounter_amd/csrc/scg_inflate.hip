@@ -241,38 +241,34 @@ struct LaneCode {
     uint32_t kind, adv, outlen, n, dist, sym;
 };
 __device__ __forceinline__ LaneCode decode_here(const WaveTables& T, uint64_t w) {
+    // Straight-line: every lane goes through the length and the distance arithmetic, whatever its code is, and the
+    // results are selected at the end.  As nested branches this cost 13 exec-mask save / restore pairs and 40 register
+    // moves per 64 offsets -- scalar instructions the whole wavefront waits for, most of them for offsets that are no code
+    // starts anyway.
     LaneCode c;
-    c.outlen = 0; c.n = 0; c.dist = 0;
     const uint32_t e = T.lit[static_cast<uint32_t>(w) & ((1u << LANES_LIT_BITS) - 1u)];
     const uint32_t l = e >> 12;
     c.sym = e & 0xFFFu;
-    c.adv = l;
-    if (e == 0) c.kind = 3;
-    else if (c.sym < 256) { c.kind = 0; c.outlen = 1; }
-    else if (c.sym == 256) c.kind = 2;
-    else if (c.sym > 285) c.kind = 3;
-    else {
-        const uint32_t t = c.sym - 257;
-        uint32_t eb, base;
-        if (t < 8) { eb = 0; base = t + 3; }
-        else if (t == 28) { eb = 0; base = 258; }
-        else { eb = (t - 4) >> 2; base = ((4u + (t & 3u)) << eb) + 3u; }
-        uint64_t w2 = w >> l;
-        c.n = base + (static_cast<uint32_t>(w2) & ((1u << eb) - 1u));
-        w2 >>= eb;
-        const uint32_t de = T.dtab[static_cast<uint32_t>(w2) & ((1u << LANES_DIST_BITS) - 1u)];
-        const uint32_t dl = de >> 12, ds = de & 0xFFFu;
-        if (de == 0 || ds >= 30) c.kind = 3;
-        else {
-            const uint32_t deb = ds < 4 ? 0u : (ds >> 1) - 1u;
-            const uint32_t dbase = ds < 4 ? ds + 1u : ((2u + (ds & 1u)) << deb) + 1u;
-            w2 >>= dl;
-            c.dist = dbase + (static_cast<uint32_t>(w2) & ((1u << deb) - 1u));
-            c.adv = l + eb + dl + deb;
-            c.outlen = c.n;
-            c.kind = 1;
-        }
-    }
+    const uint32_t t0 = c.sym - 257u;                                   // (wraps for literals: clamped, and not used then)
+    const uint32_t t = t0 < 28u ? t0 : 28u;
+    const bool plain = t < 8u || t == 28u;
+    const uint32_t eb = plain ? 0u : (t - 4u) >> 2;
+    const uint32_t base = t < 8u ? t + 3u : (t == 28u ? 258u : ((4u + (t & 3u)) << eb) + 3u);
+    uint64_t w2 = w >> l;
+    c.n = base + (static_cast<uint32_t>(w2) & ((1u << eb) - 1u));
+    w2 >>= eb;
+    const uint32_t de = T.dtab[static_cast<uint32_t>(w2) & ((1u << LANES_DIST_BITS) - 1u)];
+    const uint32_t dl = de >> 12, ds0 = de & 0xFFFu;
+    const uint32_t ds = ds0 < 29u ? ds0 : 29u;
+    const uint32_t deb = ds < 4u ? 0u : (ds >> 1) - 1u;
+    const uint32_t dbase = ds < 4u ? ds + 1u : ((2u + (ds & 1u)) << deb) + 1u;
+    w2 >>= dl;
+    c.dist = dbase + (static_cast<uint32_t>(w2) & ((1u << deb) - 1u));
+    const bool is_length = c.sym > 256u && c.sym <= 285u;
+    const bool is_match = is_length && de != 0u && ds0 < 30u;
+    c.kind = e == 0u ? 3u : (c.sym < 256u ? 0u : (c.sym == 256u ? 2u : (is_match ? 1u : 3u)));
+    c.adv = c.kind == 1u ? l + eb + dl + deb : l;
+    c.outlen = c.kind == 0u ? 1u : (c.kind == 1u ? c.n : 0u);
     return c;
 }
 
