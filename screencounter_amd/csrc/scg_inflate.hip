@@ -84,15 +84,15 @@ __global__ __launch_bounds__(INFLATE_BLOCK) void inflate_members_kernel(const ui
 //      lane, in rounds: whatever reads only text that is final goes in this round.
 // The compressed bytes come through a 1 KB ring in LDS, fetched 512 bytes at a time one fetch ahead (InRing): the 64
 // overlapping 8-byte reads of a batch were a round trip to HBM / L2 per batch.
-// Measured (profiles/r3_bgzf_pmc.txt; 16 M reads of the benchmark stream, 256 MB windows): 7.6 ms -> 3.7 ms per window,
-// 66 -> 27 scalar and 35 -> 33 vector instructions per symbol; random-sequence reads 13.0 -> 6.7 ms.  (64 offsets a
+// Measured (profiles/r3_bgzf_pmc.txt; 16 M reads of the benchmark stream, 256 MB windows): 7.6 ms -> 3.5 ms per window,
+// 66 -> 24 scalar and 35 -> 31 vector instructions per symbol; random-sequence reads 13.0 -> 6.4 ms.  (64 offsets a
 // batch: 3.9 / 6.8 ms; the per-symbol work -- one chain step, its share of 14 offsets' decoding -- is what is left.)
 // Codes longer than the primary tables, an end-of-block or an invalid pattern stop the chain; that one symbol is
 // decoded the old way (scginf::decode_symbol: canonical bit-by-bit decoding) and the batches go on behind it.
 // Block headers (once per ~30 KB of text) are read by the wavefront as a whole, as before.  Accept / reject rules are
 // scg_inflate.h's; what this decoder gets wrong on a corrupt stream the CRC kernel catches, and zlib judges the file.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int LANES_LIT_BITS = 10, LANES_DIST_BITS = 8;
+constexpr int LANES_LIT_BITS = 10, LANES_DIST_BITS = 8;      // (11 / 9 bits: no gain -- long codes are rare in FASTQ)
 struct WaveTables {                   // 3.3 KB of LDS per wavefront
     uint16_t lit[1 << LANES_LIT_BITS];
     uint16_t dtab[1 << LANES_DIST_BITS];
@@ -162,7 +162,7 @@ struct InRing {
         const uint32_t x0 = S.ring[q & (RING_BYTES / 4 - 1)], x1 = S.ring[(q + 1) & (RING_BYTES / 4 - 1)], x2 = S.ring[(q + 2) & (RING_BYTES / 4 - 1)];
         const uint32_t sh = (byte & 3u) * 8u + (b & 7u);       // < 32
         const uint64_t low = (static_cast<uint64_t>(x1) << 32) | x0;
-        return sh ? (low >> sh) | (static_cast<uint64_t>(x2) << (64u - sh)) : low;
+        return (low >> sh) | ((static_cast<uint64_t>(x2) << 1) << (63u - sh));     // (no branch for sh == 0)
     }
 };
 
