@@ -109,8 +109,8 @@ struct WaveTables {                   // 3.3 KB of LDS per wavefront
 constexpr uint32_t RING_BYTES = 1024, RING_HALF = 512, MATCH_SLOTS = 128;
 struct WaveStage {
     uint32_t ring[RING_BYTES / 4];
-    uint32_t tok_at[MATCH_SLOTS];      // place in the text | length << 16   (a BGZF member holds <= 64 KiB of text)
-    uint32_t tok_dist[MATCH_SLOTS];
+    uint32_t tok_at[MATCH_SLOTS];      // place in the text
+    uint32_t tok_dist[MATCH_SLOTS];    // distance | length << 16
 };
 
 __device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lane); }
@@ -166,6 +166,11 @@ struct InRing {
     }
 };
 
+// The decoder writes bytes (BGZF members: the text itself) or 16-bit symbols (chunks of an ordinary gzip stream, decoded
+// without the 32 KiB of text in front of them: a symbol is a byte, or MARKER + k for "byte k of the window I do not have";
+// scg_pgzip.h).  In symbol mode a match may reach in front of the chunk's first symbol: those positions read as markers.
+constexpr uint32_t MARKER = 0x8000u, MARKER_WINDOW = 32768u;
+
 // One match, copied by one lane.  A source at least 8 bytes back is moved in 8-byte words (up to four loads in flight);
 // a closer one is a pattern of period `d`, built once in a register and stored over and over.
 __device__ __forceinline__ void copy_match(uint8_t* out, uint32_t at, uint32_t len, uint32_t d) {
@@ -197,25 +202,64 @@ __device__ __forceinline__ void copy_match(uint8_t* out, uint32_t at, uint32_t l
     }
     for (uint32_t k = 0; j + k < len; ++k) dst[j + k] = static_cast<uint8_t>(w >> (8u * k));
 }
+// The same in symbols (four to a word); a match that begins in front of the chunk goes symbol by symbol.
+__device__ __forceinline__ void copy_match(uint16_t* out, uint32_t at, uint32_t len, uint32_t d) {
+    uint16_t* dst = out + at;
+    if (at < d) {
+        for (uint32_t j = 0; j < len; ++j) {
+            const int32_t from = static_cast<int32_t>(at + j) - static_cast<int32_t>(d);
+            dst[j] = from < 0 ? static_cast<uint16_t>(MARKER + MARKER_WINDOW + from) : out[from];
+        }
+        return;
+    }
+    const uint16_t* src = dst - d;
+    uint32_t j = 0;
+    uint64_t w;
+    if (d >= 4) {
+        if (d >= 16) {
+            for (; j + 16 <= len; j += 16) {
+                uint64_t x[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) __builtin_memcpy(&x[k], src + j + 4 * k, 8);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) __builtin_memcpy(dst + j + 4 * k, &x[k], 8);
+            }
+        }
+        for (; j + 4 <= len; j += 4) {
+            __builtin_memcpy(&w, src + j, 8);
+            __builtin_memcpy(dst + j, &w, 8);
+        }
+        if (j < len) __builtin_memcpy(&w, src + j, 8);
+    } else {
+        __builtin_memcpy(&w, src, 8);
+        w &= ~0ull >> (64u - 16u * d);
+        for (uint32_t have = d; have < 4; have <<= 1) w |= w << (16u * have);
+        const uint32_t step = d == 3 ? 3u : 4u;
+        for (; j + 4 <= len; j += step) __builtin_memcpy(dst + j, &w, 8);
+    }
+    for (uint32_t k = 0; j + k < len; ++k) dst[j + k] = static_cast<uint16_t>(w >> (16u * k));
+}
 
 // Copies the nm matches of S.tok_* in rounds of up to 64, one match per lane.  A match may go when everything it reads
 // is final: the text in front of the earliest match that has not been copied yet (all literals are in place already,
 // and matches before that one are done).  The earliest pending match always goes (it reads only text in front of
 // itself), so every round retires at least one; FASTQ's typical sources -- the record before, or far back -- retire
 // 30 or so per round, i.e. per memory round trip, where copying them one by one took a round trip each.
-__device__ __forceinline__ void resolve_matches(uint8_t* out, const WaveStage& S, uint32_t nm, uint32_t lane) {
+template<class OutT>
+__device__ __forceinline__ void resolve_matches(OutT* out, const WaveStage& S, uint32_t nm, uint32_t lane) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     for (uint32_t g = 0; g < nm; g += INFLATE_BLOCK) {
         const uint32_t idx = g + lane;
         const bool have = idx < nm;
-        const uint32_t a = have ? S.tok_at[idx] : 0u, d = have ? S.tok_dist[idx] : 1u;
-        const uint32_t at = a & 0xFFFFu, len = a >> 16;
-        const uint32_t src_end = at - d + (len < d ? len : d);
+        const uint32_t at = have ? S.tok_at[idx] : 0u, ld = have ? S.tok_dist[idx] : 1u;
+        const uint32_t d = ld & 0xFFFFu, len = ld >> 16;
+        // (in symbol mode a source may begin in front of the chunk: what lies there is final by definition)
+        const int32_t src_end = static_cast<int32_t>(at) - static_cast<int32_t>(d) + static_cast<int32_t>(len < d ? len : d);
         uint64_t pending = ballot64(have);
         while (pending) {
             const uint32_t first = static_cast<uint32_t>(__builtin_ctzll(pending));
             const uint32_t final_to = rdlane(at, first);
-            const bool go = ((pending >> lane) & 1ull) && (src_end <= final_to || lane == first);
+            const bool go = ((pending >> lane) & 1ull) && (src_end <= static_cast<int32_t>(final_to) || lane == first);
             if (go) copy_match(out, at, len, d);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             pending &= ~ballot64(go);
@@ -224,14 +268,21 @@ __device__ __forceinline__ void resolve_matches(uint8_t* out, const WaveStage& S
     }
 }
 
-// n bytes to out[at ...) from dist bytes back, by all lanes (n <= 258 for a match; any n for a stored block: from == nullptr
-// means "from the text itself").
-__device__ __forceinline__ void wave_copy(uint8_t* out, uint32_t at, const uint8_t* src, uint32_t n, uint32_t dist, uint32_t lane) {
+// n elements to out[at ...) from dist back, by all lanes (a match met by the bitwise decoder).
+template<class OutT>
+__device__ __forceinline__ void wave_copy(OutT* out, uint32_t at, uint32_t n, uint32_t dist, uint32_t lane) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     for (uint32_t j = lane; j < n; j += INFLATE_BLOCK) {
         const uint32_t k = dist >= n ? j : (dist == 1 ? 0u : j % dist);
-        out[at + j] = src[k];
+        const int32_t from = static_cast<int32_t>(at + k) - static_cast<int32_t>(dist);
+        out[at + j] = (sizeof(OutT) == 2 && from < 0) ? static_cast<OutT>(MARKER + MARKER_WINDOW + from) : out[from];
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+}
+// n bytes of a stored block, by all lanes.
+template<class OutT>
+__device__ __forceinline__ void wave_store(OutT* out, uint32_t at, const uint8_t* src, uint32_t n, uint32_t lane) {
+    for (uint32_t j = lane; j < n; j += INFLATE_BLOCK) out[at + j] = src[j];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 }
 
@@ -272,17 +323,69 @@ __device__ __forceinline__ LaneCode decode_here(const WaveTables& T, uint64_t w)
     return c;
 }
 
-__device__ __forceinline__ int inflate_member_lanes(const uint8_t* __restrict__ in, uint32_t in_len, uint8_t* out, uint32_t out_len,
-                                                    WaveTables& T, WaveStage& S, const uint32_t lane) {
+// The code lengths of a dynamic-Huffman block header (br stands behind BFINAL and BTYPE) and the block's two tables.
+// False for anything zlib would reject (too many codes, an over-subscribed or incomplete set, no end-of-block code).
+__device__ __forceinline__ bool read_dynamic_tables(scginf::BitReader& br, WaveTables& T, uint8_t* lens) {
     using namespace scginf;
+    const int nlen = static_cast<int>(br.bits(5)) + 257;
+    const int ndist = static_cast<int>(br.bits(5)) + 1;
+    const int ncode = static_cast<int>(br.bits(4)) + 4;
+    if (nlen > 286 || ndist > 30) return false;
+    uint8_t* const cl = lens + 320;
+    // the order of the code-length code's lengths (16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15), five bits each
+    const uint64_t order_lo = 0x22caa324e804a30ull, order_hi = 0x3c2e1346cull;
+    for (int i = 0; i < 19; ++i) cl[i] = 0;
+    for (int i = 0; i < ncode; ++i) {
+        br.refill();
+        const uint32_t at = static_cast<uint32_t>((i < 12 ? order_lo >> (5 * i) : order_hi >> (5 * (i - 12))) & 31u);
+        cl[at] = static_cast<uint8_t>(br.bits(3));
+    }
+    if (!build_code(cl, 19, 0, T.dtab, 7, T.dcount, T.dsym, T.offs)) return false;
+    int have = 0;
+    while (have < nlen + ndist) {
+        if (br.overrun()) return false;
+        br.refill();
+        const int s = decode_symbol(br, T.dtab, 7, T.dcount, T.dsym);
+        if (s < 0) return false;
+        if (s < 16) { lens[have++] = static_cast<uint8_t>(s); continue; }
+        uint8_t fill = 0;
+        int rep;
+        if (s == 16) {
+            if (have == 0) return false;
+            fill = lens[have - 1];
+            rep = 3 + static_cast<int>(br.bits(2));
+        } else if (s == 17) {
+            rep = 3 + static_cast<int>(br.bits(3));
+        } else {
+            rep = 11 + static_cast<int>(br.bits(7));
+        }
+        if (have + rep > nlen + ndist) return false;
+        while (rep--) lens[have++] = fill;
+    }
+    if (lens[256] == 0) return false;
+    if (!build_code(lens + nlen, ndist, 1, T.dtab, LANES_DIST_BITS, T.dcount, T.dsym, T.offs)) return false;
+    if (!build_code(lens, nlen, 1, T.lit, LANES_LIT_BITS, T.lcount, T.lsym, T.offs)) return false;
+    return true;
+}
+
+// Decodes DEFLATE blocks from bit `start_bit` of in[0 .. in_len) until a final block ends or a block ends at or beyond
+// `stop_bit`, into out[0 .. out_len).  `end` receives the bit position behind the last block, `made` the elements
+// written, `final_block` whether the last block was the stream's last.
+struct LanesResult {
+    uint32_t end_bit, made, final_block;
+};
+template<class OutT>
+__device__ __forceinline__ int inflate_lanes(const uint8_t* __restrict__ in, uint32_t in_len, uint32_t start_bit, uint32_t stop_bit, OutT* out,
+                                             uint32_t out_len, WaveTables& T, WaveStage& S, const uint32_t lane, LanesResult& res) {
+    using namespace scginf;
+    constexpr bool SYMBOLS = sizeof(OutT) == 2;
     uint8_t* const lens = reinterpret_cast<uint8_t*>(T.lit);             // 320 + 19 code lengths fit the 2 KiB of T.lit
-    uint32_t bitpos = 0, op = 0;
+    uint32_t bitpos = start_bit, op = 0;
     const uint32_t in_bits = in_len * 8u;
     uint32_t last;
     uint32_t nm = 0;                                                     // matches decoded, not copied yet
     InRing ring;
     ring.in = in; ring.limit = in_len + IN_SLACK; ring.lo = ring.hi = 0; ring.ahead = 0;
-    if (out_len > 0x10000u) return INFLATE_BAD_SIZE;                     // (not BGZF; S.tok_at packs places into 16 bits)
     do {
         if (bitpos > in_bits) return INFLATE_BAD_DATA;
         // ---- block header: the wavefront as a whole ----
@@ -305,58 +408,23 @@ __device__ __forceinline__ int inflate_member_lanes(const uint8_t* __restrict__ 
             if (from > in_len || n > in_len - from) return INFLATE_BAD_DATA;
             resolve_matches(out, S, nm, lane);
             nm = 0;
-            wave_copy(out, op, in + from, n, n ? n : 1u, lane);
+            wave_store(out, op, in + from, n, lane);
             op += n;
             bitpos = (from + n) * 8u;
             continue;
         }
         if (type == 3) return INFLATE_BAD_DATA;
-        int nlen, ndist;
         if (type == 1) {
-            nlen = 288; ndist = 32;
             for (int s = 0; s < 144; ++s) lens[s] = 8;
             for (int s = 144; s < 256; ++s) lens[s] = 9;
             for (int s = 256; s < 280; ++s) lens[s] = 7;
             for (int s = 280; s < 288; ++s) lens[s] = 8;
             for (int s = 0; s < 32; ++s) lens[288 + s] = 5;
-        } else {
-            nlen = static_cast<int>(br.bits(5)) + 257;
-            ndist = static_cast<int>(br.bits(5)) + 1;
-            const int ncode = static_cast<int>(br.bits(4)) + 4;
-            if (nlen > 286 || ndist > 30) return INFLATE_BAD_DATA;
-            uint8_t* const cl = lens + 320;
-            const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
-            for (int i = 0; i < 19; ++i) cl[i] = 0;
-            for (int i = 0; i < ncode; ++i) {
-                br.refill();
-                cl[order[i]] = static_cast<uint8_t>(br.bits(3));
-            }
-            if (!build_code(cl, 19, 0, T.dtab, 7, T.dcount, T.dsym, T.offs)) return INFLATE_BAD_DATA;
-            int have = 0;
-            while (have < nlen + ndist) {
-                if (br.overrun()) return INFLATE_BAD_DATA;
-                br.refill();
-                const int s = decode_symbol(br, T.dtab, 7, T.dcount, T.dsym);
-                if (s < 0) return INFLATE_BAD_DATA;
-                if (s < 16) { lens[have++] = static_cast<uint8_t>(s); continue; }
-                uint8_t fill = 0;
-                int rep;
-                if (s == 16) {
-                    if (have == 0) return INFLATE_BAD_DATA;
-                    fill = lens[have - 1];
-                    rep = 3 + static_cast<int>(br.bits(2));
-                } else if (s == 17) {
-                    rep = 3 + static_cast<int>(br.bits(3));
-                } else {
-                    rep = 11 + static_cast<int>(br.bits(7));
-                }
-                if (have + rep > nlen + ndist) return INFLATE_BAD_DATA;
-                while (rep--) lens[have++] = fill;
-            }
-            if (lens[256] == 0) return INFLATE_BAD_DATA;
+            if (!build_code(lens + 288, 32, 1, T.dtab, LANES_DIST_BITS, T.dcount, T.dsym, T.offs)) return INFLATE_BAD_DATA;
+            if (!build_code(lens, 288, 1, T.lit, LANES_LIT_BITS, T.lcount, T.lsym, T.offs)) return INFLATE_BAD_DATA;
+        } else if (!read_dynamic_tables(br, T, lens)) {
+            return INFLATE_BAD_DATA;
         }
-        if (!build_code(lens + nlen, ndist, 1, T.dtab, LANES_DIST_BITS, T.dcount, T.dsym, T.offs)) return INFLATE_BAD_DATA;
-        if (!build_code(lens, nlen, 1, T.lit, LANES_LIT_BITS, T.lcount, T.lsym, T.offs)) return INFLATE_BAD_DATA;
         bitpos = (br.pos * 8u) - br.cnt;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // the tables, written through one lane's eyes, are read per lane below
 
@@ -410,23 +478,23 @@ __device__ __forceinline__ int inflate_member_lanes(const uint8_t* __restrict__ 
             if (op > out_len) return INFLATE_BAD_SIZE;                   // (nothing of the batch has been written yet)
             const bool mineA = (chainA >> lane) & 1ull, mineB = (chainB >> lane) & 1ull;
             // literals: one byte per lane and half, all at once
-            if (mineA && A.kind == 0) out[outposA] = static_cast<uint8_t>(A.sym);
-            if (mineB && B.kind == 0) out[outposB] = static_cast<uint8_t>(B.sym);
+            if (mineA && A.kind == 0) out[outposA] = static_cast<OutT>(A.sym);
+            if (mineB && B.kind == 0) out[outposB] = static_cast<OutT>(B.sym);
             // matches: noted, copied later -- the decoder does not need their bytes to go on, so it does not wait for them
             const bool matchA = mineA && A.kind == 1, matchB = mineB && B.kind == 1;
             const uint64_t matchesA = ballot64(matchA), matchesB = ballot64(matchB);
             if (matchesA | matchesB) {
-                if (ballot64((matchA && A.dist > outposA) || (matchB && B.dist > outposB))) return INFLATE_BAD_DATA;       // "invalid distance too far back"
+                if (!SYMBOLS && ballot64((matchA && A.dist > outposA) || (matchB && B.dist > outposB))) return INFLATE_BAD_DATA;       // "invalid distance too far back"
                 const uint32_t nA = static_cast<uint32_t>(__builtin_popcountll(matchesA));
                 if (matchA) {
                     const uint32_t slot = nm + rank_below(matchesA);
-                    S.tok_at[slot] = outposA | (A.n << 16);
-                    S.tok_dist[slot] = A.dist;
+                    S.tok_at[slot] = outposA;
+                    S.tok_dist[slot] = A.dist | (A.n << 16);
                 }
                 if (matchB) {                                            // (behind the first half's: the list stays in text order)
                     const uint32_t slot = nm + nA + rank_below(matchesB);
-                    S.tok_at[slot] = outposB | (B.n << 16);
-                    S.tok_dist[slot] = B.dist;
+                    S.tok_at[slot] = outposB;
+                    S.tok_dist[slot] = B.dist | (B.n << 16);
                 }
                 nm += nA + static_cast<uint32_t>(__builtin_popcountll(matchesB));
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -453,7 +521,7 @@ __device__ __forceinline__ int inflate_member_lanes(const uint8_t* __restrict__ 
             if (s < 0) return INFLATE_BAD_DATA;
             if (s < 256) {
                 if (op >= out_len) return INFLATE_BAD_SIZE;
-                if (lane == 0) out[op] = static_cast<uint8_t>(s);
+                if (lane == 0) out[op] = static_cast<OutT>(s);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 ++op;
             } else if (s == 256) {
@@ -477,19 +545,29 @@ __device__ __forceinline__ int inflate_member_lanes(const uint8_t* __restrict__ 
                     const uint32_t eb = (static_cast<uint32_t>(dcode) >> 1) - 1u;
                     d = ((2u + (static_cast<uint32_t>(dcode) & 1u)) << eb) + 1u + sr.bits(eb);
                 }
-                if (d > op) return INFLATE_BAD_DATA;
+                if (!SYMBOLS && d > op) return INFLATE_BAD_DATA;
                 if (len > out_len - op) return INFLATE_BAD_SIZE;
                 resolve_matches(out, S, nm, lane);                       // (its source may be one of them)
                 nm = 0;
-                wave_copy(out, op, out + op - d, len, d, lane);
+                wave_copy(out, op, len, d, lane);
                 op += len;
             }
             bitpos = (sr.pos * 8u) - sr.cnt;
         }
-    } while (!last);
+    } while (!last && bitpos < stop_bit);
     resolve_matches(out, S, nm, lane);
-    if (((bitpos + 7u) >> 3) != in_len || op != out_len) return INFLATE_BAD_SIZE;
+    res.end_bit = bitpos; res.made = op; res.final_block = last;
     return INFLATE_OK;
+}
+
+// A BGZF member: one DEFLATE stream that fills its payload and yields exactly the announced text.
+__device__ __forceinline__ int inflate_member_lanes(const uint8_t* __restrict__ in, uint32_t in_len, uint8_t* out, uint32_t out_len,
+                                                    WaveTables& T, WaveStage& S, const uint32_t lane) {
+    LanesResult r;
+    const int rc = inflate_lanes<uint8_t>(in, in_len, 0u, ~0u, out, out_len, T, S, lane, r);
+    if (rc != scginf::INFLATE_OK) return rc;
+    if (!r.final_block || ((r.end_bit + 7u) >> 3) != in_len || r.made != out_len) return scginf::INFLATE_BAD_SIZE;
+    return scginf::INFLATE_OK;
 }
 
 #ifndef SCG_INFLATE_WAVES
@@ -504,6 +582,188 @@ __global__ __launch_bounds__(INFLATE_BLOCK, SCG_INFLATE_WAVES) void inflate_memb
     const scg::InflateMember M = members[m];
     const int rc = inflate_member_lanes(in + M.in_off, M.in_len, text + M.out_off, M.out_len, tables, stage, threadIdx.x);
     if (rc != scginf::INFLATE_OK && threadIdx.x == 0) atomicOr(status, scg::INFLATE_STATUS_BAD);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Ordinary gzip on the device (scg_pgzip.h explains the two-stage scheme; here its stage 1 runs one wavefront per chunk):
+//   gunzip_find_kernel     every chunk but the first looks for the first bit position at or behind its nominal start at
+//                          which a non-final dynamic-Huffman block header parses (64 positions tested per step by a
+//                          cheap filter -- block type, code counts, a complete code-length code -- the survivors parsed
+//                          in full, tables and all);
+//   gunzip_decode_kernel   every chunk decodes from its start to the next chunk's start into 16-bit symbols, without the
+//                          32 KiB of text in front of it (markers); the host then checks that every chunk ended exactly
+//                          where the next began -- by induction from the stream's known first block every chunk then
+//                          started on a true block boundary -- and that the last one ended the stream;
+//   gunzip_tails_kernel    in stream order, one workgroup: the last 32 KiB of every chunk's symbols become text (their
+//                          markers point into the 32 KiB before the chunk, which are text by then);
+//   gunzip_resolve_kernel  everything else becomes text, all chunks at once.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(INFLATE_BLOCK) void gunzip_find_kernel(const uint8_t* __restrict__ in, uint64_t size, scg::GunzipChunk* __restrict__ chunks,
+                                                                    uint32_t n, uint64_t first_byte, uint64_t chunk_bytes, uint64_t stream_end_byte) {
+    __shared__ WaveTables tables;
+    using namespace scginf;
+    const uint32_t c = blockIdx.x + 1;           // chunk 0 starts where the stream starts
+    if (c >= n) return;
+    const uint32_t lane = threadIdx.x;
+    uint8_t* const lens = reinterpret_cast<uint8_t*>(tables.lit);
+    const uint64_t from = (first_byte + chunk_bytes * c) * 8u;
+    uint64_t to = from + chunk_bytes * 8u;
+    if (to > stream_end_byte * 8u) to = stream_end_byte * 8u;
+    uint64_t found = ~0ull;
+    for (uint64_t base = from; base + 80 <= to && found == ~0ull; base += INFLATE_BLOCK) {
+        const uint64_t bit = base + lane;
+        uint64_t v, v2;
+        __builtin_memcpy(&v, in + (bit >> 3), 8);                       // (the buffer is readable IN_SLACK bytes beyond the stream)
+        v >>= (bit & 7u);                                               // >= 57 bits
+        const uint64_t bit2 = bit + 56;
+        __builtin_memcpy(&v2, in + (bit2 >> 3), 8);
+        v2 >>= (bit2 & 7u);
+        // BFINAL = 0, BTYPE = 10 (LSB first), HLIT <= 29, HDIST <= 29, and the code-length code complete (Kraft sum)
+        bool ok = (v & 7u) == 4u && ((v >> 3) & 31u) <= 29u && ((v >> 8) & 31u) <= 29u;
+        const uint32_t ncode = static_cast<uint32_t>((v >> 13) & 15u) + 4u;
+        uint32_t kraft = 0;
+        uint64_t w = v >> 17;
+#pragma unroll
+        for (uint32_t i = 0; i < 13; ++i) { const uint32_t l = static_cast<uint32_t>(w & 7u); w >>= 3; if (i < ncode && l) kraft += 128u >> l; }
+        w = v2;
+#pragma unroll
+        for (uint32_t i = 13; i < 19; ++i) { const uint32_t l = static_cast<uint32_t>(w & 7u); w >>= 3; if (i < ncode && l) kraft += 128u >> l; }
+        ok = ok && kraft == 128u && bit + 80 <= to;
+        uint64_t cand = ballot64(ok);
+        while (cand) {
+            const uint32_t k = static_cast<uint32_t>(__builtin_ctzll(cand));
+            cand &= cand - 1;
+            const uint64_t at = base + k;
+            // the header in full, by the wavefront as a whole: relative to a base that keeps positions in 32 bits
+            const uint64_t byte0 = at >> 3;
+            const uint64_t left = size - byte0;
+            BitReader br;
+            br.open(in + byte0, static_cast<uint32_t>(left < (1u << 28) ? left : (1u << 28)));
+            br.refill();
+            br.bits(static_cast<uint32_t>(at & 7u) + 3u);               // BFINAL, BTYPE
+            br.refill();
+            if (read_dynamic_tables(br, tables, lens) && !br.overrun()) { found = at; break; }
+        }
+    }
+    if (lane == 0) chunks[c].start_bit = found;
+}
+
+__global__ __launch_bounds__(INFLATE_BLOCK, SCG_INFLATE_WAVES) void gunzip_decode_kernel(const uint8_t* __restrict__ in, uint64_t size,
+                                                                                        scg::GunzipChunk* __restrict__ chunks, uint32_t n,
+                                                                                        uint16_t* __restrict__ syms, uint64_t cap_syms) {
+    __shared__ WaveTables tables;
+    __shared__ WaveStage stage;
+    const uint32_t c = blockIdx.x;
+    if (c >= n) return;
+    const uint64_t start = chunks[c].start_bit;
+    if (start == ~0ull) {                                               // no block starts here: the chunk before decodes through
+        if (threadIdx.x == 0) { chunks[c].made = 0; chunks[c].status = 0; chunks[c].end_bit = ~0ull; chunks[c].final_block = 0; }
+        return;
+    }
+    uint64_t stop = ~0ull;
+    for (uint32_t k = c + 1; k < n; ++k) {
+        const uint64_t s = chunks[k].start_bit;
+        if (s != ~0ull) { stop = s; break; }
+    }
+    const uint64_t byte0 = start >> 3;
+    const uint64_t left = size - byte0;
+    const uint32_t in_len = static_cast<uint32_t>(left < (1u << 28) ? left : (1u << 28));
+    const uint64_t rel_stop = stop == ~0ull ? ~0ull : stop - byte0 * 8u;
+    LanesResult r;
+    r.end_bit = 0; r.made = 0; r.final_block = 0;
+    const int rc = inflate_lanes<uint16_t>(in + byte0, in_len, static_cast<uint32_t>(start & 7u), rel_stop < 0x7FFFFFFFull ? static_cast<uint32_t>(rel_stop) : 0x7FFFFFFFu,
+                                           syms + cap_syms * c, static_cast<uint32_t>(cap_syms), tables, stage, threadIdx.x, r);
+    if (threadIdx.x == 0) {
+        chunks[c].status = static_cast<uint32_t>(rc);
+        chunks[c].made = r.made;
+        chunks[c].end_bit = byte0 * 8u + r.end_bit;
+        chunks[c].final_block = r.final_block;
+    }
+}
+
+constexpr int TAILS_BLOCK = 1024;
+// text_at[c] = where chunk c's text begins.  One workgroup walks the chunks in stream order and turns the last 32 KiB of
+// every chunk's symbols into text: a marker's byte lies in the 32 KiB in front of its chunk -- the tail of the chunk
+// before, final by then.  This is the one serial step of the scheme, and in FASTQ nearly every tail is full of markers
+// (a flank that every read repeats is copied from the read before, never spelled out again), so it is made short: the
+// window lives in LDS (two buffers of 32 KiB: look-ups read one while the chunk's own tail fills the other), the symbols
+// come in one coalesced sweep and the text goes out the same way -- ~2 us a chunk instead of 25 with the look-ups in HBM.
+__global__ __launch_bounds__(TAILS_BLOCK) void gunzip_tails_kernel(const uint16_t* __restrict__ syms, uint64_t cap_syms, const scg::GunzipChunk* __restrict__ chunks,
+                                                                   const uint64_t* __restrict__ text_at, uint32_t n, uint8_t* text, uint32_t* __restrict__ status) {
+    __shared__ uint8_t win[2][MARKER_WINDOW];
+    uint32_t cur = 0;
+    bool have = false;                           // win[cur] holds the 32 KiB of text in front of the next chunk
+    for (uint32_t c = 0; c < n; ++c) {
+        const uint32_t made = chunks[c].made;
+        if (made == 0) continue;                 // (no block began in this chunk: the one before decoded through it)
+        const uint64_t at = text_at[c];
+        if (made >= MARKER_WINDOW) {
+            const uint16_t* s = syms + cap_syms * c + (made - MARKER_WINDOW);
+            uint8_t* t = text + at + (made - MARKER_WINDOW);
+            constexpr int PER = MARKER_WINDOW / TAILS_BLOCK;             // 32 symbols a thread
+            uint16_t v[PER];
+#pragma unroll
+            for (int k = 0; k < PER; ++k) v[k] = s[threadIdx.x + k * TAILS_BLOCK];
+            bool bad = false;
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                uint8_t byte = static_cast<uint8_t>(v[k]);
+                if (v[k] >= MARKER) {
+                    if (have) byte = win[cur][v[k] - MARKER];
+                    else { bad = true; byte = 0; }                       // (a reference in front of the stream: not a valid file)
+                }
+                win[cur ^ 1][threadIdx.x + k * TAILS_BLOCK] = byte;
+                t[threadIdx.x + k * TAILS_BLOCK] = byte;
+            }
+            if (bad) atomicOr(status, 1u);
+            __threadfence_block();
+            __syncthreads();
+            cur ^= 1;
+            have = true;
+            continue;
+        }
+        // a short chunk (the stream's last, as a rule): look-ups in the text itself, then the window is read back from it
+        const uint16_t* s = syms + cap_syms * c;
+        uint8_t* t = text + at;
+        for (uint32_t i = threadIdx.x; i < made; i += TAILS_BLOCK) {
+            const uint32_t x = s[i];
+            uint8_t byte = static_cast<uint8_t>(x);
+            if (x >= MARKER) {
+                const uint64_t back = MARKER_WINDOW - (x - MARKER);
+                if (back > at) { atomicOr(status, 1u); byte = 0; }
+                else byte = text[at - back];
+            }
+            t[i] = byte;
+        }
+        __threadfence_block();
+        __syncthreads();
+        const uint64_t end = at + made;
+        have = end >= MARKER_WINDOW;
+        if (have) {
+            for (uint32_t i = threadIdx.x; i < MARKER_WINDOW; i += TAILS_BLOCK) win[cur ^ 1][i] = text[end - MARKER_WINDOW + i];
+            __syncthreads();
+            cur ^= 1;
+        }
+    }
+}
+
+constexpr int RESOLVE_BLOCK = 256, RESOLVE_SLICES = 16;
+__global__ __launch_bounds__(RESOLVE_BLOCK) void gunzip_resolve_kernel(const uint16_t* __restrict__ syms, uint64_t cap_syms, const scg::GunzipChunk* __restrict__ chunks,
+                                                                       const uint64_t* __restrict__ text_at, uint32_t n, uint8_t* text) {
+    const uint32_t c = blockIdx.x / RESOLVE_SLICES, slice = blockIdx.x % RESOLVE_SLICES;
+    if (c >= n) return;
+    const uint32_t made = chunks[c].made;
+    const uint32_t body = made < MARKER_WINDOW ? 0u : made - MARKER_WINDOW;     // (the tail is text already)
+    const uint64_t at = text_at[c];
+    const uint16_t* s = syms + cap_syms * c;
+    const uint32_t a = static_cast<uint32_t>(static_cast<uint64_t>(body) * slice / RESOLVE_SLICES);
+    const uint32_t b = static_cast<uint32_t>(static_cast<uint64_t>(body) * (slice + 1) / RESOLVE_SLICES);
+    for (uint32_t i = a + threadIdx.x; i < b; i += RESOLVE_BLOCK) {
+        const uint32_t v = s[i];
+        // (a marker's byte lies in the 32 KiB in front of the chunk: a tail, final since gunzip_tails_kernel)
+        const uint64_t back = MARKER_WINDOW - (v - MARKER);             // (back > at: flagged by gunzip_tails_kernel's pass over the same window)
+        text[at + i] = v >= MARKER ? (back <= at ? text[at - back] : uint8_t(0)) : static_cast<uint8_t>(v);
+    }
 }
 
 // zlib's crc32.c: a * b mod p over GF(2), reflected (bit 31 is x^0).
@@ -523,7 +783,7 @@ constexpr int CRC_BLOCK = 256;
 // byte through a 256-entry table in LDS, multiplies it by x^(8 * bytes behind the piece) and the products are XORed:
 // crc(A || B) = crc(A) * x^(8 |B|) + crc(B)  (crc32_combine).
 __global__ __launch_bounds__(CRC_BLOCK) void crc_members_kernel(const uint8_t* __restrict__ text, const scg::InflateMember* __restrict__ members, uint32_t n,
-                                                                scg::CrcPowers P, uint32_t* __restrict__ status) {
+                                                                scg::CrcPowers P, uint32_t* __restrict__ status, uint32_t* __restrict__ crcs_out) {
     __shared__ uint32_t table[256];
     __shared__ uint32_t part[CRC_BLOCK / 64];
     {
@@ -563,7 +823,8 @@ __global__ __launch_bounds__(CRC_BLOCK) void crc_members_kernel(const uint8_t* _
         if (threadIdx.x == 0) {
             uint32_t crc = 0;
             for (int w = 0; w < CRC_BLOCK / 64; ++w) crc ^= part[w];
-            if (crc != M.crc) atomicOr(status, scg::INFLATE_STATUS_CRC);
+            if (crcs_out) crcs_out[m] = crc;                              // (pieces of one long text: the host combines them)
+            else if (crc != M.crc) atomicOr(status, scg::INFLATE_STATUS_CRC);
         }
         __syncthreads();
     }
@@ -637,7 +898,35 @@ hipError_t launch_inflate_members(const uint8_t* d_in, const InflateMember* d_me
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(crc_members_kernel, dim3(n < 4096 ? n : 4096), dim3(CRC_BLOCK), 0, stream, reinterpret_cast<const uint8_t*>(d_text), d_members, n,
-                       crc_powers(), d_status);
+                       crc_powers(), d_status, static_cast<uint32_t*>(nullptr));
+    return hipGetLastError();
+}
+
+hipError_t launch_gunzip_find(const uint8_t* d_in, uint64_t size, GunzipChunk* d_chunks, uint32_t n, uint64_t first_byte, uint64_t chunk_bytes,
+                              uint64_t stream_end_byte, hipStream_t stream) {
+    if (n <= 1) return hipSuccess;
+    hipLaunchKernelGGL(gunzip_find_kernel, dim3(n - 1), dim3(INFLATE_BLOCK), 0, stream, d_in, size, d_chunks, n, first_byte, chunk_bytes, stream_end_byte);
+    return hipGetLastError();
+}
+hipError_t launch_gunzip_decode(const uint8_t* d_in, uint64_t size, GunzipChunk* d_chunks, uint32_t n, uint16_t* d_syms, uint64_t cap_syms, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(gunzip_decode_kernel, dim3(n), dim3(INFLATE_BLOCK), 0, stream, d_in, size, d_chunks, n, d_syms, cap_syms);
+    return hipGetLastError();
+}
+hipError_t launch_gunzip_text(const uint16_t* d_syms, uint64_t cap_syms, const GunzipChunk* d_chunks, const uint64_t* d_text_at, uint32_t n, char* d_text,
+                              uint32_t* d_status, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(gunzip_tails_kernel, dim3(1), dim3(TAILS_BLOCK), 0, stream, d_syms, cap_syms, d_chunks, d_text_at, n, reinterpret_cast<uint8_t*>(d_text),
+                       d_status);
+    hipLaunchKernelGGL(gunzip_resolve_kernel, dim3(n * RESOLVE_SLICES), dim3(RESOLVE_BLOCK), 0, stream, d_syms, cap_syms, d_chunks, d_text_at, n,
+                       reinterpret_cast<uint8_t*>(d_text));
+    return hipGetLastError();
+}
+// CRC-32 of the pieces members[0 .. n) of d_text (out_off, out_len; their crc fields are not looked at) -> d_crcs.
+hipError_t launch_crc_pieces(const char* d_text, const InflateMember* d_members, uint32_t n, uint32_t* d_crcs, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(crc_members_kernel, dim3(n < 4096 ? n : 4096), dim3(CRC_BLOCK), 0, stream, reinterpret_cast<const uint8_t*>(d_text), d_members, n,
+                       crc_powers(), static_cast<uint32_t*>(nullptr), d_crcs);
     return hipGetLastError();
 }
 

@@ -127,7 +127,9 @@ namespace {
 // the last `slack` bytes; 0 if there is none.  data[0] is a record start, so c is then a record boundary as long as
 // the window holds ordinary records only -- which the device scan verifies for every window (scg_textscan.hip): a
 // wrong guess here surfaces there as a line count that is not a multiple of four.
-size_t find_cut(const char* data, size_t len, size_t slack = size_t(1) << 20) {
+} // namespace
+
+size_t find_cut(const char* data, size_t len, size_t slack) {
     const size_t floor = len > slack ? len - slack : 0;
     size_t pos = len;
     while (pos > floor) {
@@ -146,6 +148,8 @@ size_t find_cut(const char* data, size_t len, size_t slack = size_t(1) << 20) {
     }
     return 0;
 }
+
+namespace {
 
 struct MappedFile {
     int fd = -1;
@@ -660,6 +664,17 @@ protected:
 };
 
 } // namespace
+
+// A gzip file that is not BGZF and large enough for the chunked decoders (the host threads', or the device's).
+bool TextSource::ordinary_gzip(const char* path, int threads) {
+    unsigned char h[2] = {0, 0};
+    FILE* fp = std::fopen(path, "rb");
+    if (!fp) return false;
+    const size_t got = std::fread(h, 1, 2, fp);
+    std::fclose(fp);
+    if (got != 2 || h[0] != 0x1f || h[1] != 0x8b) return false;
+    return !BgzfSource::looks_like(path) && PgzipSource::wanted(path, threads);
+}
 
 std::unique_ptr<TextSource> TextSource::open(const char* path, int threads, bool parallel_gzip, int gzip_threads) {
     if (gzip_threads <= 0) gzip_threads = threads;

@@ -38,6 +38,10 @@ private:
 // trailing newline); otherwise 0.  Optionally reports where its sequence line lies.
 size_t strict_record_end(const char* data, size_t size, size_t p, const char** seq = nullptr, size_t* seq_len = nullptr);
 
+// The largest cut <= len such that data[.. cut) ends with two consecutive ordinary records (searched for in the last
+// `slack` bytes); 0 if there is none.
+size_t find_cut(const char* data, size_t len, size_t slack = size_t(1) << 20);
+
 // The sequences of one window, found by the host (TextSource::next_parsed): each segment is the work of one thread,
 // `seq_bytes` bytes of sequences back to back at seqs[seq_at ...) and n_records + 1 byte offsets, relative to the
 // segment's first sequence, at offsets[off_at ...).
@@ -86,12 +90,22 @@ public:
     // set: a member in a form only zlib should judge).
     virtual bool has_members() const { return false; }
     virtual size_t next_members(char*, size_t, size_t, size_t, std::vector<CompressedMember>&, size_t&, bool&) { return 0; }
+    // Text that already lies in HBM (an ordinary gzip file decoded by the device, scg_dgzip.cpp): the next window is
+    // copied device to device into d_dst (device `device()`, on `stream`: a hipStream_t) instead of crossing the link twice.
+    virtual bool device_resident() const { return false; }
+    virtual int device() const { return -1; }
+    virtual size_t next_device(char*, size_t, void*) { return 0; }
     // The text could not be cut at a verified record boundary: the caller must redo the file sequentially.
     bool unusual() const { return odd; }
     // An upper estimate of the text bytes still to come (window sizing only).
     virtual uint64_t size_hint() const = 0;
     virtual const char* kind() const = 0;
     static size_t min_capacity() { return size_t(4) << 20; }
+    // An ordinary (one-member) gzip file decoded on `device`, its text left in HBM; null when the file is not of that
+    // kind, too small to bother, too large for the symbol buffers, or anything about it is unusual -- the caller then
+    // opens it the ordinary way (scg_dgzip.cpp).
+    static std::unique_ptr<TextSource> open_on_device(const char* path, int device, int threads);
+    static bool ordinary_gzip(const char* path, int threads);      // a gzip file, not BGZF, of a size the chunked decoders take
 
 protected:
     bool odd = false;

@@ -307,11 +307,21 @@ private:
         const auto f0 = std::chrono::steady_clock::now();
         t_busy += std::chrono::duration<double, std::milli>(f0 - b0).count();
         scg::ParsedWindow w;
-        const size_t bytes = host_scan ? src.next_parsed(s.text.as<char>(), s.cap, s.h_offsets.as<uint32_t>(), s.B.cap_records + 1, w)
+        const bool on_device = src.device_resident() && src.device() == s.plan_device;       // text that lies in this device's HBM already
+        const size_t bytes = on_device ? src.next_device(s.d_text.as<char>(), s.cap, s.stream)
+                           : host_scan ? src.next_parsed(s.text.as<char>(), s.cap, s.h_offsets.as<uint32_t>(), s.B.cap_records + 1, w)
                                        : src.next(s.text.as<char>(), s.cap);
         t_fill += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - f0).count();
         if (src.unusual()) throw UnusualInput();
         if (bytes == 0) { ended = true; return; }
+        if (on_device) {
+            s.parsed = false;
+            HIP_CHECK(scg::launch_text_scan(s.d_text.as<char>(), bytes, s.B, s.stream));
+            HIP_CHECK(hipMemcpyAsync(s.h_result.p, s.d_result.p, sizeof(scg::TextScanResult), hipMemcpyDeviceToHost, s.stream));
+            s.pending = true;
+            ++filled;
+            return;
+        }
         if (host_scan) {
             const uint32_t rec = enqueue_gather(s, w);
             s.host_result = scg::TextScanResult{0, rec, w.max_len, 0, w.seq_bytes, 0, 0};
@@ -1142,7 +1152,18 @@ std::unique_ptr<PlanSet> compile_and_count_single_end(const char* path, scg::Fas
     try {
         devices = devices_for_input(text_bytes_hint(path));
         if (device_scan_enabled()) {
-            src = scg::TextSource::open(path, scg::default_host_threads(nthreads, static_cast<int>(devices.size())));
+            const int host_threads = scg::default_host_threads(nthreads, static_cast<int>(devices.size()));
+            // an ordinary gzip file of some size: decoded by the device when it is of the plain kind (one member), its text
+            // left in HBM; whatever that decoder declines goes to the host threads' decoder
+            if (scg::TextSource::ordinary_gzip(path, host_threads)) {
+                src = scg::TextSource::open_on_device(path, devices[0], host_threads);
+                // (test hook SCG_DEVICE_GUNZIP=2: a file the device decoder hands back is an error, so that a test on a
+                // well-formed file cannot pass on the host decoders)
+                const char* e = std::getenv("SCG_DEVICE_GUNZIP");
+                if (!src && e && *e == '2') throw Error(SCG_ERR_UNSUPPORTED, "the device gzip decoder handed the file back (SCG_DEVICE_GUNZIP=2 forbids the fall-back)");
+            }
+            if (src) devices.resize(1);
+            else src = scg::TextSource::open(path, host_threads);
             if (src->has_members() && device_inflate_enabled()) {
                 inflate.reset(new InflatePipeline(*src, devices));
                 devices.resize(inflate->n_devices());  // (one device when the others cannot be reached over xGMI)

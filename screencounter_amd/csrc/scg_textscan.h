@@ -87,6 +87,22 @@ hipError_t launch_inflate_members(const uint8_t* d_in, const InflateMember* d_me
 hipError_t launch_carry_tail(const char* prev_text, const TextScanResult* prev_result, uint32_t prev_bytes, char* text, uint32_t gap, uint32_t* d_status,
                              hipStream_t stream);
 
+// ---- ordinary gzip decoded on the device (scg_inflate.hip; host side: scg_dgzip.cpp) ----
+struct GunzipChunk {
+    uint64_t start_bit;           // where the chunk's first block begins (absolute bit in the file; ~0: none found, merged into the chunk before)
+    uint64_t end_bit;             // where its last block ended
+    uint32_t status;              // scginf::INFLATE_* of its decoding
+    uint32_t made;                // symbols written
+    uint32_t final_block;         // its last block was the stream's last
+    uint32_t pad;
+};
+hipError_t launch_gunzip_find(const uint8_t* d_in, uint64_t size, GunzipChunk* d_chunks, uint32_t n, uint64_t first_byte, uint64_t chunk_bytes,
+                              uint64_t stream_end_byte, hipStream_t stream);
+hipError_t launch_gunzip_decode(const uint8_t* d_in, uint64_t size, GunzipChunk* d_chunks, uint32_t n, uint16_t* d_syms, uint64_t cap_syms, hipStream_t stream);
+hipError_t launch_gunzip_text(const uint16_t* d_syms, uint64_t cap_syms, const GunzipChunk* d_chunks, const uint64_t* d_text_at, uint32_t n, char* d_text,
+                              uint32_t* d_status, hipStream_t stream);
+hipError_t launch_crc_pieces(const char* d_text, const InflateMember* d_members, uint32_t n, uint32_t* d_crcs, hipStream_t stream);
+
 } // namespace scg
 
 #endif

@@ -496,3 +496,84 @@ def test_paired_plain_files_over_several_devices(sc, oracle, gpu, tmp_path, monk
         with pytest.raises(_lib.ScgError) as e:
             sc.count_dual_barcodes(a, ta, False, 1, pa, b, tb, False, 1, pb, False, True, False, 4)
         assert e.value.code == _lib.SCG_ERR_IO and "different number of reads" in str(e.value)
+
+
+def test_ordinary_gzip_decoded_by_the_device(sc, oracle, gpu, tmp_path, monkeypatch):
+    """One-member gzip files (what `gzip` writes) go to the device: chunks decoded into symbols by one wavefront each, the
+    chain checked on the host, symbols turned into text that stays in HBM (csrc/scg_dgzip.cpp).  SCG_DEVICE_GUNZIP=2 makes
+    a hand-back an error, so these well-formed files cannot pass on the host decoders; files of a kind the device decoder
+    does not take (several members, a header CRC, trailing bytes, a flipped bit) must come out as the host readers have
+    them -- same counts, or the same error."""
+    import gzip as gz_mod
+    import io
+    import zlib
+    rng = random.Random(4242)
+    template = "ACGTACGA" + "-" * 12 + "TGCATGCA"
+    pool = gen.make_pool(rng, 60, 12, "ACGT")
+    reads = gen.make_reads(rng, template, [pool], 30000, 2, 0.03, 0.01, 0.02, 0.1, 60)
+    text = gen.fastq_text(reads)
+    exp = oracle.count_single(reads, template, 2, pool, 1, True)
+
+    def gz(data, level):
+        c = zlib.compressobj(level, zlib.DEFLATED, 31)
+        return c.compress(data) + c.flush()
+
+    def count(path):
+        return sc.count_single_barcodes(path, template, 2, pool, 1, True, 4)
+
+    monkeypatch.setenv("SCG_PGZIP_CHUNK_KB", "64")                 # (these files are small: let the chunked decoders have them)
+    p = str(tmp_path / "one.fastq.gz")
+    for level in (1, 4, 6, 9):
+        for chunk_kb in (4, 16, 128):
+            for window_kb in (None, 100):
+                open(p, "wb").write(gz(text, level))
+                monkeypatch.setenv("SCG_DGZIP_CHUNK_KB", str(chunk_kb))
+                monkeypatch.setenv("SCG_DEVICE_GUNZIP", "2")
+                if window_kb:
+                    monkeypatch.setenv("SCG_WINDOW_KB", str(window_kb))
+                else:
+                    monkeypatch.delenv("SCG_WINDOW_KB", raising=False)
+                try:
+                    c, t = count(p)
+                except sc.ScgError as e:
+                    raise AssertionError((level, chunk_kb, window_kb, str(e)))
+                assert t == exp[1] and np.array_equal(c, exp[0]), (level, chunk_kb, window_kb)
+    monkeypatch.delenv("SCG_WINDOW_KB", raising=False)
+    monkeypatch.setenv("SCG_DGZIP_CHUNK_KB", "16")
+    # a named file (FNAME) is taken; the final record without its newline too
+    b = io.BytesIO()
+    with gz_mod.GzipFile(filename="reads.fastq", mode="wb", fileobj=b, compresslevel=5) as f:
+        f.write(text[:-1])
+    open(p, "wb").write(b.getvalue())
+    c, t = count(p)
+    assert t == exp[1] and np.array_equal(c, exp[0])
+    # handed back: the strict switch says so, the default quietly takes the host decoders
+    half = len(text) // 2
+    cut = text.rfind(b"\n@", 0, half) + 1
+    raw = gz(text, 6)
+    hdr = bytearray(raw[:10]); hdr[3] = 2
+    with_hcrc = bytes(hdr) + (zlib.crc32(bytes(hdr)) & 0xFFFF).to_bytes(2, "little") + raw[10:]
+    for name, data in (("two members", gz(text[:cut], 6) + gz(text[cut:], 6)), ("header crc", with_hcrc), ("trailing bytes", raw + b"\0\0\0\0")):
+        open(p, "wb").write(data)
+        monkeypatch.setenv("SCG_DEVICE_GUNZIP", "2")
+        with pytest.raises(sc.ScgError):
+            count(p)
+        monkeypatch.setenv("SCG_DEVICE_GUNZIP", "1")
+        c, t = count(p)
+        assert t == exp[1] and np.array_equal(c, exp[0]), name
+    # flipped bits: whatever the sequential reader makes of the file (SCG_DEVICE_SCAN=0) is what every path must give
+    for k in range(12):
+        data = bytearray(raw)
+        data[rng.randrange(12, len(data) - 8)] ^= 1 << rng.randrange(8)
+        open(p, "wb").write(bytes(data))
+        monkeypatch.setenv("SCG_DEVICE_SCAN", "0")
+        try:
+            want = ("ok",) + tuple(x if isinstance(x, int) else x.tobytes() for x in count(p)[::-1])
+        except sc.ScgError as e:
+            want = ("error", e.code, str(e))
+        monkeypatch.delenv("SCG_DEVICE_SCAN")
+        try:
+            got = ("ok",) + tuple(x if isinstance(x, int) else x.tobytes() for x in count(p)[::-1])
+        except sc.ScgError as e:
+            got = ("error", e.code, str(e))
+        assert got == want, k
