@@ -240,7 +240,8 @@ void scg_free(void* p);
  * pipelines is 128 MB of pinned memory + ~290 MB of HBM; a slot of the BGZF pipeline (members inflated on the device)
  * ~145 MB pinned + ~0.6 GB of HBM, so a process that has read both kinds keeps up to ~3.6 GB of HBM and ~1.1 GB of pinned
  * memory per device between calls.  The parallel gzip decoder
- * likewise keeps its symbol buffers (up to 40, ~12 MB resident each).  This releases all of them; SCG_BUFFER_CACHE=0
+ * likewise keeps its symbol buffers (up to 40, ~12 MB resident each), the device gzip decoder its scratch in HBM (33 bytes per
+ * compressed byte of the largest file so far) and two pinned buffers of 32 MB.  This releases all of them; SCG_BUFFER_CACHE=0
  * disables the cache of window slots altogether. */
 void scg_release_buffers(void);
 

@@ -25,6 +25,7 @@ void scg_free(void* p) { std::free(p); }
 void scg_release_buffers(void) {
     release_cached_slots();
     scg::ParallelGunzip::release_cached();
+    scg::release_device_gunzip_scratch();
 }
 
 int scg_parse_fastq(const char* path, char** seqs_out, uint64_t** offsets_out, int64_t* n_reads_out, char* err, size_t errcap) {

@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -42,6 +43,10 @@ struct DevMem {
     void* p = nullptr;
     ~DevMem() { if (p) (void)hipFree(p); }
     void alloc(size_t n) { DGZ_CHECK(hipMalloc(&p, n)); }
+    template<class T> T* as() const { return static_cast<T*>(p); }
+};
+struct View {                                            // (memory owned by the scratch set)
+    void* p;
     template<class T> T* as() const { return static_cast<T*>(p); }
 };
 struct PinnedMem {
@@ -70,6 +75,80 @@ struct Mapping {
 };
 
 bool trace_on() { const char* e = std::getenv("SCG_TRACE"); return e && *e && *e != '0'; }
+
+// The decoder's scratch -- the compressed file and the chunks' symbols in HBM (33 bytes per compressed byte), two pinned
+// buffers for the way there -- is kept for the next file: allocating and freeing 13 GB per call cost 20 ms of the 100 a
+// 0.4 GB file takes.  One set per process; a second call at the same time allocates its own.  scg_release_buffers() frees.
+struct Scratch {
+    int device = -1;
+    void* d_in = nullptr; size_t in_bytes = 0;
+    void* d_syms = nullptr; size_t sym_bytes = 0;
+    void* bounce[2] = {nullptr, nullptr};
+    bool busy = false;
+    void drop() {
+        if (device >= 0) {
+            int before = 0;
+            (void)hipGetDevice(&before);
+            (void)hipSetDevice(device);
+            if (d_in) (void)hipFree(d_in);
+            if (d_syms) (void)hipFree(d_syms);
+            for (auto& b : bounce) if (b) (void)hipHostFree(b);
+            (void)hipSetDevice(before);
+        }
+        d_in = d_syms = bounce[0] = bounce[1] = nullptr;
+        in_bytes = sym_bytes = 0;
+        device = -1;
+    }
+};
+std::mutex scratch_mu;
+Scratch scratch_cache;
+constexpr size_t BOUNCE_BYTES = size_t(32) << 20;
+
+// The cached set if it is free (grown to the sizes asked for), else a fresh one; `own` says which.
+struct ScratchLease {
+    Scratch local;
+    Scratch* s = nullptr;
+    bool cached = false;
+    ScratchLease(int device, size_t in_bytes, size_t sym_bytes) {
+        {
+            std::lock_guard<std::mutex> g(scratch_mu);
+            const char* e = std::getenv("SCG_BUFFER_CACHE");
+            if (!scratch_cache.busy && !(e && *e == '0')) { scratch_cache.busy = true; cached = true; }
+        }
+        s = cached ? &scratch_cache : &local;
+        try {
+            grow(device, in_bytes, sym_bytes);
+        } catch (...) {
+            release();
+            throw;
+        }
+    }
+    void release() {
+        if (cached) {
+            std::lock_guard<std::mutex> g(scratch_mu);
+            scratch_cache.busy = false;
+            cached = false;
+        } else {
+            local.drop();
+        }
+    }
+    void grow(int device, size_t in_bytes, size_t sym_bytes) {
+        if (s->device != device) s->drop();
+        s->device = device;
+        if (s->in_bytes < in_bytes) {
+            if (s->d_in) { (void)hipFree(s->d_in); s->d_in = nullptr; s->in_bytes = 0; }
+            DGZ_CHECK(hipMalloc(&s->d_in, in_bytes));
+            s->in_bytes = in_bytes;
+        }
+        if (s->sym_bytes < sym_bytes) {
+            if (s->d_syms) { (void)hipFree(s->d_syms); s->d_syms = nullptr; s->sym_bytes = 0; }
+            DGZ_CHECK(hipMalloc(&s->d_syms, sym_bytes));
+            s->sym_bytes = sym_bytes;
+        }
+        for (auto& b : s->bounce) if (!b) DGZ_CHECK(hipHostMalloc(&b, BOUNCE_BYTES, hipHostMallocDefault));
+    }
+    ~ScratchLease() { release(); }
+};
 
 class DeviceGunzipSource : public TextSource {
     int dev;
@@ -164,16 +243,21 @@ std::unique_ptr<TextSource> decode(const char* path, int device, int threads) {
     struct Restore { int d; ~Restore() { (void)hipSetDevice(d); } } restore{before};
     try {
         DGZ_CHECK(hipSetDevice(device));
-        DevMem d_in, d_chunks, d_syms;
-        d_in.alloc(f.size + 64);
+        // (not more than the card has to spare: the symbols take 32 bytes per compressed byte)
+        size_t free_bytes = 0, total_bytes = 0;
+        DGZ_CHECK(hipMemGetInfo(&free_bytes, &total_bytes));
+        const size_t need = f.size + 64 + cap_syms * n * sizeof(uint16_t) + f.size * 12;
+        ScratchLease lease(device, f.size + 64, cap_syms * n * sizeof(uint16_t));
+        if (need > free_bytes + lease.s->in_bytes + lease.s->sym_bytes) return nullptr;
+        const View d_in{lease.s->d_in}, d_syms{lease.s->d_syms};
+        DevMem d_chunks;
         d_chunks.alloc(sizeof(GunzipChunk) * n);
-        d_syms.alloc(cap_syms * n * sizeof(uint16_t));
         // the file into HBM through two pinned buffers filled by a few threads each
         {
-            const size_t piece = size_t(32) << 20;
-            PinnedMem bounce[2];
+            const size_t piece = BOUNCE_BYTES;
+            struct { void* p; } bounce[2] = {{lease.s->bounce[0]}, {lease.s->bounce[1]}};
             hipEvent_t done[2];
-            for (int k = 0; k < 2; ++k) { bounce[k].alloc(piece); DGZ_CHECK(hipEventCreateWithFlags(&done[k], hipEventDisableTiming)); }
+            for (int k = 0; k < 2; ++k) DGZ_CHECK(hipEventCreateWithFlags(&done[k], hipEventDisableTiming));
             const int nt = std::max(1, std::min(threads, 8));
             size_t off = 0;
             for (int k = 0; off < f.size; ++k, off += piece) {
@@ -185,6 +269,11 @@ std::unique_ptr<TextSource> decode(const char* path, int device, int threads) {
                     th.emplace_back([&, i] {
                         const size_t a = len * i / nt, e = len * (i + 1) / nt;
                         std::memcpy(static_cast<char*>(bounce[b].p) + a, f.data + off + a, e - a);
+                        // (the pages are not read again: their entries go here, in parallel, not in the final munmap)
+                        const uintptr_t page = 4096;
+                        const uintptr_t lo = (reinterpret_cast<uintptr_t>(f.data + off + a) + page - 1) & ~(page - 1);
+                        const uintptr_t hi = reinterpret_cast<uintptr_t>(f.data + off + e) & ~(page - 1);
+                        if (hi > lo && off + a >= 4096 && off + e + 4096 <= f.size) (void)::madvise(reinterpret_cast<void*>(lo), hi - lo, MADV_DONTNEED);
                     });
                 }
                 for (auto& x : th) x.join();
@@ -258,6 +347,11 @@ std::unique_ptr<TextSource> decode(const char* path, int device, int threads) {
 }
 
 } // namespace
+
+void release_device_gunzip_scratch() {
+    std::lock_guard<std::mutex> g(scratch_mu);
+    if (!scratch_cache.busy) scratch_cache.drop();
+}
 
 std::unique_ptr<TextSource> TextSource::open_on_device(const char* path, int device, int threads) {
     const char* e = std::getenv("SCG_DEVICE_GUNZIP");

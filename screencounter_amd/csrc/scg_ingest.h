@@ -38,6 +38,9 @@ private:
 // trailing newline); otherwise 0.  Optionally reports where its sequence line lies.
 size_t strict_record_end(const char* data, size_t size, size_t p, const char** seq = nullptr, size_t* seq_len = nullptr);
 
+// Frees what the device gzip decoder keeps between files (scg_dgzip.cpp; scg_release_buffers()).
+void release_device_gunzip_scratch();
+
 // The largest cut <= len such that data[.. cut) ends with two consecutive ordinary records (searched for in the last
 // `slack` bytes); 0 if there is none.
 size_t find_cut(const char* data, size_t len, size_t slack = size_t(1) << 20);
