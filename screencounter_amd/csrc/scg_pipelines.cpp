@@ -743,17 +743,19 @@ private:
                 continue;
             }
             scg::ParsedWindow w;
-            const size_t bytes = m.host_scan ? m.src->next_parsed(s.text.as<char>(), s.cap, s.h_offsets.as<uint32_t>(), s.B.cap_records + 1, w)
+            const bool on_device = m.src->device_resident() && m.src->device() == device;        // (an ordinary gzip mate decoded by this device)
+            const size_t bytes = on_device ? m.src->next_device(s.d_text.as<char>(), s.cap, s.stream)
+                               : m.host_scan ? m.src->next_parsed(s.text.as<char>(), s.cap, s.h_offsets.as<uint32_t>(), s.B.cap_records + 1, w)
                                              : m.src->next(s.text.as<char>(), s.cap);
             t_fill += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - f0).count();
             if (m.src->unusual()) throw UnusualInput();
             m.n = m.k = 0;
             if (bytes == 0) { m.done = true; continue; }
-            if (m.host_scan) {
+            if (m.host_scan && !on_device) {
                 m.n = enqueue_gather(s, w);
                 m.max_len = w.max_len;
             } else {
-                HIP_CHECK(hipMemcpyAsync(s.d_text.p, s.text.p, bytes, hipMemcpyHostToDevice, s.stream));
+                if (!on_device) HIP_CHECK(hipMemcpyAsync(s.d_text.p, s.text.p, bytes, hipMemcpyHostToDevice, s.stream));
                 HIP_CHECK(scg::launch_text_scan(s.d_text.as<char>(), bytes, s.B, s.stream));
                 HIP_CHECK(hipMemcpyAsync(s.h_result.p, s.d_result.p, sizeof(scg::TextScanResult), hipMemcpyDeviceToHost, s.stream));
                 m.fresh = true;
@@ -1415,9 +1417,20 @@ void count_paired_files(scg_plan* P, const char* path1, const char* path2, scg::
         try {
             const int threads = scg::default_host_threads(nthreads);
             // (two parallel gzip decoders share the host threads)
-            std::unique_ptr<scg::TextSource> s1 = scg::TextSource::open(path1, threads, parallel_gzip, std::max(2, threads / 2)),
-                                             s2 = scg::TextSource::open(path2, threads, parallel_gzip, std::max(2, threads / 2));
-            declined_gzip = is_parallel_gzip(s1.get()) || is_parallel_gzip(s2.get());
+            // (an ordinary gzip mate is decoded by the device when it is of the plain kind, one mate after the other; what
+            // the device hands back, and every other form, is opened the ordinary way)
+            auto open_mate = [&](const char* path) {
+                std::unique_ptr<scg::TextSource> s;
+                if (parallel_gzip && scg::TextSource::ordinary_gzip(path, threads)) {
+                    s = scg::TextSource::open_on_device(path, P->device, threads);
+                    const char* e = std::getenv("SCG_DEVICE_GUNZIP");          // (test hook, as for single-end input)
+                    if (!s && e && *e == '2') throw Error(SCG_ERR_UNSUPPORTED, "the device gzip decoder handed the file back (SCG_DEVICE_GUNZIP=2 forbids the fall-back)");
+                }
+                if (!s) s = scg::TextSource::open(path, threads, parallel_gzip, std::max(2, threads / 2));
+                return s;
+            };
+            std::unique_ptr<scg::TextSource> s1 = open_mate(path1), s2 = open_mate(path2);
+            declined_gzip = is_parallel_gzip(s1.get()) || is_parallel_gzip(s2.get()) || s1->device_resident() || s2->device_resident();
             bool device_inflate = try_device_inflate;
             for (;;) {
                 {

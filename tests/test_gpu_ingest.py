@@ -577,3 +577,36 @@ def test_ordinary_gzip_decoded_by_the_device(sc, oracle, gpu, tmp_path, monkeypa
         except sc.ScgError as e:
             got = ("error", e.code, str(e))
         assert got == want, k
+
+
+def test_paired_ordinary_gzip_mates_decoded_by_the_device(sc, oracle, gpu, tmp_path, monkeypatch):
+    """R1.fastq.gz / R2.fastq.gz as `gzip` writes them: each mate decoded on the device (one after the other), both texts
+    in HBM, windows paired by cursors as for any other paired input.  Also one gzip mate next to a plain one."""
+    import zlib
+    rng = random.Random(4343)
+    case = gen.random_dual_case(rng, hazard_free=True, sizes=(20000,), max_mm=1)
+    exp = oracle.count_dual(case["reads1"], case["reads2"], case["template1"], case["reverse1"], case["mismatches1"], case["pool1"],
+                            case["template2"], case["reverse2"], case["mismatches2"], case["pool2"], case["randomized"], case["use_first"])
+
+    def gz(data, level):
+        c = zlib.compressobj(level, zlib.DEFLATED, 31)
+        return c.compress(data) + c.flush()
+
+    t1, t2 = gen.fastq_text(case["reads1"]), gen.fastq_text(case["reads2"], name_prefix="a_longer_name_for_the_second_mate_")
+    p1, p2, plain2 = str(tmp_path / "r1.fastq.gz"), str(tmp_path / "r2.fastq.gz"), str(tmp_path / "r2.fastq")
+    open(p1, "wb").write(gz(t1, 6))
+    open(p2, "wb").write(gz(t2, 1))
+    open(plain2, "wb").write(t2)
+    monkeypatch.setenv("SCG_PGZIP_CHUNK_KB", "64")
+    monkeypatch.setenv("SCG_DGZIP_CHUNK_KB", "16")
+    monkeypatch.setenv("SCG_DEVICE_GUNZIP", "2")
+    for second in (p2, plain2):
+        for window_kb in (None, 100):
+            if window_kb:
+                monkeypatch.setenv("SCG_WINDOW_KB", str(window_kb))
+            else:
+                monkeypatch.delenv("SCG_WINDOW_KB", raising=False)
+            c, t = sc.count_dual_barcodes(p1, case["template1"], case["reverse1"], case["mismatches1"], case["pool1"],
+                                          second, case["template2"], case["reverse2"], case["mismatches2"], case["pool2"],
+                                          case["randomized"], case["use_first"], False, 4)
+            assert t == exp[1] and np.array_equal(c, exp[0]), (second, window_kb)
