@@ -1409,6 +1409,20 @@ void count_paired_host(scg_plan* P, const char* path1, const char* path2, scg::F
     st.drain();
 }
 
+// One mate of a paired run.  An ordinary gzip mate is decoded by the device when it is of the plain kind (one member), one
+// mate after the other; what the device hands back, and every other form, is opened the ordinary way (two parallel gzip
+// decoders share the host threads).
+std::unique_ptr<scg::TextSource> open_paired_mate(const char* path, int device, int threads, bool parallel_gzip) {
+    std::unique_ptr<scg::TextSource> s;
+    if (parallel_gzip && scg::TextSource::ordinary_gzip(path, threads)) {
+        s = scg::TextSource::open_on_device(path, device, threads);
+        const char* e = std::getenv("SCG_DEVICE_GUNZIP");          // (test hook, as for single-end input)
+        if (!s && e && *e == '2') throw Error(SCG_ERR_UNSUPPORTED, "the device gzip decoder handed the file back (SCG_DEVICE_GUNZIP=2 forbids the fall-back)");
+    }
+    if (!s) s = scg::TextSource::open(path, threads, parallel_gzip, std::max(2, threads / 2));
+    return s;
+}
+
 void count_paired_files(scg_plan* P, const char* path1, const char* path2, scg::FastqStream& fq1, scg::FastqStream& fq2, int nthreads,
                         bool try_device_inflate, bool parallel_gzip) {
     if (device_scan_enabled()) {
@@ -1417,19 +1431,8 @@ void count_paired_files(scg_plan* P, const char* path1, const char* path2, scg::
         try {
             const int threads = scg::default_host_threads(nthreads);
             // (two parallel gzip decoders share the host threads)
-            // (an ordinary gzip mate is decoded by the device when it is of the plain kind, one mate after the other; what
-            // the device hands back, and every other form, is opened the ordinary way)
-            auto open_mate = [&](const char* path) {
-                std::unique_ptr<scg::TextSource> s;
-                if (parallel_gzip && scg::TextSource::ordinary_gzip(path, threads)) {
-                    s = scg::TextSource::open_on_device(path, P->device, threads);
-                    const char* e = std::getenv("SCG_DEVICE_GUNZIP");          // (test hook, as for single-end input)
-                    if (!s && e && *e == '2') throw Error(SCG_ERR_UNSUPPORTED, "the device gzip decoder handed the file back (SCG_DEVICE_GUNZIP=2 forbids the fall-back)");
-                }
-                if (!s) s = scg::TextSource::open(path, threads, parallel_gzip, std::max(2, threads / 2));
-                return s;
-            };
-            std::unique_ptr<scg::TextSource> s1 = open_mate(path1), s2 = open_mate(path2);
+            std::unique_ptr<scg::TextSource> s1 = open_paired_mate(path1, P->device, threads, parallel_gzip),
+                                             s2 = open_paired_mate(path2, P->device, threads, parallel_gzip);
             declined_gzip = is_parallel_gzip(s1.get()) || is_parallel_gzip(s2.get()) || s1->device_resident() || s2->device_resident();
             bool device_inflate = try_device_inflate;
             for (;;) {
@@ -1484,8 +1487,8 @@ std::unique_ptr<PlanSet> compile_and_count_paired(const char* path1, const char*
         devices = devices_for_input(text_bytes_hint(path1) + text_bytes_hint(path2));
         if (device_scan_enabled()) {
             const int threads = scg::default_host_threads(nthreads, static_cast<int>(devices.size()));
-            s1 = scg::TextSource::open(path1, threads, true, std::max(2, threads / 2));
-            s2 = scg::TextSource::open(path2, threads, true, std::max(2, threads / 2));
+            s1 = open_paired_mate(path1, devices[0], threads, true);
+            s2 = open_paired_mate(path2, devices[0], threads, true);
             gzip_parallel = is_parallel_gzip(s1.get()) || is_parallel_gzip(s2.get());
             if (devices.size() > 1 && s1->parses() && s2->parses() && host_scan_enabled()) {
                 rounds.reset(new PairedRounds(devices, *s1, *s2));
