@@ -150,28 +150,112 @@ struct ScratchLease {
     ~ScratchLease() { release(); }
 };
 
+// The stream is decoded in GROUPS of chunks (512 MB of compressed bytes by default: the symbols of a group take 33 bytes per
+// compressed byte while it is decoded), each group like a file of its own except for what it takes over from the group
+// before: the bit position its first chunk starts at, and the end of the text before it -- the last 32 KiB (the window its
+// markers point into) or more (the records the scan has not taken yet), copied to the front of the new group's text.  The
+// CRC-32 and the length are known to be right only when the last group is through: a file that fails them then has been
+// counted in part already, and is redone by the host decoders like any other input that turns out unusual late.
 class DeviceGunzipSource : public TextSource {
     int dev;
-    DevMem text;                   // the whole text (+ 64 bytes)
-    uint64_t total = 0, pos = 0;
+    Mapping f;
+    uint64_t first_byte = 0, stream_end = 0;
+    uint32_t want_crc = 0, want_size = 0;
+    size_t chunk_bytes = 0;
+    uint64_t n_chunks = 0, cap_syms = 0, group_chunks = 0;
+    int host_threads = 1;
+    bool tr = false;
+    // progress through the stream
+    uint64_t next_chunk = 0, expect_bit = 0;
+    bool ended = false;
+    uLong crc_acc = 0;
+    uint64_t text_total = 0;
+    // the current group's text: [prefix: the end of the text before][the group's own], of which [0, pos) has been handed out
+    DevMem text;
+    uint64_t text_bytes = 0, pos = 0;
     std::vector<char> tail;        // host copy of a window's last stretch (where the cut is looked for)
+
 public:
-    DeviceGunzipSource(int device, DevMem&& t, uint64_t n) : dev(device), total(n) { text.p = t.p; t.p = nullptr; }
+    DeviceGunzipSource(const char* path, int device, int threads) : dev(device), f(path), host_threads(threads), tr(trace_on()) {}
     const char* kind() const override { return "gzip-device"; }
-    uint64_t size_hint() const override { return total - pos; }
+    uint64_t size_hint() const override { return (text_bytes - pos) + (ended ? 0 : (stream_end - std::min<uint64_t>(stream_end, first_byte + next_chunk * chunk_bytes)) * 8); }
     bool device_resident() const override { return true; }
     int device() const override { return dev; }
 
-    // How much text the next window of at most cap bytes takes; `last`: the input ends with it.
-    size_t window(size_t cap, bool& last, bool& pad) {
-        last = pad = false;
-        if (odd || pos >= total) return 0;
-        const uint64_t left = total - pos;
+    // The header, the sizes, and the first group.  False: not a file for this decoder.
+    bool begin() {
+        const bool test_hook = std::getenv("SCG_DGZIP_CHUNK_KB") != nullptr;       // (tiny chunks, tiny files)
+        if (!f.data || f.size < (test_hook ? size_t(64) : size_t(2) << 20)) return false;
+        const uint8_t* p = f.data;
+        // RFC 1952 header: deflate, no header CRC; name / comment / extra fields are skipped
+        if (p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || (p[3] & 0xE2)) return false;
+        size_t at = 10;
+        if (p[3] & 4) { if (at + 2 > f.size) return false; at += 2 + (p[at] | (static_cast<size_t>(p[at + 1]) << 8)); }
+        for (int field = 0; field < 2; ++field) {
+            if (p[3] & (field == 0 ? 8 : 16)) {
+                while (at < f.size && p[at]) ++at;
+                ++at;
+            }
+        }
+        if (at + 8 + 2 >= f.size) return false;
+        first_byte = at;
+        stream_end = f.size - 8;
+        const uint8_t* t = p + stream_end;
+        want_crc = t[0] | (uint32_t(t[1]) << 8) | (uint32_t(t[2]) << 16) | (uint32_t(t[3]) << 24);
+        want_size = t[4] | (uint32_t(t[5]) << 8) | (uint32_t(t[6]) << 16) | (uint32_t(t[7]) << 24);
+        chunk_bytes = size_t(128) << 10;
+        if (const char* e = std::getenv("SCG_DGZIP_CHUNK_KB")) { const long kb = std::atol(e); if (kb >= 4) chunk_bytes = static_cast<size_t>(kb) << 10; }
+        n_chunks = (stream_end - first_byte + chunk_bytes - 1) / chunk_bytes;
+        // a chunk decodes from its block start to the next chunk's: up to two chunks of input when a neighbour holds no block start
+        // (a DEFLATE block is 30-60 KB of compressed bytes as a rule: small chunks -- the tests' -- mostly hold no block start at all)
+        cap_syms = std::max<uint64_t>(chunk_bytes * 16, uint64_t(1) << 20) + 65536;
+        uint64_t group_bytes = uint64_t(512) << 20;                     // (its text must stay below 4 GB: the CRC pieces are indexed with 32 bits)
+        if (const char* e = std::getenv("SCG_DGZIP_GROUP_KB")) { const long kb = std::atol(e); if (kb >= 4) group_bytes = static_cast<uint64_t>(kb) << 10; }
+        group_chunks = std::max<uint64_t>(1, group_bytes / chunk_bytes);
+        expect_bit = first_byte * 8;
+        crc_acc = crc32(0L, Z_NULL, 0);
+        return next_group();
+    }
+
+    size_t next(char* dst, size_t cap) override {
+        bool pad;
+        size_t take = window(cap, pad);
+        if (!take) return 0;
+        if (hipMemcpy(dst, text.as<char>() + pos, take, hipMemcpyDeviceToHost) != hipSuccess) { odd = true; return 0; }
+        pos += take;
+        if (pad) dst[take++] = '\n';
+        return take;
+    }
+    size_t next_device(char* d_dst, size_t cap, void* stream) override {
+        bool pad;
+        size_t take = window(cap, pad);
+        if (!take) return 0;
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        if (hipMemcpyAsync(d_dst, text.as<char>() + pos, take, hipMemcpyDeviceToDevice, s) != hipSuccess) { odd = true; return 0; }
+        pos += take;
+        if (pad) {
+            if (hipMemsetAsync(d_dst + take, '\n', 1, s) != hipSuccess) { odd = true; return 0; }
+            ++take;
+        }
+        return take;
+    }
+
+private:
+    // How much text the next window of at most cap bytes takes (0: none, or odd set); pad: the input ends in it without a newline.
+    size_t window(size_t cap, bool& pad) {
+        pad = false;
+        if (odd) return 0;
+        // (the text in HBM is still being copied from by the windows handed out: they are stream-ordered copies, and the
+        // next group's decoding synchronises the device before the old text is let go)
+        while (text_bytes - pos + 1 <= cap && !ended) {
+            if (!next_group()) { odd = true; return 0; }
+        }
+        if (pos >= text_bytes) return 0;
+        const uint64_t left = text_bytes - pos;
         const size_t slack = size_t(1) << 20;
-        if (left + 1 <= cap) {
+        if (left + 1 <= cap) {                                          // (the stream has ended: the rest)
             char c = 0;
-            if (hipMemcpy(&c, text.as<char>() + total - 1, 1, hipMemcpyDeviceToHost) != hipSuccess) { odd = true; return 0; }
-            last = true;
+            if (hipMemcpy(&c, text.as<char>() + text_bytes - 1, 1, hipMemcpyDeviceToHost) != hipSuccess) { odd = true; return 0; }
             pad = c != '\n';
             return static_cast<size_t>(left);
         }
@@ -183,168 +267,148 @@ public:
         if (!cut) { odd = true; return 0; }
         return n - look + cut;
     }
-    size_t next(char* dst, size_t cap) override {
-        bool last, pad;
-        size_t take = window(cap, last, pad);
-        if (!take) return 0;
-        if (hipMemcpy(dst, text.as<char>() + pos, take, hipMemcpyDeviceToHost) != hipSuccess) { odd = true; return 0; }
-        pos += take;
-        if (pad) dst[take++] = '\n';
-        return take;
-    }
-    size_t next_device(char* d_dst, size_t cap, void* stream) override {
-        bool last, pad;
-        size_t take = window(cap, last, pad);
-        if (!take) return 0;
-        hipStream_t s = static_cast<hipStream_t>(stream);
-        if (hipMemcpyAsync(d_dst, text.as<char>() + pos, take, hipMemcpyDeviceToDevice, s) != hipSuccess) { odd = true; return 0; }
-        pos += take;
-        if (pad) {
-            if (hipMemsetAsync(d_dst + take, '\n', 1, s) != hipSuccess) { odd = true; return 0; }
-            ++take;
+
+    // Decodes the next group of chunks into a new text buffer (behind what the old one still holds).  False: declined.
+    bool next_group() {
+        const auto t0 = std::chrono::steady_clock::now();
+        auto ms = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
+        int before = 0;
+        (void)hipGetDevice(&before);
+        struct Restore { int d; ~Restore() { (void)hipSetDevice(d); } } restore{before};
+        try {
+            DGZ_CHECK(hipSetDevice(dev));
+            const uint64_t lo = next_chunk, hi = std::min(n_chunks, lo + group_chunks);
+            const bool last_group = hi == n_chunks;
+            // a few chunks of the next group are searched as well: the first of them with a block start says where this group ends
+            const uint64_t extra = last_group ? 0 : std::min<uint64_t>(8, n_chunks - hi);
+            const uint32_t n = static_cast<uint32_t>(hi - lo + extra), n_decode = static_cast<uint32_t>(hi - lo);
+            const uint64_t a = lo == 0 ? 0 : (expect_bit >> 3);                      // bytes [a, b) of the file go to the device
+            const uint64_t b = last_group ? f.size : std::min<uint64_t>(f.size, first_byte + (hi + extra) * chunk_bytes + 8192);
+            size_t free_bytes = 0, total_bytes = 0;
+            DGZ_CHECK(hipMemGetInfo(&free_bytes, &total_bytes));
+            const size_t in_bytes = static_cast<size_t>(b - a) + 64, sym_bytes = cap_syms * n_decode * sizeof(uint16_t);
+            ScratchLease lease(dev, in_bytes, sym_bytes);
+            if (in_bytes + sym_bytes + (b - a) * 12 > free_bytes + lease.s->in_bytes + lease.s->sym_bytes) return false;
+            const View d_in{lease.s->d_in}, d_syms{lease.s->d_syms};
+            DevMem d_chunks;
+            d_chunks.alloc(sizeof(GunzipChunk) * n);
+            // the bytes into HBM through two pinned buffers filled by a few threads each
+            {
+                const size_t piece = BOUNCE_BYTES;
+                hipEvent_t done[2];
+                for (int k = 0; k < 2; ++k) DGZ_CHECK(hipEventCreateWithFlags(&done[k], hipEventDisableTiming));
+                const int nt = std::max(1, std::min(host_threads, 8));
+                uint64_t off = a;
+                for (int k = 0; off < b; ++k, off += piece) {
+                    const size_t len = static_cast<size_t>(std::min<uint64_t>(piece, b - off));
+                    char* const dst = static_cast<char*>(lease.s->bounce[k & 1]);
+                    if (k >= 2) DGZ_CHECK(hipEventSynchronize(done[k & 1]));
+                    std::vector<std::thread> th;
+                    for (int i = 0; i < nt; ++i) {
+                        th.emplace_back([&, i] {
+                            const size_t x = len * i / nt, y = len * (i + 1) / nt;
+                            std::memcpy(dst + x, f.data + off + x, y - x);
+                            // (pages that are not read again lose their entries here, in parallel, not in the final munmap;
+                            // the stretch the next group starts in, and the header and trailer, stay)
+                            const uintptr_t page = 4096;
+                            const uintptr_t l = (reinterpret_cast<uintptr_t>(f.data + off + x) + page - 1) & ~(page - 1);
+                            const uintptr_t h = reinterpret_cast<uintptr_t>(f.data + off + y) & ~(page - 1);
+                            const uint64_t keep_from = last_group ? f.size - 4096 : first_byte + hi * chunk_bytes - 4096;
+                            if (h > l && off + x >= 4096 && off + y <= keep_from) (void)::madvise(reinterpret_cast<void*>(l), h - l, MADV_DONTNEED);
+                        });
+                    }
+                    for (auto& t : th) t.join();
+                    DGZ_CHECK(hipMemcpyAsync(d_in.as<char>() + (off - a), dst, len, hipMemcpyHostToDevice, nullptr));
+                    DGZ_CHECK(hipEventRecord(done[k & 1], nullptr));
+                }
+                DGZ_CHECK(hipMemsetAsync(d_in.as<char>() + (b - a), 0, 64, nullptr));
+                DGZ_CHECK(hipStreamSynchronize(nullptr));
+                for (int k = 0; k < 2; ++k) (void)hipEventDestroy(done[k]);
+            }
+            if (tr) std::fprintf(stderr, "[scg]   gzip on the device: chunks %llu-%llu of %llu (%zu KB each), their bytes in HBM after %.2f ms\n",
+                                 (unsigned long long)lo, (unsigned long long)hi, (unsigned long long)n_chunks, chunk_bytes >> 10, ms());
+            std::vector<GunzipChunk> chunks(n);
+            std::memset(chunks.data(), 0, sizeof(GunzipChunk) * n);
+            chunks[0].start_bit = expect_bit;
+            DGZ_CHECK(hipMemcpy(d_chunks.p, chunks.data(), sizeof(GunzipChunk) * n, hipMemcpyHostToDevice));
+            DGZ_CHECK(launch_gunzip_find(d_in.as<uint8_t>(), a, b, d_chunks.as<GunzipChunk>(), n, lo, first_byte, chunk_bytes, stream_end, nullptr));
+            DGZ_CHECK(launch_gunzip_decode(d_in.as<uint8_t>(), a, b, d_chunks.as<GunzipChunk>(), n, n_decode, d_syms.as<uint16_t>(), cap_syms, nullptr));
+            DGZ_CHECK(hipMemcpy(chunks.data(), d_chunks.p, sizeof(GunzipChunk) * n, hipMemcpyDeviceToHost));
+            if (tr) std::fprintf(stderr, "[scg]   gzip on the device: chunks decoded after %.2f ms\n", ms());
+            // the chain: every chunk ends where the next one (that found a block start) begins; the last group's last ends the stream
+            const uint64_t keep = text_bytes - pos;                                   // what the scan has not taken yet
+            const uint64_t prefix = text_bytes == 0 ? 0 : std::max<uint64_t>(keep, std::min<uint64_t>(text_bytes, 32768));
+            std::vector<uint64_t> text_at(n_decode);
+            uint64_t expect = expect_bit, made = 0;
+            bool final_seen = false;
+            for (uint32_t c = 0; c < n_decode; ++c) {
+                text_at[c] = prefix + made;
+                if (chunks[c].start_bit == ~uint64_t(0)) continue;
+                if (final_seen || chunks[c].status != scginf::INFLATE_OK || chunks[c].start_bit != expect) return false;
+                expect = chunks[c].end_bit;
+                made += chunks[c].made;
+                final_seen = chunks[c].final_block != 0;
+            }
+            if (made == 0 || prefix + made + 64 >= (uint64_t(1) << 32)) return false;       // (the scan's windows and the CRC pieces index the text with 32 bits)
+            uint64_t resume = n_chunks;
+            if (final_seen) {
+                if (((expect + 7) >> 3) != stream_end) return false;                  // (more members, or trailing bytes: not for this decoder)
+            } else {
+                if (last_group) return false;
+                resume = 0;
+                for (uint32_t c = n_decode; c < n; ++c) {
+                    if (chunks[c].start_bit != ~uint64_t(0)) { resume = lo + c; break; }
+                }
+                if (!resume || chunks[resume - lo].start_bit != expect) return false;   // (the group did not end where the next begins)
+            }
+            // the new text: the end of the old one in front, then this group's
+            DevMem fresh, d_at, d_status, d_pieces, d_crcs;
+            fresh.alloc(prefix + made + 64);
+            if (prefix) DGZ_CHECK(hipMemcpy(fresh.p, text.as<char>() + (text_bytes - prefix), prefix, hipMemcpyDeviceToDevice));
+            d_at.alloc(sizeof(uint64_t) * n_decode);
+            d_status.alloc(sizeof(uint32_t));
+            DGZ_CHECK(hipMemcpy(d_at.p, text_at.data(), sizeof(uint64_t) * n_decode, hipMemcpyHostToDevice));
+            DGZ_CHECK(hipMemset(d_status.p, 0, sizeof(uint32_t)));
+            DGZ_CHECK(launch_gunzip_text(d_syms.as<uint16_t>(), cap_syms, d_chunks.as<GunzipChunk>(), d_at.as<uint64_t>(), n_decode, fresh.as<char>(),
+                                         d_status.as<uint32_t>(), nullptr));
+            // CRC-32: pieces of 4 MB on the device, combined here like zlib's crc32_combine
+            const uint64_t piece = uint64_t(4) << 20;
+            const uint32_t np = static_cast<uint32_t>((made + piece - 1) / piece);
+            std::vector<InflateMember> pieces(np);
+            for (uint32_t i = 0; i < np; ++i) {
+                pieces[i].in_off = pieces[i].in_len = 0;
+                pieces[i].out_off = static_cast<uint32_t>(prefix + piece * i);
+                pieces[i].out_len = static_cast<uint32_t>(std::min<uint64_t>(piece, made - piece * i));
+                pieces[i].crc = 0;
+            }
+            d_pieces.alloc(sizeof(InflateMember) * np);
+            d_crcs.alloc(sizeof(uint32_t) * np);
+            DGZ_CHECK(hipMemcpy(d_pieces.p, pieces.data(), sizeof(InflateMember) * np, hipMemcpyHostToDevice));
+            DGZ_CHECK(launch_crc_pieces(fresh.as<char>(), d_pieces.as<InflateMember>(), np, d_crcs.as<uint32_t>(), nullptr));
+            std::vector<uint32_t> crcs(np);
+            uint32_t status = 0;
+            DGZ_CHECK(hipMemcpy(crcs.data(), d_crcs.p, sizeof(uint32_t) * np, hipMemcpyDeviceToHost));
+            DGZ_CHECK(hipMemcpy(&status, d_status.p, sizeof(uint32_t), hipMemcpyDeviceToHost));
+            if (status) return false;
+            for (uint32_t i = 0; i < np; ++i) crc_acc = crc32_combine(crc_acc, crcs[i], static_cast<z_off_t>(pieces[i].out_len));
+            text_total += made;
+            if (final_seen && (static_cast<uint32_t>(crc_acc) != want_crc || static_cast<uint32_t>(text_total) != want_size)) return false;
+            // (every copy out of the old text was enqueued before this point and the device has been synchronised since)
+            DGZ_CHECK(hipDeviceSynchronize());
+            if (text.p) { (void)hipFree(text.p); text.p = nullptr; }
+            text.p = fresh.p; fresh.p = nullptr;
+            pos = prefix - keep;
+            text_bytes = prefix + made;
+            ended = final_seen;
+            next_chunk = resume;
+            expect_bit = expect;
+            if (tr) std::fprintf(stderr, "[scg]   gzip on the device: %.2f GB of text in HBM%s after %.2f ms\n", made / 1e9, ended ? ", CRC-32 checked," : "", ms());
+            return true;
+        } catch (const Declined&) {
+            return false;
         }
-        return take;
     }
 };
-
-std::unique_ptr<TextSource> decode(const char* path, int device, int threads) {
-    const bool tr = trace_on();
-    const auto t0 = std::chrono::steady_clock::now();
-    auto ms = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
-    Mapping f(path);
-    const bool test_hook = std::getenv("SCG_DGZIP_CHUNK_KB") != nullptr;       // (tiny chunks, tiny files)
-    if (!f.data || f.size < (test_hook ? size_t(64) : size_t(2) << 20) || f.size > (size_t(2) << 30)) return nullptr;
-    const uint8_t* p = f.data;
-    // RFC 1952 header: deflate, no header CRC; name / comment / extra fields are skipped
-    if (p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || (p[3] & 0xE2)) return nullptr;
-    size_t at = 10;
-    if (p[3] & 4) { if (at + 2 > f.size) return nullptr; at += 2 + (p[at] | (static_cast<size_t>(p[at + 1]) << 8)); }
-    for (int field = 0; field < 2; ++field) {
-        if (p[3] & (field == 0 ? 8 : 16)) {
-            while (at < f.size && p[at]) ++at;
-            ++at;
-        }
-    }
-    if (at + 8 + 2 >= f.size) return nullptr;
-    const uint64_t first_byte = at, stream_end = f.size - 8;
-    const uint8_t* t = p + stream_end;
-    const uint32_t want_crc = t[0] | (uint32_t(t[1]) << 8) | (uint32_t(t[2]) << 16) | (uint32_t(t[3]) << 24);
-    const uint32_t want_size = t[4] | (uint32_t(t[5]) << 8) | (uint32_t(t[6]) << 16) | (uint32_t(t[7]) << 24);
-
-    size_t chunk_bytes = size_t(128) << 10;
-    if (const char* e = std::getenv("SCG_DGZIP_CHUNK_KB")) { const long kb = std::atol(e); if (kb >= 4) chunk_bytes = static_cast<size_t>(kb) << 10; }
-    const uint32_t n = static_cast<uint32_t>((stream_end - first_byte + chunk_bytes - 1) / chunk_bytes);
-    // a chunk decodes from its block start to the next chunk's: up to two chunks of input when a neighbour holds no block start
-    // (a DEFLATE block is 30-60 KB of compressed bytes as a rule: small chunks -- the tests' -- mostly hold no block start at all)
-    const uint64_t cap_syms = std::max<uint64_t>(chunk_bytes * 16, uint64_t(1) << 20) + 65536;
-
-    int before = 0;
-    (void)hipGetDevice(&before);
-    struct Restore { int d; ~Restore() { (void)hipSetDevice(d); } } restore{before};
-    try {
-        DGZ_CHECK(hipSetDevice(device));
-        // (not more than the card has to spare: the symbols take 32 bytes per compressed byte)
-        size_t free_bytes = 0, total_bytes = 0;
-        DGZ_CHECK(hipMemGetInfo(&free_bytes, &total_bytes));
-        const size_t need = f.size + 64 + cap_syms * n * sizeof(uint16_t) + f.size * 12;
-        ScratchLease lease(device, f.size + 64, cap_syms * n * sizeof(uint16_t));
-        if (need > free_bytes + lease.s->in_bytes + lease.s->sym_bytes) return nullptr;
-        const View d_in{lease.s->d_in}, d_syms{lease.s->d_syms};
-        DevMem d_chunks;
-        d_chunks.alloc(sizeof(GunzipChunk) * n);
-        // the file into HBM through two pinned buffers filled by a few threads each
-        {
-            const size_t piece = BOUNCE_BYTES;
-            struct { void* p; } bounce[2] = {{lease.s->bounce[0]}, {lease.s->bounce[1]}};
-            hipEvent_t done[2];
-            for (int k = 0; k < 2; ++k) DGZ_CHECK(hipEventCreateWithFlags(&done[k], hipEventDisableTiming));
-            const int nt = std::max(1, std::min(threads, 8));
-            size_t off = 0;
-            for (int k = 0; off < f.size; ++k, off += piece) {
-                const size_t len = std::min(piece, f.size - off);
-                const int b = k & 1;
-                if (k >= 2) DGZ_CHECK(hipEventSynchronize(done[b]));
-                std::vector<std::thread> th;
-                for (int i = 0; i < nt; ++i) {
-                    th.emplace_back([&, i] {
-                        const size_t a = len * i / nt, e = len * (i + 1) / nt;
-                        std::memcpy(static_cast<char*>(bounce[b].p) + a, f.data + off + a, e - a);
-                        // (the pages are not read again: their entries go here, in parallel, not in the final munmap)
-                        const uintptr_t page = 4096;
-                        const uintptr_t lo = (reinterpret_cast<uintptr_t>(f.data + off + a) + page - 1) & ~(page - 1);
-                        const uintptr_t hi = reinterpret_cast<uintptr_t>(f.data + off + e) & ~(page - 1);
-                        if (hi > lo && off + a >= 4096 && off + e + 4096 <= f.size) (void)::madvise(reinterpret_cast<void*>(lo), hi - lo, MADV_DONTNEED);
-                    });
-                }
-                for (auto& x : th) x.join();
-                DGZ_CHECK(hipMemcpyAsync(d_in.as<char>() + off, bounce[b].p, len, hipMemcpyHostToDevice, nullptr));
-                DGZ_CHECK(hipEventRecord(done[b], nullptr));
-            }
-            DGZ_CHECK(hipMemsetAsync(d_in.as<char>() + f.size, 0, 64, nullptr));
-            DGZ_CHECK(hipStreamSynchronize(nullptr));
-            for (int k = 0; k < 2; ++k) (void)hipEventDestroy(done[k]);
-        }
-        if (tr) std::fprintf(stderr, "[scg]   gzip on the device: %u chunks of %zu KB, file in HBM after %.2f ms\n", n, chunk_bytes >> 10, ms());
-        std::vector<GunzipChunk> chunks(n);
-        std::memset(chunks.data(), 0, sizeof(GunzipChunk) * n);
-        chunks[0].start_bit = first_byte * 8;
-        DGZ_CHECK(hipMemcpy(d_chunks.p, chunks.data(), sizeof(GunzipChunk) * n, hipMemcpyHostToDevice));
-        DGZ_CHECK(launch_gunzip_find(d_in.as<uint8_t>(), f.size, d_chunks.as<GunzipChunk>(), n, first_byte, chunk_bytes, stream_end, nullptr));
-        DGZ_CHECK(launch_gunzip_decode(d_in.as<uint8_t>(), f.size, d_chunks.as<GunzipChunk>(), n, d_syms.as<uint16_t>(), cap_syms, nullptr));
-        DGZ_CHECK(hipMemcpy(chunks.data(), d_chunks.p, sizeof(GunzipChunk) * n, hipMemcpyDeviceToHost));
-        if (tr) std::fprintf(stderr, "[scg]   gzip on the device: chunks decoded after %.2f ms\n", ms());
-        // the chain: every chunk ends where the next one (that found a block start) begins, the last one ends the stream
-        std::vector<uint64_t> text_at(n);
-        uint64_t expect = first_byte * 8, total = 0;
-        bool ended = false;
-        for (uint32_t c = 0; c < n; ++c) {
-            text_at[c] = total;
-            if (chunks[c].start_bit == ~uint64_t(0)) continue;
-            if (ended || chunks[c].status != scginf::INFLATE_OK || chunks[c].start_bit != expect) return nullptr;
-            expect = chunks[c].end_bit;
-            total += chunks[c].made;
-            ended = chunks[c].final_block != 0;
-        }
-        if (!ended || ((expect + 7) >> 3) != stream_end) return nullptr;            // (more members, or trailing bytes: not for this decoder)
-        if (static_cast<uint32_t>(total) != want_size || total == 0 || total >= (uint64_t(1) << 32) - (uint64_t(1) << 26)) return nullptr;
-        DevMem d_text, d_at, d_status, d_pieces, d_crcs;
-        d_text.alloc(total + 64);
-        d_at.alloc(sizeof(uint64_t) * n);
-        d_status.alloc(sizeof(uint32_t));
-        if (tr) { DGZ_CHECK(hipDeviceSynchronize()); std::fprintf(stderr, "[scg]   gzip on the device: text buffer allocated after %.2f ms\n", ms()); }
-        DGZ_CHECK(hipMemcpy(d_at.p, text_at.data(), sizeof(uint64_t) * n, hipMemcpyHostToDevice));
-        DGZ_CHECK(hipMemset(d_status.p, 0, sizeof(uint32_t)));
-        DGZ_CHECK(launch_gunzip_text(d_syms.as<uint16_t>(), cap_syms, d_chunks.as<GunzipChunk>(), d_at.as<uint64_t>(), n, d_text.as<char>(),
-                                     d_status.as<uint32_t>(), nullptr));
-        if (tr) { DGZ_CHECK(hipDeviceSynchronize()); std::fprintf(stderr, "[scg]   gzip on the device: symbols turned into text after %.2f ms\n", ms()); }
-        // CRC-32: pieces of 4 MB on the device, combined here like zlib's crc32_combine
-        const uint64_t piece = uint64_t(4) << 20;
-        const uint32_t np = static_cast<uint32_t>((total + piece - 1) / piece);
-        std::vector<InflateMember> pieces(np);
-        for (uint32_t i = 0; i < np; ++i) {
-            pieces[i].in_off = pieces[i].in_len = 0;
-            pieces[i].out_off = static_cast<uint32_t>(piece * i);
-            pieces[i].out_len = static_cast<uint32_t>(std::min<uint64_t>(piece, total - piece * i));
-            pieces[i].crc = 0;
-        }
-        d_pieces.alloc(sizeof(InflateMember) * np);
-        d_crcs.alloc(sizeof(uint32_t) * np);
-        DGZ_CHECK(hipMemcpy(d_pieces.p, pieces.data(), sizeof(InflateMember) * np, hipMemcpyHostToDevice));
-        DGZ_CHECK(launch_crc_pieces(d_text.as<char>(), d_pieces.as<InflateMember>(), np, d_crcs.as<uint32_t>(), nullptr));
-        std::vector<uint32_t> crcs(np);
-        uint32_t status = 0;
-        DGZ_CHECK(hipMemcpy(crcs.data(), d_crcs.p, sizeof(uint32_t) * np, hipMemcpyDeviceToHost));
-        DGZ_CHECK(hipMemcpy(&status, d_status.p, sizeof(uint32_t), hipMemcpyDeviceToHost));
-        if (status) return nullptr;
-        uLong crc = crc32(0L, Z_NULL, 0);
-        for (uint32_t i = 0; i < np; ++i) crc = crc32_combine(crc, crcs[i], static_cast<z_off_t>(pieces[i].out_len));
-        if (static_cast<uint32_t>(crc) != want_crc) return nullptr;
-        if (tr) std::fprintf(stderr, "[scg]   gzip on the device: %.2f GB of text in HBM, CRC-32 checked, after %.2f ms\n", total / 1e9, ms());
-        return std::unique_ptr<TextSource>(new DeviceGunzipSource(device, std::move(d_text), total));
-    } catch (const Declined&) {
-        return nullptr;
-    }
-}
 
 } // namespace
 
@@ -356,7 +420,9 @@ void release_device_gunzip_scratch() {
 std::unique_ptr<TextSource> TextSource::open_on_device(const char* path, int device, int threads) {
     const char* e = std::getenv("SCG_DEVICE_GUNZIP");
     if (e && *e == '0') return nullptr;
-    return decode(path, device, threads);
+    std::unique_ptr<DeviceGunzipSource> s(new DeviceGunzipSource(path, device, threads));
+    if (!s->begin()) return nullptr;
+    return std::unique_ptr<TextSource>(s.release());
 }
 
 } // namespace scg

@@ -598,15 +598,18 @@ __global__ __launch_bounds__(INFLATE_BLOCK, SCG_INFLATE_WAVES) void inflate_memb
 //                          markers point into the 32 KiB before the chunk, which are text by then);
 //   gunzip_resolve_kernel  everything else becomes text, all chunks at once.
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(INFLATE_BLOCK) void gunzip_find_kernel(const uint8_t* __restrict__ in, uint64_t size, scg::GunzipChunk* __restrict__ chunks,
-                                                                    uint32_t n, uint64_t first_byte, uint64_t chunk_bytes, uint64_t stream_end_byte) {
+// `in` holds the file's bytes [origin, size); chunks[k] is chunk number chunk0 + k of the stream (a group of a long file).
+__global__ __launch_bounds__(INFLATE_BLOCK) void gunzip_find_kernel(const uint8_t* __restrict__ in_slice, uint64_t origin, uint64_t size,
+                                                                    scg::GunzipChunk* __restrict__ chunks, uint32_t n, uint64_t chunk0, uint64_t first_byte,
+                                                                    uint64_t chunk_bytes, uint64_t stream_end_byte) {
     __shared__ WaveTables tables;
     using namespace scginf;
-    const uint32_t c = blockIdx.x + 1;           // chunk 0 starts where the stream starts
+    const uint8_t* in = in_slice - origin;       // (indexed by the file's own byte positions, all >= origin)
+    const uint32_t c = blockIdx.x + 1;           // the group's first chunk starts where the one before ended
     if (c >= n) return;
     const uint32_t lane = threadIdx.x;
     uint8_t* const lens = reinterpret_cast<uint8_t*>(tables.lit);
-    const uint64_t from = (first_byte + chunk_bytes * c) * 8u;
+    const uint64_t from = (first_byte + chunk_bytes * (chunk0 + c)) * 8u;
     uint64_t to = from + chunk_bytes * 8u;
     if (to > stream_end_byte * 8u) to = stream_end_byte * 8u;
     uint64_t found = ~0ull;
@@ -648,13 +651,16 @@ __global__ __launch_bounds__(INFLATE_BLOCK) void gunzip_find_kernel(const uint8_
     if (lane == 0) chunks[c].start_bit = found;
 }
 
-__global__ __launch_bounds__(INFLATE_BLOCK, SCG_INFLATE_WAVES) void gunzip_decode_kernel(const uint8_t* __restrict__ in, uint64_t size,
-                                                                                        scg::GunzipChunk* __restrict__ chunks, uint32_t n,
+// (chunks[0 .. n) are searched; the first n_decode of them are decoded: the rest belong to the next group and only say where
+// this group's last chunk has to stop)
+__global__ __launch_bounds__(INFLATE_BLOCK, SCG_INFLATE_WAVES) void gunzip_decode_kernel(const uint8_t* __restrict__ in_slice, uint64_t origin, uint64_t size,
+                                                                                        scg::GunzipChunk* __restrict__ chunks, uint32_t n, uint32_t n_decode,
                                                                                         uint16_t* __restrict__ syms, uint64_t cap_syms) {
     __shared__ WaveTables tables;
     __shared__ WaveStage stage;
+    const uint8_t* in = in_slice - origin;
     const uint32_t c = blockIdx.x;
-    if (c >= n) return;
+    if (c >= n_decode) return;
     const uint64_t start = chunks[c].start_bit;
     if (start == ~0ull) {                                               // no block starts here: the chunk before decodes through
         if (threadIdx.x == 0) { chunks[c].made = 0; chunks[c].status = 0; chunks[c].end_bit = ~0ull; chunks[c].final_block = 0; }
@@ -693,6 +699,11 @@ __global__ __launch_bounds__(TAILS_BLOCK) void gunzip_tails_kernel(const uint16_
     __shared__ uint8_t win[2][MARKER_WINDOW];
     uint32_t cur = 0;
     bool have = false;                           // win[cur] holds the 32 KiB of text in front of the next chunk
+    if (n && text_at[0] >= MARKER_WINDOW) {      // (a later group of a long file: the end of the text before it lies in front)
+        for (uint32_t i = threadIdx.x; i < MARKER_WINDOW; i += TAILS_BLOCK) win[0][i] = text[text_at[0] - MARKER_WINDOW + i];
+        __syncthreads();
+        have = true;
+    }
     for (uint32_t c = 0; c < n; ++c) {
         const uint32_t made = chunks[c].made;
         if (made == 0) continue;                 // (no block began in this chunk: the one before decoded through it)
@@ -902,15 +913,17 @@ hipError_t launch_inflate_members(const uint8_t* d_in, const InflateMember* d_me
     return hipGetLastError();
 }
 
-hipError_t launch_gunzip_find(const uint8_t* d_in, uint64_t size, GunzipChunk* d_chunks, uint32_t n, uint64_t first_byte, uint64_t chunk_bytes,
-                              uint64_t stream_end_byte, hipStream_t stream) {
+hipError_t launch_gunzip_find(const uint8_t* d_in, uint64_t origin, uint64_t size, GunzipChunk* d_chunks, uint32_t n, uint64_t chunk0, uint64_t first_byte,
+                              uint64_t chunk_bytes, uint64_t stream_end_byte, hipStream_t stream) {
     if (n <= 1) return hipSuccess;
-    hipLaunchKernelGGL(gunzip_find_kernel, dim3(n - 1), dim3(INFLATE_BLOCK), 0, stream, d_in, size, d_chunks, n, first_byte, chunk_bytes, stream_end_byte);
+    hipLaunchKernelGGL(gunzip_find_kernel, dim3(n - 1), dim3(INFLATE_BLOCK), 0, stream, d_in, origin, size, d_chunks, n, chunk0, first_byte, chunk_bytes,
+                       stream_end_byte);
     return hipGetLastError();
 }
-hipError_t launch_gunzip_decode(const uint8_t* d_in, uint64_t size, GunzipChunk* d_chunks, uint32_t n, uint16_t* d_syms, uint64_t cap_syms, hipStream_t stream) {
-    if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(gunzip_decode_kernel, dim3(n), dim3(INFLATE_BLOCK), 0, stream, d_in, size, d_chunks, n, d_syms, cap_syms);
+hipError_t launch_gunzip_decode(const uint8_t* d_in, uint64_t origin, uint64_t size, GunzipChunk* d_chunks, uint32_t n, uint32_t n_decode, uint16_t* d_syms,
+                                uint64_t cap_syms, hipStream_t stream) {
+    if (n_decode == 0) return hipSuccess;
+    hipLaunchKernelGGL(gunzip_decode_kernel, dim3(n_decode), dim3(INFLATE_BLOCK), 0, stream, d_in, origin, size, d_chunks, n, n_decode, d_syms, cap_syms);
     return hipGetLastError();
 }
 hipError_t launch_gunzip_text(const uint16_t* d_syms, uint64_t cap_syms, const GunzipChunk* d_chunks, const uint64_t* d_text_at, uint32_t n, char* d_text,

@@ -1257,8 +1257,10 @@ __global__ __launch_bounds__(BLOCK) void hot_fold_kernel(int32_t* __restrict__ h
     for (int which = 0; which < 2; ++which) {
         int acc = 0;
         for (int i = threadIdx.x; i < SCG_HOT_SLOTS; i += BLOCK) {
-            acc += hot[which * SCG_HOT_SLOTS + i];
-            hot[which * SCG_HOT_SLOTS + i] = 0;
+            // (exchanged, not loaded and stored: the diagnostics kernel of another stream may be adding to the slot right now;
+            // and looked at through L2: see fold_kernel)
+            int32_t* p = hot + which * SCG_HOT_SLOTS + i;
+            if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) acc += atomicExch(p, 0);
         }
         for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
         if ((threadIdx.x & 63) == 0) sums[which][threadIdx.x >> 6] = acc;
@@ -1271,6 +1273,11 @@ __global__ __launch_bounds__(BLOCK) void hot_fold_kernel(int32_t* __restrict__ h
     }
 }
 
+// The "is there anything in this replica" look goes to L2 (an agent-scope atomic load), not through the CU's vector cache:
+// the folds and counting kernels of a file's windows overlap on several streams, and a line of zeros that an earlier
+// wavefront of another launch left in this CU's L1 hid the counts a kernel had added since -- they stayed in the replicas,
+// and when it was the call's last fold they were missing from the result: four neighbouring counters (one 64-byte line of
+// a 4-replica array) a few reads short, once in 30 000 calls with 100 KB windows (tools/stress_bgzf.py).
 __global__ __launch_bounds__(BLOCK) void fold_kernel(int32_t* __restrict__ replicas, int shift, int64_t n,
                                                      int32_t* __restrict__ counters) {
     const int R = 1 << shift;
@@ -1280,7 +1287,7 @@ __global__ __launch_bounds__(BLOCK) void fold_kernel(int32_t* __restrict__ repli
         int32_t* p = replicas + (i << shift);
         int32_t sum = 0;
         for (int r = 0; r < R; ++r) {
-            if (p[r]) sum += atomicExch(p + r, 0);
+            if (__hip_atomic_load(p + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) sum += atomicExch(p + r, 0);
         }
         if (sum) atomicAdd(&counters[i], sum);
     } else {
@@ -1290,7 +1297,7 @@ __global__ __launch_bounds__(BLOCK) void fold_kernel(int32_t* __restrict__ repli
         int32_t* p = replicas + (i << shift);
         int32_t sum = 0;
         for (int r = lane; r < R; r += 64) {
-            if (p[r]) sum += atomicExch(p + r, 0);
+            if (__hip_atomic_load(p + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) sum += atomicExch(p + r, 0);
         }
         for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
         if (lane == 0 && sum) atomicAdd(&counters[i], sum);

@@ -1218,6 +1218,7 @@ std::unique_ptr<PlanSet> compile_and_count_single_end(const char* path, scg::Fas
     bool retry_gzip = parallel_gzip_declined;
     if (pipe) {
         const bool parallel = is_parallel_gzip(src.get());
+        const bool was_on_device = src && src->device_resident();
         try {
             pipe->run(set->all());
             done = true;
@@ -1227,6 +1228,21 @@ std::unique_ptr<PlanSet> compile_and_count_single_end(const char* path, scg::Fas
             retry_gzip = parallel;
         }
         pipe.reset();
+        if (!done && was_on_device) {
+            // the device's gzip decoder gave up on a later group of the file (or the text is not ordinary records): the host
+            // threads' decoder next, with its own fall-backs behind it
+            try {
+                src = scg::TextSource::open(path, scg::default_host_threads(nthreads));
+                retry_gzip = is_parallel_gzip(src.get());
+                pipe.reset(new TextPipeline(*src, devices));
+                pipe->run(set->all());
+                done = true;
+            } catch (const UnusualInput&) {
+                pipe.reset();
+                set->reset();
+            }
+            pipe.reset();
+        }
     }
     if (!done && retry_gzip) {
         // the parallel gzip decoder handed the file back: one inflate stream, records scanned on the device

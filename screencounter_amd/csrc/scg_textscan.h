@@ -96,9 +96,12 @@ struct GunzipChunk {
     uint32_t final_block;         // its last block was the stream's last
     uint32_t pad;
 };
-hipError_t launch_gunzip_find(const uint8_t* d_in, uint64_t size, GunzipChunk* d_chunks, uint32_t n, uint64_t first_byte, uint64_t chunk_bytes,
-                              uint64_t stream_end_byte, hipStream_t stream);
-hipError_t launch_gunzip_decode(const uint8_t* d_in, uint64_t size, GunzipChunk* d_chunks, uint32_t n, uint16_t* d_syms, uint64_t cap_syms, hipStream_t stream);
+// d_in holds the file's bytes [origin, size); d_chunks[k] is chunk chunk0 + k of the stream; all n are searched for their block
+// starts (but the first, whose start is given), the first n_decode decoded.
+hipError_t launch_gunzip_find(const uint8_t* d_in, uint64_t origin, uint64_t size, GunzipChunk* d_chunks, uint32_t n, uint64_t chunk0, uint64_t first_byte,
+                              uint64_t chunk_bytes, uint64_t stream_end_byte, hipStream_t stream);
+hipError_t launch_gunzip_decode(const uint8_t* d_in, uint64_t origin, uint64_t size, GunzipChunk* d_chunks, uint32_t n, uint32_t n_decode, uint16_t* d_syms,
+                                uint64_t cap_syms, hipStream_t stream);
 hipError_t launch_gunzip_text(const uint16_t* d_syms, uint64_t cap_syms, const GunzipChunk* d_chunks, const uint64_t* d_text_at, uint32_t n, char* d_text,
                               uint32_t* d_status, hipStream_t stream);
 hipError_t launch_crc_pieces(const char* d_text, const InflateMember* d_members, uint32_t n, uint32_t* d_crcs, hipStream_t stream);

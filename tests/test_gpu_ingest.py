@@ -524,10 +524,14 @@ def test_ordinary_gzip_decoded_by_the_device(sc, oracle, gpu, tmp_path, monkeypa
     monkeypatch.setenv("SCG_PGZIP_CHUNK_KB", "64")                 # (these files are small: let the chunked decoders have them)
     p = str(tmp_path / "one.fastq.gz")
     for level in (1, 4, 6, 9):
-        for chunk_kb in (4, 16, 128):
+        for chunk_kb, group_kb in ((4, None), (16, 256), (128, None), (32, 128)):    # (group_kb: the stream decoded in several groups of chunks)
             for window_kb in (None, 100):
                 open(p, "wb").write(gz(text, level))
                 monkeypatch.setenv("SCG_DGZIP_CHUNK_KB", str(chunk_kb))
+                if group_kb:
+                    monkeypatch.setenv("SCG_DGZIP_GROUP_KB", str(group_kb))
+                else:
+                    monkeypatch.delenv("SCG_DGZIP_GROUP_KB", raising=False)
                 monkeypatch.setenv("SCG_DEVICE_GUNZIP", "2")
                 if window_kb:
                     monkeypatch.setenv("SCG_WINDOW_KB", str(window_kb))
@@ -536,9 +540,10 @@ def test_ordinary_gzip_decoded_by_the_device(sc, oracle, gpu, tmp_path, monkeypa
                 try:
                     c, t = count(p)
                 except sc.ScgError as e:
-                    raise AssertionError((level, chunk_kb, window_kb, str(e)))
-                assert t == exp[1] and np.array_equal(c, exp[0]), (level, chunk_kb, window_kb)
+                    raise AssertionError((level, chunk_kb, group_kb, window_kb, str(e)))
+                assert t == exp[1] and np.array_equal(c, exp[0]), (level, chunk_kb, group_kb, window_kb)
     monkeypatch.delenv("SCG_WINDOW_KB", raising=False)
+    monkeypatch.delenv("SCG_DGZIP_GROUP_KB", raising=False)
     monkeypatch.setenv("SCG_DGZIP_CHUNK_KB", "16")
     # a named file (FNAME) is taken; the final record without its newline too
     b = io.BytesIO()

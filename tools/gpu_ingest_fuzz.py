@@ -25,7 +25,7 @@ from tests import gen  # noqa: E402
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 50_000
 TEMPLATE = "ACGTACGA" + "-" * 12 + "TGCATGCA"
-MODE_VARS = ("SCG_DEVICE_SCAN", "SCG_HOST_SCAN", "SCG_DEVICE_INFLATE", "SCG_WINDOW_KB", "SCG_PGZIP", "SCG_PGZIP_CHUNK_KB", "SCG_DEVICE_GUNZIP", "SCG_DGZIP_CHUNK_KB")
+MODE_VARS = ("SCG_DEVICE_SCAN", "SCG_HOST_SCAN", "SCG_DEVICE_INFLATE", "SCG_WINDOW_KB", "SCG_PGZIP", "SCG_PGZIP_CHUNK_KB", "SCG_DEVICE_GUNZIP", "SCG_DGZIP_CHUNK_KB", "SCG_DGZIP_GROUP_KB")
 
 
 def set_mode(**kw):
@@ -154,7 +154,7 @@ with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") els
         # the same text as ordinary gzip: one member or a few, any level, now and then a flipped bit
         import zlib
         gz = os.path.join(tmp, "f.plain.gz")
-        cuts = sorted(rng.sample(range(len(text) + 1), rng.choice([0, 0, 1, 3]))) if text else []
+        cuts = sorted(rng.sample(range(len(text) + 1), min(rng.choice([0, 0, 1, 3]), len(text) + 1))) if text else []
         parts = [text[a:b] for a, b in zip([0] + cuts, cuts + [len(text)])]
         raw = b""
         for part in parts:
@@ -173,7 +173,8 @@ with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") els
         modes = [("host_scan", plain, dict(SCG_WINDOW_KB=kb)), ("device_scan", plain, dict(SCG_HOST_SCAN=0, SCG_WINDOW_KB=kb)),
                  ("device_inflate", bg, dict(SCG_WINDOW_KB=kb)), ("host_inflate", bg, dict(SCG_DEVICE_INFLATE=0, SCG_WINDOW_KB=kb)),
                  ("gzip_parallel", gz, dict(SCG_PGZIP_CHUNK_KB=rng.choice([4, 16, 64]), SCG_DEVICE_GUNZIP=0, SCG_WINDOW_KB=kb)),
-                 ("gzip_device", gz, dict(SCG_PGZIP_CHUNK_KB=16, SCG_DGZIP_CHUNK_KB=rng.choice([4, 16, 64]), SCG_WINDOW_KB=kb)),
+                 ("gzip_device", gz, dict(SCG_PGZIP_CHUNK_KB=16, SCG_DGZIP_CHUNK_KB=rng.choice([4, 16, 64]), SCG_DGZIP_GROUP_KB=rng.choice([None, 128, 512]),
+                                         SCG_WINDOW_KB=kb)),
                  ("gzip_stream", gz, dict(SCG_PGZIP=0, SCG_WINDOW_KB=kb))]
         for name, path, env in modes:
             set_mode(**env)
@@ -184,8 +185,13 @@ with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") els
             if got != exp:
                 print(f"MISMATCH seed {seed} file {it} flaw {flaw} bitflip {bitflip} gzflip {gzflip} mode {name} env {env} window_kb {kb}: got {got[:2]} {got[2][:80] if got[0] == 'error' else ''} "
                       f"want {exp[:2]} {exp[2][:80] if exp[0] == 'error' else ''}", flush=True)
-                again = [run(path, pool)[:2] for _ in range(3)]              # a race, or state left behind by an earlier call?
-                print(f"  the same call three more times: {again}", flush=True)
+                again = [run(path, pool) for _ in range(3)]                  # a race, or state left behind by an earlier call?
+                print(f"  the same call three more times: {[a[:2] + (a == exp,) for a in again]}", flush=True)
+                if got[0] == "ok" and exp[0] == "ok":
+                    g, w = np.frombuffer(got[2], dtype=np.int32), np.frombuffer(exp[2], dtype=np.int32)
+                    print(f"  counts differ at {[(int(i), int(g[i]), int(w[i])) for i in np.nonzero(g != w)[0][:12]]}", flush=True)
+                set_mode(SCG_DEVICE_SCAN=0)
+                print(f"  the sequential reader once more: {run(path, pool) == exp}", flush=True)
                 import shutil
                 keep = os.path.join(ROOT, "gpurun_out", f"fuzz_mismatch_{seed}" + os.path.splitext(path)[1])
                 os.makedirs(os.path.dirname(keep), exist_ok=True)
