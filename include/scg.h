@@ -77,11 +77,11 @@ int scg_device_count(void);
  *
  * Input forms of the file-level entry points: plain FASTQ (records found by the host threads, sequences shipped), BGZF
  * (members inflated, checked and scanned on the device), any other gzip of 2 MB or more (decoded in chunks: speculatively,
- * stitched in order, CRC-32 and length checked -- a one-member file of up to 2 GB on the device, single-end calls only, its
- * text never leaving HBM, SCG_DEVICE_GUNZIP=0 switches that off; other files and whatever the device hands back by all host
+ * stitched in order, CRC-32 and length checked -- a one-member file on the device, in groups of 512 MB of compressed bytes,
+ * its text never leaving HBM, SCG_DEVICE_GUNZIP=0 switches that off; other files and whatever the device hands back by all host
  * threads at once, SCG_PGZIP=0 switches both off), small gzip files and whatever those decoders hand back (one inflate
  * stream on the host: libdeflate on the whole file when the image has it and the text fits $SCG_GZIP_WHOLE_GB, default
- * 8; zlib streaming otherwise).  The device decoder takes 32 bytes of HBM per compressed byte while it runs.
+ *  8; zlib streaming otherwise).  The device decoder takes 33 bytes of HBM per compressed byte of a group while it runs.
  * nthreads raises the number of host threads above the default (sixteen per device the call feeds, at most 64 and at
  * most the CPUs the process may use, cgroup quota included; $SCG_HOST_THREADS overrides).
  * Test and measurement switches, none of which changes a result: SCG_HOST_SCAN=0 (plain files: raw text to the
