@@ -77,7 +77,7 @@ int scg_device_count(void);
  *
  * Input forms of the file-level entry points: plain FASTQ (records found by the host threads, sequences shipped), BGZF
  * (members inflated, checked and scanned on the device), any other gzip of 2 MB or more (decoded in chunks: speculatively,
- * stitched in order, CRC-32 and length checked -- a one-member file on the device, in groups of 512 MB of compressed bytes,
+ * stitched in order, CRC-32 and length checked -- files of one member or several large ones on the device, in groups of 512 MB of compressed bytes,
  * its text never leaving HBM, SCG_DEVICE_GUNZIP=0 switches that off; other files and whatever the device hands back by all host
  * threads at once, SCG_PGZIP=0 switches both off), small gzip files and whatever those decoders hand back (one inflate
  * stream on the host: libdeflate on the whole file when the image has it and the text fits $SCG_GZIP_WHOLE_GB, default

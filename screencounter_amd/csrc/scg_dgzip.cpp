@@ -7,7 +7,7 @@
 // host checks that the chunks chain up exactly -- the only thing it has to know about them -- and two kernels turn the
 // symbols into text that never leaves HBM; the windows the record scan takes are device-to-device copies.
 // Replaces byteme::GzipFileReader (inst/include/byteme/GzipFileReader.hpp:39-51) for the files it accepts; anything
-// unusual -- several members, a header CRC, a stored block at a chunk start, a ratio beyond the symbol buffers, a chunk
+// unusual -- many small members, a header CRC, a stored block at a chunk start, a ratio beyond the symbol buffers, a chunk
 // that does not end where the next begins, a CRC-32 or length mismatch -- makes open_on_device() return null, and the
 // file goes to the host decoders, whose last resort is zlib itself.
 #include <hip/hip_runtime_api.h>
@@ -159,8 +159,8 @@ struct ScratchLease {
 class DeviceGunzipSource : public TextSource {
     int dev;
     Mapping f;
-    uint64_t first_byte = 0, stream_end = 0;
-    uint32_t want_crc = 0, want_size = 0;
+    uint64_t member_start = 0, first_byte = 0, stream_end = 0;
+    uint64_t min_member_chunks = 32;             // a member that is not the file's last is decoded here when it has this many chunks
     size_t chunk_bytes = 0;
     uint64_t n_chunks = 0, cap_syms = 0, group_chunks = 0;
     int host_threads = 1;
@@ -186,35 +186,43 @@ public:
     bool begin() {
         const bool test_hook = std::getenv("SCG_DGZIP_CHUNK_KB") != nullptr;       // (tiny chunks, tiny files)
         if (!f.data || f.size < (test_hook ? size_t(64) : size_t(2) << 20)) return false;
-        const uint8_t* p = f.data;
-        // RFC 1952 header: deflate, no header CRC; name / comment / extra fields are skipped
-        if (p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || (p[3] & 0xE2)) return false;
-        size_t at = 10;
-        if (p[3] & 4) { if (at + 2 > f.size) return false; at += 2 + (p[at] | (static_cast<size_t>(p[at + 1]) << 8)); }
-        for (int field = 0; field < 2; ++field) {
-            if (p[3] & (field == 0 ? 8 : 16)) {
-                while (at < f.size && p[at]) ++at;
-                ++at;
-            }
-        }
-        if (at + 8 + 2 >= f.size) return false;
-        first_byte = at;
-        stream_end = f.size - 8;
-        const uint8_t* t = p + stream_end;
-        want_crc = t[0] | (uint32_t(t[1]) << 8) | (uint32_t(t[2]) << 16) | (uint32_t(t[3]) << 24);
-        want_size = t[4] | (uint32_t(t[5]) << 8) | (uint32_t(t[6]) << 16) | (uint32_t(t[7]) << 24);
         chunk_bytes = size_t(128) << 10;
         if (const char* e = std::getenv("SCG_DGZIP_CHUNK_KB")) { const long kb = std::atol(e); if (kb >= 4) chunk_bytes = static_cast<size_t>(kb) << 10; }
-        n_chunks = (stream_end - first_byte + chunk_bytes - 1) / chunk_bytes;
+        if (const char* e = std::getenv("SCG_DGZIP_MIN_MEMBER_CHUNKS")) min_member_chunks = static_cast<uint64_t>(std::max(0L, std::atol(e)));   // (tests: members of any size)
+        if (!member_at(0)) return false;
         // a chunk decodes from its block start to the next chunk's: up to two chunks of input when a neighbour holds no block start
         // (a DEFLATE block is 30-60 KB of compressed bytes as a rule: small chunks -- the tests' -- mostly hold no block start at all)
         cap_syms = std::max<uint64_t>(chunk_bytes * 16, uint64_t(1) << 20) + 65536;
         uint64_t group_bytes = uint64_t(512) << 20;                     // (its text must stay below 4 GB: the CRC pieces are indexed with 32 bits)
         if (const char* e = std::getenv("SCG_DGZIP_GROUP_KB")) { const long kb = std::atol(e); if (kb >= 4) group_bytes = static_cast<uint64_t>(kb) << 10; }
         group_chunks = std::max<uint64_t>(1, group_bytes / chunk_bytes);
+        return next_group();
+    }
+
+    // A member's header at byte `at` of the file (RFC 1952: deflate, no header CRC; name / comment / extra fields are
+    // skipped): the chunk grid, the chain and the checksums start afresh behind it.  False: not a header this decoder takes.
+    bool member_at(uint64_t at0) {
+        const uint8_t* p = f.data + at0;
+        if (at0 + 18 + 2 > f.size) return false;
+        if (p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || (p[3] & 0xE2)) return false;
+        uint64_t at = at0 + 10;
+        if (p[3] & 4) { if (at + 2 > f.size) return false; at += 2 + (f.data[at] | (static_cast<uint64_t>(f.data[at + 1]) << 8)); }
+        for (int field = 0; field < 2; ++field) {
+            if (p[3] & (field == 0 ? 8 : 16)) {
+                while (at < f.size && f.data[at]) ++at;
+                ++at;
+            }
+        }
+        if (at + 8 + 2 > f.size) return false;
+        member_start = at0;
+        first_byte = at;
+        stream_end = f.size - 8;                  // (where the LAST member's stream ends; an earlier member's end is found by decoding)
+        n_chunks = (stream_end - first_byte + chunk_bytes - 1) / chunk_bytes;
+        next_chunk = 0;
         expect_bit = first_byte * 8;
         crc_acc = crc32(0L, Z_NULL, 0);
-        return next_group();
+        text_total = 0;
+        return true;
     }
 
     size_t next(char* dst, size_t cap) override {
@@ -282,7 +290,7 @@ private:
             // a few chunks of the next group are searched as well: the first of them with a block start says where this group ends
             const uint64_t extra = last_group ? 0 : std::min<uint64_t>(8, n_chunks - hi);
             const uint32_t n = static_cast<uint32_t>(hi - lo + extra), n_decode = static_cast<uint32_t>(hi - lo);
-            const uint64_t a = lo == 0 ? 0 : (expect_bit >> 3);                      // bytes [a, b) of the file go to the device
+            const uint64_t a = expect_bit >> 3;                                     // bytes [a, b) of the file go to the device
             const uint64_t b = last_group ? f.size : std::min<uint64_t>(f.size, first_byte + (hi + extra) * chunk_bytes + 8192);
             size_t free_bytes = 0, total_bytes = 0;
             DGZ_CHECK(hipMemGetInfo(&free_bytes, &total_bytes));
@@ -341,18 +349,28 @@ private:
             std::vector<uint64_t> text_at(n_decode);
             uint64_t expect = expect_bit, made = 0;
             bool final_seen = false;
-            for (uint32_t c = 0; c < n_decode; ++c) {
+            uint32_t n_use = 0;                                                        // chunks of this group that belong to the member
+            for (uint32_t c = 0; c < n_decode && !final_seen; ++c) {
                 text_at[c] = prefix + made;
+                n_use = c + 1;
                 if (chunks[c].start_bit == ~uint64_t(0)) continue;
-                if (final_seen || chunks[c].status != scginf::INFLATE_OK || chunks[c].start_bit != expect) return false;
+                if (chunks[c].status != scginf::INFLATE_OK || chunks[c].start_bit != expect) return false;
                 expect = chunks[c].end_bit;
                 made += chunks[c].made;
                 final_seen = chunks[c].final_block != 0;
             }
-            if (made == 0 || prefix + made + 64 >= (uint64_t(1) << 32)) return false;       // (the scan's windows and the CRC pieces index the text with 32 bits)
+            if ((made == 0 && !final_seen) || prefix + made + 64 >= (uint64_t(1) << 32)) return false;   // (the scan's windows and the CRC pieces index the text with 32 bits)
             uint64_t resume = n_chunks;
+            uint64_t trailer = 0;
+            bool file_ends = false;
             if (final_seen) {
-                if (((expect + 7) >> 3) != stream_end) return false;                  // (more members, or trailing bytes: not for this decoder)
+                // the member's trailer; behind it the file ends or the next member begins (what was decoded of this group behind
+                // the member's last block, on the old member's grid, is dropped: the next group starts at the new member's header)
+                trailer = (expect + 7) >> 3;
+                if (trailer + 8 > f.size) return false;
+                file_ends = trailer + 8 == f.size;
+                // (a file of many small members -- BGZF without its size fields -- would take a group per member: the host's)
+                if (!file_ends && trailer - first_byte < min_member_chunks * chunk_bytes) return false;
             } else {
                 if (last_group) return false;
                 resume = 0;
@@ -369,8 +387,8 @@ private:
             d_status.alloc(sizeof(uint32_t));
             DGZ_CHECK(hipMemcpy(d_at.p, text_at.data(), sizeof(uint64_t) * n_decode, hipMemcpyHostToDevice));
             DGZ_CHECK(hipMemset(d_status.p, 0, sizeof(uint32_t)));
-            DGZ_CHECK(launch_gunzip_text(d_syms.as<uint16_t>(), cap_syms, d_chunks.as<GunzipChunk>(), d_at.as<uint64_t>(), n_decode, fresh.as<char>(),
-                                         d_status.as<uint32_t>(), nullptr));
+            DGZ_CHECK(launch_gunzip_text(d_syms.as<uint16_t>(), cap_syms, d_chunks.as<GunzipChunk>(), d_at.as<uint64_t>(), n_use, fresh.as<char>(),
+                                         prefix - std::min<uint64_t>(prefix, text_total), d_status.as<uint32_t>(), nullptr));
             // CRC-32: pieces of 4 MB on the device, combined here like zlib's crc32_combine
             const uint64_t piece = uint64_t(4) << 20;
             const uint32_t np = static_cast<uint32_t>((made + piece - 1) / piece);
@@ -392,16 +410,22 @@ private:
             if (status) return false;
             for (uint32_t i = 0; i < np; ++i) crc_acc = crc32_combine(crc_acc, crcs[i], static_cast<z_off_t>(pieces[i].out_len));
             text_total += made;
-            if (final_seen && (static_cast<uint32_t>(crc_acc) != want_crc || static_cast<uint32_t>(text_total) != want_size)) return false;
+            if (final_seen) {
+                const uint8_t* t = f.data + trailer;
+                const uint32_t want_crc = t[0] | (uint32_t(t[1]) << 8) | (uint32_t(t[2]) << 16) | (uint32_t(t[3]) << 24);
+                const uint32_t want_size = t[4] | (uint32_t(t[5]) << 8) | (uint32_t(t[6]) << 16) | (uint32_t(t[7]) << 24);
+                if (static_cast<uint32_t>(crc_acc) != want_crc || static_cast<uint32_t>(text_total) != want_size) return false;
+            }
             // (every copy out of the old text was enqueued before this point and the device has been synchronised since)
             DGZ_CHECK(hipDeviceSynchronize());
             if (text.p) { (void)hipFree(text.p); text.p = nullptr; }
             text.p = fresh.p; fresh.p = nullptr;
             pos = prefix - keep;
             text_bytes = prefix + made;
-            ended = final_seen;
+            ended = final_seen && file_ends;
             next_chunk = resume;
             expect_bit = expect;
+            if (final_seen && !file_ends && !member_at(trailer + 8)) return false;      // (trailing bytes that are no member: zlib's to judge)
             if (tr) std::fprintf(stderr, "[scg]   gzip on the device: %.2f GB of text in HBM%s after %.2f ms\n", made / 1e9, ended ? ", CRC-32 checked," : "", ms());
             return true;
         } catch (const Declined&) {

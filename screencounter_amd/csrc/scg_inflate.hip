@@ -695,14 +695,18 @@ constexpr int TAILS_BLOCK = 1024;
 // window lives in LDS (two buffers of 32 KiB: look-ups read one while the chunk's own tail fills the other), the symbols
 // come in one coalesced sweep and the text goes out the same way -- ~2 us a chunk instead of 25 with the look-ups in HBM.
 __global__ __launch_bounds__(TAILS_BLOCK) void gunzip_tails_kernel(const uint16_t* __restrict__ syms, uint64_t cap_syms, const scg::GunzipChunk* __restrict__ chunks,
-                                                                   const uint64_t* __restrict__ text_at, uint32_t n, uint8_t* text, uint32_t* __restrict__ status) {
+                                                                   const uint64_t* __restrict__ text_at, uint32_t n, uint8_t* text, uint64_t floor,
+                                                                   uint32_t* __restrict__ status) {
     __shared__ uint8_t win[2][MARKER_WINDOW];
     uint32_t cur = 0;
-    bool have = false;                           // win[cur] holds the 32 KiB of text in front of the next chunk
-    if (n && text_at[0] >= MARKER_WINDOW) {      // (a later group of a long file: the end of the text before it lies in front)
-        for (uint32_t i = threadIdx.x; i < MARKER_WINDOW; i += TAILS_BLOCK) win[0][i] = text[text_at[0] - MARKER_WINDOW + i];
+    // win[cur] holds the 32 KiB of text in front of the next chunk, of which the last `avail` bytes belong to the member
+    // (text[floor] is its first byte: a reference in front of that is not a valid file, whatever text lies there)
+    uint32_t avail = 0;
+    if (n && text_at[0] > floor) {               // (a later group of a long member: the end of the text before it lies in front)
+        const uint64_t at = text_at[0];
+        avail = static_cast<uint32_t>(at - floor < MARKER_WINDOW ? at - floor : MARKER_WINDOW);
+        for (uint32_t i = threadIdx.x; i < avail; i += TAILS_BLOCK) win[0][MARKER_WINDOW - avail + i] = text[at - avail + i];
         __syncthreads();
-        have = true;
     }
     for (uint32_t c = 0; c < n; ++c) {
         const uint32_t made = chunks[c].made;
@@ -716,12 +720,14 @@ __global__ __launch_bounds__(TAILS_BLOCK) void gunzip_tails_kernel(const uint16_
 #pragma unroll
             for (int k = 0; k < PER; ++k) v[k] = s[threadIdx.x + k * TAILS_BLOCK];
             bool bad = false;
+            const uint32_t first_valid = MARKER_WINDOW - avail;
 #pragma unroll
             for (int k = 0; k < PER; ++k) {
                 uint8_t byte = static_cast<uint8_t>(v[k]);
                 if (v[k] >= MARKER) {
-                    if (have) byte = win[cur][v[k] - MARKER];
-                    else { bad = true; byte = 0; }                       // (a reference in front of the stream: not a valid file)
+                    const uint32_t w = v[k] - MARKER;
+                    if (w >= first_valid) byte = win[cur][w];
+                    else { bad = true; byte = 0; }                       // (a reference in front of the stream)
                 }
                 win[cur ^ 1][threadIdx.x + k * TAILS_BLOCK] = byte;
                 t[threadIdx.x + k * TAILS_BLOCK] = byte;
@@ -730,7 +736,7 @@ __global__ __launch_bounds__(TAILS_BLOCK) void gunzip_tails_kernel(const uint16_
             __threadfence_block();
             __syncthreads();
             cur ^= 1;
-            have = true;
+            avail = MARKER_WINDOW;
             continue;
         }
         // a short chunk (the stream's last, as a rule): look-ups in the text itself, then the window is read back from it
@@ -741,7 +747,7 @@ __global__ __launch_bounds__(TAILS_BLOCK) void gunzip_tails_kernel(const uint16_
             uint8_t byte = static_cast<uint8_t>(x);
             if (x >= MARKER) {
                 const uint64_t back = MARKER_WINDOW - (x - MARKER);
-                if (back > at) { atomicOr(status, 1u); byte = 0; }
+                if (back > at - floor) { atomicOr(status, 1u); byte = 0; }
                 else byte = text[at - back];
             }
             t[i] = byte;
@@ -749,18 +755,17 @@ __global__ __launch_bounds__(TAILS_BLOCK) void gunzip_tails_kernel(const uint16_
         __threadfence_block();
         __syncthreads();
         const uint64_t end = at + made;
-        have = end >= MARKER_WINDOW;
-        if (have) {
-            for (uint32_t i = threadIdx.x; i < MARKER_WINDOW; i += TAILS_BLOCK) win[cur ^ 1][i] = text[end - MARKER_WINDOW + i];
-            __syncthreads();
-            cur ^= 1;
-        }
+        avail = static_cast<uint32_t>(end - floor < MARKER_WINDOW ? end - floor : MARKER_WINDOW);
+        for (uint32_t i = threadIdx.x; i < avail; i += TAILS_BLOCK) win[cur ^ 1][MARKER_WINDOW - avail + i] = text[end - avail + i];
+        __syncthreads();
+        cur ^= 1;
     }
 }
 
 constexpr int RESOLVE_BLOCK = 256, RESOLVE_SLICES = 16;
 __global__ __launch_bounds__(RESOLVE_BLOCK) void gunzip_resolve_kernel(const uint16_t* __restrict__ syms, uint64_t cap_syms, const scg::GunzipChunk* __restrict__ chunks,
-                                                                       const uint64_t* __restrict__ text_at, uint32_t n, uint8_t* text) {
+                                                                       const uint64_t* __restrict__ text_at, uint32_t n, uint8_t* text, uint64_t floor,
+                                                                       uint32_t* __restrict__ status) {
     const uint32_t c = blockIdx.x / RESOLVE_SLICES, slice = blockIdx.x % RESOLVE_SLICES;
     if (c >= n) return;
     const uint32_t made = chunks[c].made;
@@ -769,12 +774,19 @@ __global__ __launch_bounds__(RESOLVE_BLOCK) void gunzip_resolve_kernel(const uin
     const uint16_t* s = syms + cap_syms * c;
     const uint32_t a = static_cast<uint32_t>(static_cast<uint64_t>(body) * slice / RESOLVE_SLICES);
     const uint32_t b = static_cast<uint32_t>(static_cast<uint64_t>(body) * (slice + 1) / RESOLVE_SLICES);
+    bool bad = false;
     for (uint32_t i = a + threadIdx.x; i < b; i += RESOLVE_BLOCK) {
         const uint32_t v = s[i];
         // (a marker's byte lies in the 32 KiB in front of the chunk: a tail, final since gunzip_tails_kernel)
-        const uint64_t back = MARKER_WINDOW - (v - MARKER);             // (back > at: flagged by gunzip_tails_kernel's pass over the same window)
-        text[at + i] = v >= MARKER ? (back <= at ? text[at - back] : uint8_t(0)) : static_cast<uint8_t>(v);
+        const uint64_t back = MARKER_WINDOW - (v - MARKER);
+        uint8_t byte = static_cast<uint8_t>(v);
+        if (v >= MARKER) {
+            if (back <= at - floor) byte = text[at - back];
+            else { bad = true; byte = 0; }                               // (in front of the member)
+        }
+        text[at + i] = byte;
     }
+    if (bad) atomicOr(status, 1u);
 }
 
 // zlib's crc32.c: a * b mod p over GF(2), reflected (bit 31 is x^0).
@@ -927,12 +939,12 @@ hipError_t launch_gunzip_decode(const uint8_t* d_in, uint64_t origin, uint64_t s
     return hipGetLastError();
 }
 hipError_t launch_gunzip_text(const uint16_t* d_syms, uint64_t cap_syms, const GunzipChunk* d_chunks, const uint64_t* d_text_at, uint32_t n, char* d_text,
-                              uint32_t* d_status, hipStream_t stream) {
+                              uint64_t floor, uint32_t* d_status, hipStream_t stream) {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(gunzip_tails_kernel, dim3(1), dim3(TAILS_BLOCK), 0, stream, d_syms, cap_syms, d_chunks, d_text_at, n, reinterpret_cast<uint8_t*>(d_text),
-                       d_status);
+                       floor, d_status);
     hipLaunchKernelGGL(gunzip_resolve_kernel, dim3(n * RESOLVE_SLICES), dim3(RESOLVE_BLOCK), 0, stream, d_syms, cap_syms, d_chunks, d_text_at, n,
-                       reinterpret_cast<uint8_t*>(d_text));
+                       reinterpret_cast<uint8_t*>(d_text), floor, d_status);
     return hipGetLastError();
 }
 // CRC-32 of the pieces members[0 .. n) of d_text (out_off, out_len; their crc fields are not looked at) -> d_crcs.

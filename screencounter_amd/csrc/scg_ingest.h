@@ -104,7 +104,7 @@ public:
     virtual uint64_t size_hint() const = 0;
     virtual const char* kind() const = 0;
     static size_t min_capacity() { return size_t(4) << 20; }
-    // An ordinary (one-member) gzip file decoded on `device`, its text left in HBM; null when the file is not of that
+    // An ordinary gzip file (one member, or several large ones) decoded on `device`, its text left in HBM; null when the file is not of that
     // kind, too small to bother, too large for the symbol buffers, or anything about it is unusual -- the caller then
     // opens it the ordinary way (scg_dgzip.cpp).
     static std::unique_ptr<TextSource> open_on_device(const char* path, int device, int threads);

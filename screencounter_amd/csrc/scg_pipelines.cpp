@@ -1155,7 +1155,7 @@ std::unique_ptr<PlanSet> compile_and_count_single_end(const char* path, scg::Fas
         devices = devices_for_input(text_bytes_hint(path));
         if (device_scan_enabled()) {
             const int host_threads = scg::default_host_threads(nthreads, static_cast<int>(devices.size()));
-            // an ordinary gzip file of some size: decoded by the device when it is of the plain kind (one member), its text
+            // an ordinary gzip file of some size: decoded by the device when it is of the plain kind (one member, or several large ones), its text
             // left in HBM; whatever that decoder declines goes to the host threads' decoder
             if (scg::TextSource::ordinary_gzip(path, host_threads)) {
                 src = scg::TextSource::open_on_device(path, devices[0], host_threads);
@@ -1425,7 +1425,7 @@ void count_paired_host(scg_plan* P, const char* path1, const char* path2, scg::F
     st.drain();
 }
 
-// One mate of a paired run.  An ordinary gzip mate is decoded by the device when it is of the plain kind (one member), one
+// One mate of a paired run.  An ordinary gzip mate is decoded by the device when it is of the plain kind, one
 // mate after the other; what the device hands back, and every other form, is opened the ordinary way (two parallel gzip
 // decoders share the host threads).
 std::unique_ptr<scg::TextSource> open_paired_mate(const char* path, int device, int threads, bool parallel_gzip) {

@@ -103,7 +103,7 @@ hipError_t launch_gunzip_find(const uint8_t* d_in, uint64_t origin, uint64_t siz
 hipError_t launch_gunzip_decode(const uint8_t* d_in, uint64_t origin, uint64_t size, GunzipChunk* d_chunks, uint32_t n, uint32_t n_decode, uint16_t* d_syms,
                                 uint64_t cap_syms, hipStream_t stream);
 hipError_t launch_gunzip_text(const uint16_t* d_syms, uint64_t cap_syms, const GunzipChunk* d_chunks, const uint64_t* d_text_at, uint32_t n, char* d_text,
-                              uint32_t* d_status, hipStream_t stream);
+                              uint64_t floor, uint32_t* d_status, hipStream_t stream);   // (d_text[floor]: the member's first byte, or later)
 hipError_t launch_crc_pieces(const char* d_text, const InflateMember* d_members, uint32_t n, uint32_t* d_crcs, hipStream_t stream);
 
 } // namespace scg

@@ -499,10 +499,10 @@ def test_paired_plain_files_over_several_devices(sc, oracle, gpu, tmp_path, monk
 
 
 def test_ordinary_gzip_decoded_by_the_device(sc, oracle, gpu, tmp_path, monkeypatch):
-    """One-member gzip files (what `gzip` writes) go to the device: chunks decoded into symbols by one wavefront each, the
+    """Ordinary gzip files (what `gzip` writes; several members too, when they are large) go to the device: chunks decoded into symbols by one wavefront each, the
     chain checked on the host, symbols turned into text that stays in HBM (csrc/scg_dgzip.cpp).  SCG_DEVICE_GUNZIP=2 makes
     a hand-back an error, so these well-formed files cannot pass on the host decoders; files of a kind the device decoder
-    does not take (several members, a header CRC, trailing bytes, a flipped bit) must come out as the host readers have
+    does not take (many small members, a header CRC, trailing bytes, a flipped bit) must come out as the host readers have
     them -- same counts, or the same error."""
     import gzip as gz_mod
     import io
@@ -558,7 +558,32 @@ def test_ordinary_gzip_decoded_by_the_device(sc, oracle, gpu, tmp_path, monkeypa
     raw = gz(text, 6)
     hdr = bytearray(raw[:10]); hdr[3] = 2
     with_hcrc = bytes(hdr) + (zlib.crc32(bytes(hdr)) & 0xFFFF).to_bytes(2, "little") + raw[10:]
-    for name, data in (("two members", gz(text[:cut], 6) + gz(text[cut:], 6)), ("header crc", with_hcrc), ("trailing bytes", raw + b"\0\0\0\0")):
+    # several members (`cat a.gz b.gz`, or a writer that flushes now and then): each one's chain, CRC-32 and ISIZE checked on
+    # its own, the next one's chunk grid starting behind its header; a member may end anywhere in a group of chunks
+    third = text.rfind(b"\n@", 0, len(text) // 3) + 1
+    two_thirds = text.rfind(b"\n@", 0, 2 * len(text) // 3) + 1
+    near_end = text.rfind(b"\n@", 0, len(text) - 3000) + 1
+    monkeypatch.setenv("SCG_DEVICE_GUNZIP", "2")
+    for name, data, chunk_kb in (("two members", gz(text[:cut], 6) + gz(text[cut:], 6), 8),         # (32 chunks and more: taken)
+                                 ("three members, levels", gz(text[:third], 1) + gz(text[third:two_thirds], 9) + gz(text[two_thirds:], 4), 4),
+                                 ("an empty member last", gz(text, 6) + gz(b"", 6), 16),
+                                 ("a small member last", gz(text[:near_end], 6) + gz(text[near_end:], 6), 4)):
+        open(p, "wb").write(data)
+        monkeypatch.setenv("SCG_DGZIP_CHUNK_KB", str(chunk_kb))
+        for group_kb in (None, 64, 400):
+            if group_kb:
+                monkeypatch.setenv("SCG_DGZIP_GROUP_KB", str(group_kb))
+            else:
+                monkeypatch.delenv("SCG_DGZIP_GROUP_KB", raising=False)
+            try:
+                c, t = count(p)
+            except sc.ScgError as e:
+                raise AssertionError((name, group_kb, str(e)))
+            assert t == exp[1] and np.array_equal(c, exp[0]), (name, group_kb)
+    monkeypatch.delenv("SCG_DGZIP_GROUP_KB", raising=False)
+    monkeypatch.setenv("SCG_DGZIP_CHUNK_KB", "16")
+    many = b"".join(gz(text[i:i + 50000], 6) for i in range(0, len(text), 50000))      # (members too small to give each a launch)
+    for name, data in (("many small members", many), ("header crc", with_hcrc), ("trailing bytes", raw + b"\0\0\0\0")):
         open(p, "wb").write(data)
         monkeypatch.setenv("SCG_DEVICE_GUNZIP", "2")
         with pytest.raises(sc.ScgError):
