@@ -346,7 +346,8 @@ __device__ __forceinline__ void index_search(const ScgIndex& X, const QueryT<W>&
         // the slot of a group key holds the head node of its chain: an exact hit is one access
         // (tried: 4-byte slots -- hash tag over head index -- so that the tables of a 100 k-barcode library stay in an
         // XCD's L2, the node fetched behind a matching tag: +12 % on configs 2 and 5; the second, dependent gather costs
-        // more than the L2 misses it saves, and fewer slots per entry made it worse still)
+        // more than the L2 misses it saves, and fewer slots per entry made it worse still; 8-byte slots with key planes and
+        // value in one word, no dependent access for one-member chains: +2 %, profiles/r3_packed_slots_ab.txt)
         typename K::Node ent;
         bool found = false;
         for (;;) {
