@@ -36,6 +36,28 @@
 namespace scg {
 namespace {
 
+// CRC-32 of a text from the CRCs of its pieces: crc(A B) = crc(A) * x^(8 |B|) + crc(B) over GF(2) modulo the CRC polynomial
+// (reflected: bit 31 is x^0) -- zlib's crc32_combine, whose 1.2.11 form squares a 32 x 32 matrix per call; thousands of
+// pieces of one length need the power only once.
+uint32_t gf2_mult(uint32_t a, uint32_t b) {
+    uint32_t p = 0;
+    for (int i = 0; i < 32 && a; ++i) {
+        if (a & 0x80000000u) p ^= b;
+        a <<= 1;
+        b = (b & 1u) ? (b >> 1) ^ 0xEDB88320u : b >> 1;
+    }
+    return p;
+}
+uint32_t x_pow_bytes(uint64_t len) {                   // x^(8 len)
+    uint32_t sq = 0x40000000u, x = 0x80000000u;         // x^1, x^0
+    for (int k = 0; k < 3; ++k) sq = gf2_mult(sq, sq);
+    for (; len; len >>= 1) {
+        if (len & 1u) x = gf2_mult(sq, x);
+        sq = gf2_mult(sq, sq);
+    }
+    return x;
+}
+
 struct Declined {};                                     // (thrown inside decode(); never leaves this file)
 #define DGZ_CHECK(expr) do { if ((expr) != hipSuccess) throw Declined(); } while (0)
 
@@ -389,8 +411,9 @@ private:
             DGZ_CHECK(hipMemset(d_status.p, 0, sizeof(uint32_t)));
             DGZ_CHECK(launch_gunzip_text(d_syms.as<uint16_t>(), cap_syms, d_chunks.as<GunzipChunk>(), d_at.as<uint64_t>(), n_use, fresh.as<char>(),
                                          prefix - std::min<uint64_t>(prefix, text_total), d_status.as<uint32_t>(), nullptr));
-            // CRC-32: pieces of 4 MB on the device, combined here like zlib's crc32_combine
-            const uint64_t piece = uint64_t(4) << 20;
+            // CRC-32: pieces of 512 KB on the device (thousands of workgroups: the byte-serial sums hide one another's
+            // latency), combined here like zlib's crc32_combine
+            const uint64_t piece = uint64_t(512) << 10;
             const uint32_t np = static_cast<uint32_t>((made + piece - 1) / piece);
             std::vector<InflateMember> pieces(np);
             for (uint32_t i = 0; i < np; ++i) {
@@ -408,7 +431,11 @@ private:
             DGZ_CHECK(hipMemcpy(crcs.data(), d_crcs.p, sizeof(uint32_t) * np, hipMemcpyDeviceToHost));
             DGZ_CHECK(hipMemcpy(&status, d_status.p, sizeof(uint32_t), hipMemcpyDeviceToHost));
             if (status) return false;
-            for (uint32_t i = 0; i < np; ++i) crc_acc = crc32_combine(crc_acc, crcs[i], static_cast<z_off_t>(pieces[i].out_len));
+            const uint32_t whole_piece = x_pow_bytes(piece);
+            for (uint32_t i = 0; i < np; ++i) {
+                const uint32_t shift = pieces[i].out_len == piece ? whole_piece : x_pow_bytes(pieces[i].out_len);
+                crc_acc = gf2_mult(shift, static_cast<uint32_t>(crc_acc)) ^ crcs[i];
+            }
             text_total += made;
             if (final_seen) {
                 const uint8_t* t = f.data + trailer;

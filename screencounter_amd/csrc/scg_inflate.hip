@@ -763,28 +763,62 @@ __global__ __launch_bounds__(TAILS_BLOCK) void gunzip_tails_kernel(const uint16_
 }
 
 constexpr int RESOLVE_BLOCK = 256, RESOLVE_SLICES = 16;
+// Everything in front of a chunk's tail becomes text, one slice of a chunk per workgroup.  A marker's byte lies in the
+// 32 KiB in front of the chunk -- tails, final since gunzip_tails_kernel -- which every workgroup first copies to LDS;
+// then eight symbols a thread and step: one 16-byte load, look-ups in LDS, one 8-byte store (cap_syms is a multiple of 8,
+// so a chunk's symbols begin on a 16-byte boundary; the text's position is whatever the chunks before made it).
 __global__ __launch_bounds__(RESOLVE_BLOCK) void gunzip_resolve_kernel(const uint16_t* __restrict__ syms, uint64_t cap_syms, const scg::GunzipChunk* __restrict__ chunks,
                                                                        const uint64_t* __restrict__ text_at, uint32_t n, uint8_t* text, uint64_t floor,
                                                                        uint32_t* __restrict__ status) {
+    __shared__ __attribute__((aligned(16))) uint8_t win[MARKER_WINDOW];
     const uint32_t c = blockIdx.x / RESOLVE_SLICES, slice = blockIdx.x % RESOLVE_SLICES;
     if (c >= n) return;
     const uint32_t made = chunks[c].made;
-    const uint32_t body = made < MARKER_WINDOW ? 0u : made - MARKER_WINDOW;     // (the tail is text already)
+    if (made <= MARKER_WINDOW) return;                                   // (all tail: text already)
+    const uint32_t body = made - MARKER_WINDOW;
     const uint64_t at = text_at[c];
-    const uint16_t* s = syms + cap_syms * c;
-    const uint32_t a = static_cast<uint32_t>(static_cast<uint64_t>(body) * slice / RESOLVE_SLICES);
-    const uint32_t b = static_cast<uint32_t>(static_cast<uint64_t>(body) * (slice + 1) / RESOLVE_SLICES);
-    bool bad = false;
-    for (uint32_t i = a + threadIdx.x; i < b; i += RESOLVE_BLOCK) {
-        const uint32_t v = s[i];
-        // (a marker's byte lies in the 32 KiB in front of the chunk: a tail, final since gunzip_tails_kernel)
-        const uint64_t back = MARKER_WINDOW - (v - MARKER);
-        uint8_t byte = static_cast<uint8_t>(v);
-        if (v >= MARKER) {
-            if (back <= at - floor) byte = text[at - back];
-            else { bad = true; byte = 0; }                               // (in front of the member)
+    // the window: text[at - 32 KiB + w] for the w that lie in the member (a reference in front of it is not a valid file)
+    const uint32_t avail = static_cast<uint32_t>(at - floor < MARKER_WINDOW ? at - floor : MARKER_WINDOW);
+    const uint32_t first_valid = MARKER_WINDOW - avail;
+    {
+        const uint8_t* src = text + at - MARKER_WINDOW;                  // (only src[first_valid ..] is touched)
+        const uint32_t whole = (first_valid + 15u) & ~15u;               // 16-byte groups from here on
+        for (uint32_t w = first_valid + threadIdx.x; w < whole && w < MARKER_WINDOW; w += RESOLVE_BLOCK) win[w] = src[w];
+        for (uint32_t w = whole + threadIdx.x * 16u; w < MARKER_WINDOW; w += RESOLVE_BLOCK * 16u) {
+            uint4 v;
+            __builtin_memcpy(&v, src + w, 16);
+            *reinterpret_cast<uint4*>(win + w) = v;
         }
-        text[at + i] = byte;
+    }
+    __syncthreads();
+    const uint16_t* s = syms + cap_syms * c;
+    uint8_t* t = text + at;
+    const uint32_t groups = (body + 7u) >> 3;
+    const uint32_t ga = static_cast<uint32_t>(static_cast<uint64_t>(groups) * slice / RESOLVE_SLICES);
+    const uint32_t gb = static_cast<uint32_t>(static_cast<uint64_t>(groups) * (slice + 1) / RESOLVE_SLICES);
+    bool bad = false;
+    auto byte_of = [&](uint32_t x) -> uint32_t {
+        if (x < MARKER) return x & 0xFFu;
+        const uint32_t w = x - MARKER;
+        if (w >= first_valid) return win[w];
+        bad = true;
+        return 0u;
+    };
+    for (uint32_t g = ga + threadIdx.x; g < gb; g += RESOLVE_BLOCK) {
+        const uint32_t i = g << 3;
+        if (i + 8u <= body) {
+            const uint4 v = *reinterpret_cast<const uint4*>(s + i);
+            const uint32_t q[4] = {v.x, v.y, v.z, v.w};
+            uint64_t out = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                out |= static_cast<uint64_t>(byte_of(q[k] & 0xFFFFu)) << (16 * k);
+                out |= static_cast<uint64_t>(byte_of(q[k] >> 16)) << (16 * k + 8);
+            }
+            __builtin_memcpy(t + i, &out, 8);
+        } else {
+            for (uint32_t j = i; j < body; ++j) t[j] = static_cast<uint8_t>(byte_of(s[j]));   // (the tail behind is text already)
+        }
     }
     if (bad) atomicOr(status, 1u);
 }
