@@ -182,6 +182,7 @@ class DeviceGunzipSource : public TextSource {
     int dev;
     Mapping f;
     uint64_t member_start = 0, first_byte = 0, stream_end = 0;
+    uint32_t tail_group = 32;                    // chunks per group of the tails' scan (scg_inflate.hip, "The tails")
     uint64_t min_member_chunks = 32;             // a member that is not the file's last is decoded here when it has this many chunks
     size_t chunk_bytes = 0;
     uint64_t n_chunks = 0, cap_syms = 0, group_chunks = 0;
@@ -210,6 +211,7 @@ public:
         if (!f.data || f.size < (test_hook ? size_t(64) : size_t(2) << 20)) return false;
         chunk_bytes = size_t(128) << 10;
         if (const char* e = std::getenv("SCG_DGZIP_CHUNK_KB")) { const long kb = std::atol(e); if (kb >= 4) chunk_bytes = static_cast<size_t>(kb) << 10; }
+        if (const char* e = std::getenv("SCG_DGZIP_TAIL_GROUP")) tail_group = static_cast<uint32_t>(std::max(1L, std::atol(e)));   // (tests: many groups in small files)
         if (const char* e = std::getenv("SCG_DGZIP_MIN_MEMBER_CHUNKS")) min_member_chunks = static_cast<uint64_t>(std::max(0L, std::atol(e)));   // (tests: members of any size)
         if (!member_at(0)) return false;
         // a chunk decodes from its block start to the next chunk's: up to two chunks of input when a neighbour holds no block start
@@ -409,8 +411,17 @@ private:
             d_status.alloc(sizeof(uint32_t));
             DGZ_CHECK(hipMemcpy(d_at.p, text_at.data(), sizeof(uint64_t) * n_decode, hipMemcpyHostToDevice));
             DGZ_CHECK(hipMemset(d_status.p, 0, sizeof(uint32_t)));
+            // the tails' scratch: per group of chunks a map (64 KB), a window (32 KB) and a count
+            GunzipTailScratch tails;
+            tails.group = tail_group;
+            const size_t tail_groups = (n_use + tail_group - 1) / tail_group;
+            DevMem d_tails;
+            d_tails.alloc(tail_groups * (size_t(65536) + 32768 + 64));
+            tails.maps = d_tails.as<uint16_t>();
+            tails.wins = d_tails.as<uint8_t>() + tail_groups * 65536;
+            tails.avails = reinterpret_cast<uint32_t*>(d_tails.as<uint8_t>() + tail_groups * (size_t(65536) + 32768));
             DGZ_CHECK(launch_gunzip_text(d_syms.as<uint16_t>(), cap_syms, d_chunks.as<GunzipChunk>(), d_at.as<uint64_t>(), n_use, fresh.as<char>(),
-                                         prefix - std::min<uint64_t>(prefix, text_total), d_status.as<uint32_t>(), nullptr));
+                                         prefix - std::min<uint64_t>(prefix, text_total), tails, d_status.as<uint32_t>(), nullptr));
             // CRC-32: pieces of 512 KB on the device (thousands of workgroups: the byte-serial sums hide one another's
             // latency), combined here like zlib's crc32_combine
             const uint64_t piece = uint64_t(512) << 10;

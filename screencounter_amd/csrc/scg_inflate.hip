@@ -688,30 +688,104 @@ __global__ __launch_bounds__(INFLATE_BLOCK, SCG_INFLATE_WAVES) void gunzip_decod
 }
 
 constexpr int TAILS_BLOCK = 1024;
-// text_at[c] = where chunk c's text begins.  One workgroup walks the chunks in stream order and turns the last 32 KiB of
-// every chunk's symbols into text: a marker's byte lies in the 32 KiB in front of its chunk -- the tail of the chunk
-// before, final by then.  This is the one serial step of the scheme, and in FASTQ nearly every tail is full of markers
-// (a flank that every read repeats is copied from the read before, never spelled out again), so it is made short: the
-// window lives in LDS (two buffers of 32 KiB: look-ups read one while the chunk's own tail fills the other), the symbols
-// come in one coalesced sweep and the text goes out the same way -- ~2 us a chunk instead of 25 with the look-ups in HBM.
-__global__ __launch_bounds__(TAILS_BLOCK) void gunzip_tails_kernel(const uint16_t* __restrict__ syms, uint64_t cap_syms, const scg::GunzipChunk* __restrict__ chunks,
-                                                                   const uint64_t* __restrict__ text_at, uint32_t n, uint8_t* text, uint64_t floor,
-                                                                   uint32_t* __restrict__ status) {
-    __shared__ uint8_t win[2][MARKER_WINDOW];
+// The tails.  The last 32 KiB of every chunk's symbols become text first: a marker's byte lies in the 32 KiB in front of
+// its chunk -- the tail of the chunk before -- so the tails form a chain through the whole stream, and in FASTQ nearly
+// every tail is full of markers (a flank that every read repeats is copied from the read before, never spelled out
+// again).  A chain of functions, though: a chunk turns the window in front of it into the window behind it, every byte
+// of the new window either a literal or a copy of one byte of the old -- and such maps compose.  So, like a scan:
+//   gunzip_tail_maps_kernel     one workgroup per GROUP of chunks composes its chunks' maps: the window behind the group
+//                               as a function of the window in front of it (32 Ki 16-bit entries: literal or marker);
+//   gunzip_tail_windows_kernel  one workgroup walks the groups -- not the chunks -- and leaves every group's window;
+//   gunzip_tails_kernel         one workgroup per group walks its chunks with that window and writes the tails.
+// The windows live in LDS throughout (two buffers: look-ups read one while the other is filled).
+//
+// avail: how many bytes of a window, from its end, belong to the member (a reference in front of the member is not a
+// valid file, whatever text lies there).
+__device__ __forceinline__ uint32_t group_made(const scg::GunzipChunk* __restrict__ chunks, uint32_t c0, uint32_t c1) {
+    uint64_t sum = 0;
+    for (uint32_t c = c0; c < c1; ++c) sum += chunks[c].made;
+    return static_cast<uint32_t>(sum < MARKER_WINDOW ? sum : MARKER_WINDOW);
+}
+
+__global__ __launch_bounds__(TAILS_BLOCK) void gunzip_tail_maps_kernel(const uint16_t* __restrict__ syms, uint64_t cap_syms, const scg::GunzipChunk* __restrict__ chunks,
+                                                                       uint32_t n, uint32_t group, uint16_t* __restrict__ maps) {
+    __shared__ uint16_t map[2][MARKER_WINDOW];
+    const uint32_t g = blockIdx.x, c0 = g * group, c1 = min(n, c0 + group);
     uint32_t cur = 0;
-    // win[cur] holds the 32 KiB of text in front of the next chunk, of which the last `avail` bytes belong to the member
-    // (text[floor] is its first byte: a reference in front of that is not a valid file, whatever text lies there)
-    uint32_t avail = 0;
-    if (n && text_at[0] > floor) {               // (a later group of a long member: the end of the text before it lies in front)
+    for (uint32_t i = threadIdx.x; i < MARKER_WINDOW; i += TAILS_BLOCK) map[0][i] = static_cast<uint16_t>(MARKER + i);
+    __syncthreads();
+    for (uint32_t c = c0; c < c1; ++c) {
+        const uint32_t made = chunks[c].made;
+        if (made == 0) continue;                 // (no block began in this chunk: the one before decoded through it)
+        const uint16_t* s = syms + cap_syms * c;
+        // the window behind the chunk: the last 32 Ki of (the window in front ++ the chunk's symbols)
+        for (uint32_t i = threadIdx.x; i < MARKER_WINDOW; i += TAILS_BLOCK) {
+            const uint64_t j = static_cast<uint64_t>(i) + made;
+            uint16_t v;
+            if (j < MARKER_WINDOW) v = map[cur][j];
+            else {
+                v = s[j - MARKER_WINDOW];
+                if (v >= MARKER) v = map[cur][v - MARKER];
+            }
+            map[cur ^ 1][i] = v;
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    uint16_t* out = maps + static_cast<size_t>(g) * MARKER_WINDOW;
+    for (uint32_t i = threadIdx.x; i < MARKER_WINDOW; i += TAILS_BLOCK) out[i] = map[cur][i];
+}
+
+// wins[g], avails[g]: the window in front of group g's first chunk.  text_at[0] > floor: a later group of a long member,
+// the end of the text before it lies in front.
+__global__ __launch_bounds__(TAILS_BLOCK) void gunzip_tail_windows_kernel(const scg::GunzipChunk* __restrict__ chunks, const uint64_t* __restrict__ text_at, uint32_t n,
+                                                                          uint32_t group, const uint16_t* __restrict__ maps, const uint8_t* __restrict__ text,
+                                                                          uint64_t floor, uint8_t* __restrict__ wins, uint32_t* __restrict__ avails) {
+    __shared__ uint8_t win[2][MARKER_WINDOW];
+    uint32_t cur = 0, avail = 0;
+    if (n && text_at[0] > floor) {
         const uint64_t at = text_at[0];
         avail = static_cast<uint32_t>(at - floor < MARKER_WINDOW ? at - floor : MARKER_WINDOW);
         for (uint32_t i = threadIdx.x; i < avail; i += TAILS_BLOCK) win[0][MARKER_WINDOW - avail + i] = text[at - avail + i];
+    }
+    __syncthreads();
+    const uint32_t groups = (n + group - 1) / group;
+    for (uint32_t g = 0; g < groups; ++g) {
+        uint8_t* out = wins + static_cast<size_t>(g) * MARKER_WINDOW;
+        for (uint32_t i = threadIdx.x; i < MARKER_WINDOW; i += TAILS_BLOCK) out[i] = win[cur][i];
+        if (threadIdx.x == 0) avails[g] = avail;
+        if (g + 1 == groups) break;
+        const uint16_t* m = maps + static_cast<size_t>(g) * MARKER_WINDOW;
+        for (uint32_t i = threadIdx.x; i < MARKER_WINDOW; i += TAILS_BLOCK) {
+            const uint16_t v = m[i];
+            win[cur ^ 1][i] = v >= MARKER ? win[cur][v - MARKER] : static_cast<uint8_t>(v);   // (bytes in front of the member: never looked at)
+        }
+        const uint32_t made = group_made(chunks, g * group, min(n, (g + 1) * group));
+        avail = min(avail + made, static_cast<uint32_t>(MARKER_WINDOW));
+        __syncthreads();
+        cur ^= 1;
+    }
+}
+
+// text_at[c] = where chunk c's text begins.
+__global__ __launch_bounds__(TAILS_BLOCK) void gunzip_tails_kernel(const uint16_t* __restrict__ syms, uint64_t cap_syms, const scg::GunzipChunk* __restrict__ chunks,
+                                                                   const uint64_t* __restrict__ text_at, uint32_t n, uint32_t group, const uint8_t* __restrict__ wins,
+                                                                   const uint32_t* __restrict__ avails, uint8_t* text, uint32_t* __restrict__ status) {
+    __shared__ uint8_t win[2][MARKER_WINDOW];
+    const uint32_t g = blockIdx.x, c0 = g * group, c1 = min(n, c0 + group);
+    uint32_t cur = 0;
+    uint32_t avail = avails[g];
+    {
+        const uint8_t* w0 = wins + static_cast<size_t>(g) * MARKER_WINDOW;
+        for (uint32_t i = threadIdx.x; i < MARKER_WINDOW; i += TAILS_BLOCK) win[0][i] = w0[i];
         __syncthreads();
     }
-    for (uint32_t c = 0; c < n; ++c) {
+    bool bad = false;
+    for (uint32_t c = c0; c < c1; ++c) {
         const uint32_t made = chunks[c].made;
-        if (made == 0) continue;                 // (no block began in this chunk: the one before decoded through it)
+        if (made == 0) continue;
         const uint64_t at = text_at[c];
+        const uint32_t first_valid = MARKER_WINDOW - avail;
         if (made >= MARKER_WINDOW) {
             const uint16_t* s = syms + cap_syms * c + (made - MARKER_WINDOW);
             uint8_t* t = text + at + (made - MARKER_WINDOW);
@@ -719,8 +793,6 @@ __global__ __launch_bounds__(TAILS_BLOCK) void gunzip_tails_kernel(const uint16_
             uint16_t v[PER];
 #pragma unroll
             for (int k = 0; k < PER; ++k) v[k] = s[threadIdx.x + k * TAILS_BLOCK];
-            bool bad = false;
-            const uint32_t first_valid = MARKER_WINDOW - avail;
 #pragma unroll
             for (int k = 0; k < PER; ++k) {
                 uint8_t byte = static_cast<uint8_t>(v[k]);
@@ -732,34 +804,30 @@ __global__ __launch_bounds__(TAILS_BLOCK) void gunzip_tails_kernel(const uint16_
                 win[cur ^ 1][threadIdx.x + k * TAILS_BLOCK] = byte;
                 t[threadIdx.x + k * TAILS_BLOCK] = byte;
             }
-            if (bad) atomicOr(status, 1u);
-            __threadfence_block();
-            __syncthreads();
-            cur ^= 1;
             avail = MARKER_WINDOW;
-            continue;
-        }
-        // a short chunk (the stream's last, as a rule): look-ups in the text itself, then the window is read back from it
-        const uint16_t* s = syms + cap_syms * c;
-        uint8_t* t = text + at;
-        for (uint32_t i = threadIdx.x; i < made; i += TAILS_BLOCK) {
-            const uint32_t x = s[i];
-            uint8_t byte = static_cast<uint8_t>(x);
-            if (x >= MARKER) {
-                const uint64_t back = MARKER_WINDOW - (x - MARKER);
-                if (back > at - floor) { atomicOr(status, 1u); byte = 0; }
-                else byte = text[at - back];
+        } else {
+            // a short chunk (the stream's last, as a rule): all of it is tail, and the window keeps the end of the old one
+            const uint16_t* s = syms + cap_syms * c;
+            uint8_t* t = text + at;
+            const uint32_t keep = MARKER_WINDOW - made;
+            for (uint32_t i = threadIdx.x; i < keep; i += TAILS_BLOCK) win[cur ^ 1][i] = win[cur][i + made];
+            for (uint32_t i = threadIdx.x; i < made; i += TAILS_BLOCK) {
+                const uint32_t x = s[i];
+                uint8_t byte = static_cast<uint8_t>(x);
+                if (x >= MARKER) {
+                    const uint32_t w = x - MARKER;
+                    if (w >= first_valid) byte = win[cur][w];
+                    else { bad = true; byte = 0; }
+                }
+                win[cur ^ 1][keep + i] = byte;
+                t[i] = byte;
             }
-            t[i] = byte;
+            avail = min(avail + made, static_cast<uint32_t>(MARKER_WINDOW));
         }
-        __threadfence_block();
-        __syncthreads();
-        const uint64_t end = at + made;
-        avail = static_cast<uint32_t>(end - floor < MARKER_WINDOW ? end - floor : MARKER_WINDOW);
-        for (uint32_t i = threadIdx.x; i < avail; i += TAILS_BLOCK) win[cur ^ 1][MARKER_WINDOW - avail + i] = text[end - avail + i];
         __syncthreads();
         cur ^= 1;
     }
+    if (bad) atomicOr(status, 1u);
 }
 
 constexpr int RESOLVE_BLOCK = 256, RESOLVE_SLICES = 16;
@@ -973,12 +1041,17 @@ hipError_t launch_gunzip_decode(const uint8_t* d_in, uint64_t origin, uint64_t s
     return hipGetLastError();
 }
 hipError_t launch_gunzip_text(const uint16_t* d_syms, uint64_t cap_syms, const GunzipChunk* d_chunks, const uint64_t* d_text_at, uint32_t n, char* d_text,
-                              uint64_t floor, uint32_t* d_status, hipStream_t stream) {
+                              uint64_t floor, const GunzipTailScratch& scratch, uint32_t* d_status, hipStream_t stream) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(gunzip_tails_kernel, dim3(1), dim3(TAILS_BLOCK), 0, stream, d_syms, cap_syms, d_chunks, d_text_at, n, reinterpret_cast<uint8_t*>(d_text),
-                       floor, d_status);
-    hipLaunchKernelGGL(gunzip_resolve_kernel, dim3(n * RESOLVE_SLICES), dim3(RESOLVE_BLOCK), 0, stream, d_syms, cap_syms, d_chunks, d_text_at, n,
-                       reinterpret_cast<uint8_t*>(d_text), floor, d_status);
+    const uint32_t group = scratch.group, groups = (n + group - 1) / group;
+    uint8_t* text = reinterpret_cast<uint8_t*>(d_text);
+    if (groups > 1)
+        hipLaunchKernelGGL(gunzip_tail_maps_kernel, dim3(groups - 1), dim3(TAILS_BLOCK), 0, stream, d_syms, cap_syms, d_chunks, n, group, scratch.maps);
+    hipLaunchKernelGGL(gunzip_tail_windows_kernel, dim3(1), dim3(TAILS_BLOCK), 0, stream, d_chunks, d_text_at, n, group, scratch.maps, text, floor, scratch.wins,
+                       scratch.avails);
+    hipLaunchKernelGGL(gunzip_tails_kernel, dim3(groups), dim3(TAILS_BLOCK), 0, stream, d_syms, cap_syms, d_chunks, d_text_at, n, group, scratch.wins, scratch.avails,
+                       text, d_status);
+    hipLaunchKernelGGL(gunzip_resolve_kernel, dim3(n * RESOLVE_SLICES), dim3(RESOLVE_BLOCK), 0, stream, d_syms, cap_syms, d_chunks, d_text_at, n, text, floor, d_status);
     return hipGetLastError();
 }
 // CRC-32 of the pieces members[0 .. n) of d_text (out_off, out_len; their crc fields are not looked at) -> d_crcs.

@@ -102,8 +102,11 @@ hipError_t launch_gunzip_find(const uint8_t* d_in, uint64_t origin, uint64_t siz
                               uint64_t chunk_bytes, uint64_t stream_end_byte, hipStream_t stream);
 hipError_t launch_gunzip_decode(const uint8_t* d_in, uint64_t origin, uint64_t size, GunzipChunk* d_chunks, uint32_t n, uint32_t n_decode, uint16_t* d_syms,
                                 uint64_t cap_syms, hipStream_t stream);
+// The tails' scratch (scg_inflate.hip, "The tails"): chunks are taken in groups of `group`; per group a map of 32 Ki 16-bit
+// entries (maps; the last group needs none), a window of 32 KiB (wins) and a count (avails).
+struct GunzipTailScratch { uint32_t group; uint16_t* maps; uint8_t* wins; uint32_t* avails; };
 hipError_t launch_gunzip_text(const uint16_t* d_syms, uint64_t cap_syms, const GunzipChunk* d_chunks, const uint64_t* d_text_at, uint32_t n, char* d_text,
-                              uint64_t floor, uint32_t* d_status, hipStream_t stream);   // (d_text[floor]: the member's first byte, or later)
+                              uint64_t floor, const GunzipTailScratch& scratch, uint32_t* d_status, hipStream_t stream);   // (d_text[floor]: the member's first byte, or later)
 hipError_t launch_crc_pieces(const char* d_text, const InflateMember* d_members, uint32_t n, uint32_t* d_crcs, hipStream_t stream);
 
 } // namespace scg

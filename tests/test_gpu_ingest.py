@@ -523,10 +523,18 @@ def test_ordinary_gzip_decoded_by_the_device(sc, oracle, gpu, tmp_path, monkeypa
 
     monkeypatch.setenv("SCG_PGZIP_CHUNK_KB", "64")                 # (these files are small: let the chunked decoders have them)
     p = str(tmp_path / "one.fastq.gz")
+    turn = 0
     for level in (1, 4, 6, 9):
         for chunk_kb, group_kb in ((4, None), (16, 256), (128, None), (32, 128)):    # (group_kb: the stream decoded in several groups of chunks)
             for window_kb in (None, 100):
                 open(p, "wb").write(gz(text, level))
+                # the tails' scan over groups of 32 chunks (default), of 1, 3 or 7: the 250 chunks of 4 KB make up to 250 groups
+                tail_group = (None, 1, 3, 7)[turn % 4]
+                turn += 1
+                if tail_group:
+                    monkeypatch.setenv("SCG_DGZIP_TAIL_GROUP", str(tail_group))
+                else:
+                    monkeypatch.delenv("SCG_DGZIP_TAIL_GROUP", raising=False)
                 monkeypatch.setenv("SCG_DGZIP_CHUNK_KB", str(chunk_kb))
                 if group_kb:
                     monkeypatch.setenv("SCG_DGZIP_GROUP_KB", str(group_kb))
@@ -540,9 +548,10 @@ def test_ordinary_gzip_decoded_by_the_device(sc, oracle, gpu, tmp_path, monkeypa
                 try:
                     c, t = count(p)
                 except sc.ScgError as e:
-                    raise AssertionError((level, chunk_kb, group_kb, window_kb, str(e)))
-                assert t == exp[1] and np.array_equal(c, exp[0]), (level, chunk_kb, group_kb, window_kb)
+                    raise AssertionError((level, chunk_kb, group_kb, window_kb, tail_group, str(e)))
+                assert t == exp[1] and np.array_equal(c, exp[0]), (level, chunk_kb, group_kb, window_kb, tail_group)
     monkeypatch.delenv("SCG_WINDOW_KB", raising=False)
+    monkeypatch.setenv("SCG_DGZIP_TAIL_GROUP", "5")
     monkeypatch.delenv("SCG_DGZIP_GROUP_KB", raising=False)
     monkeypatch.setenv("SCG_DGZIP_CHUNK_KB", "16")
     # a named file (FNAME) is taken; the final record without its newline too

@@ -25,7 +25,7 @@ from tests import gen  # noqa: E402
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 50_000
 TEMPLATE = "ACGTACGA" + "-" * 12 + "TGCATGCA"
-MODE_VARS = ("SCG_DEVICE_SCAN", "SCG_HOST_SCAN", "SCG_DEVICE_INFLATE", "SCG_WINDOW_KB", "SCG_PGZIP", "SCG_PGZIP_CHUNK_KB", "SCG_DEVICE_GUNZIP", "SCG_DGZIP_CHUNK_KB", "SCG_DGZIP_GROUP_KB", "SCG_DGZIP_MIN_MEMBER_CHUNKS")
+MODE_VARS = ("SCG_DEVICE_SCAN", "SCG_HOST_SCAN", "SCG_DEVICE_INFLATE", "SCG_WINDOW_KB", "SCG_PGZIP", "SCG_PGZIP_CHUNK_KB", "SCG_DEVICE_GUNZIP", "SCG_DGZIP_CHUNK_KB", "SCG_DGZIP_GROUP_KB", "SCG_DGZIP_MIN_MEMBER_CHUNKS", "SCG_DGZIP_TAIL_GROUP")
 
 
 def set_mode(**kw):
@@ -173,7 +173,7 @@ with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") els
         modes = [("host_scan", plain, dict(SCG_WINDOW_KB=kb)), ("device_scan", plain, dict(SCG_HOST_SCAN=0, SCG_WINDOW_KB=kb)),
                  ("device_inflate", bg, dict(SCG_WINDOW_KB=kb)), ("host_inflate", bg, dict(SCG_DEVICE_INFLATE=0, SCG_WINDOW_KB=kb)),
                  ("gzip_parallel", gz, dict(SCG_PGZIP_CHUNK_KB=rng.choice([4, 16, 64]), SCG_DEVICE_GUNZIP=0, SCG_WINDOW_KB=kb)),
-                 ("gzip_device", gz, dict(SCG_PGZIP_CHUNK_KB=16, SCG_DGZIP_CHUNK_KB=rng.choice([4, 16, 64]), SCG_DGZIP_GROUP_KB=rng.choice([None, 128, 512]), SCG_DGZIP_MIN_MEMBER_CHUNKS=rng.choice([None, 0, 0, 1]),
+                 ("gzip_device", gz, dict(SCG_PGZIP_CHUNK_KB=16, SCG_DGZIP_CHUNK_KB=rng.choice([4, 16, 64]), SCG_DGZIP_GROUP_KB=rng.choice([None, 128, 512]), SCG_DGZIP_MIN_MEMBER_CHUNKS=rng.choice([None, 0, 0, 1]), SCG_DGZIP_TAIL_GROUP=rng.choice([None, 1, 2, 5]),
                                          SCG_WINDOW_KB=kb)),
                  ("gzip_stream", gz, dict(SCG_PGZIP=0, SCG_WINDOW_KB=kb))]
         for name, path, env in modes:
