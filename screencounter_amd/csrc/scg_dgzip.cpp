@@ -2,7 +2,7 @@
 //
 // What a sequencer or `gzip` writes is one DEFLATE stream without entry points; scg_pgzip.h explains the two-stage scheme
 // that breaks the chain, and decodes it on the host threads (46 Mreads/s on 16 of them).  Here the same scheme runs where
-// the BGZF members are inflated: the compressed bytes cross the link as they are, one wavefront per 128 KB chunk finds a
+// the BGZF members are inflated: the compressed bytes cross the link as they are, one wavefront per 64 KB chunk finds a
 // block start and decodes to the next chunk's start into 16-bit symbols (markers for the unknown 32 KiB in front), the
 // host checks that the chunks chain up exactly -- the only thing it has to know about them -- and two kernels turn the
 // symbols into text that never leaves HBM; the windows the record scan takes are device-to-device copies.
@@ -209,7 +209,7 @@ public:
     bool begin() {
         const bool test_hook = std::getenv("SCG_DGZIP_CHUNK_KB") != nullptr;       // (tiny chunks, tiny files)
         if (!f.data || f.size < (test_hook ? size_t(64) : size_t(2) << 20)) return false;
-        chunk_bytes = size_t(128) << 10;
+        chunk_bytes = size_t(64) << 10;          // (MI355X, 8 M reads: 128 KB 131 Mreads/s, 64 KB 139, 32 KB 120)
         if (const char* e = std::getenv("SCG_DGZIP_CHUNK_KB")) { const long kb = std::atol(e); if (kb >= 4) chunk_bytes = static_cast<size_t>(kb) << 10; }
         if (const char* e = std::getenv("SCG_DGZIP_TAIL_GROUP")) tail_group = static_cast<uint32_t>(std::max(1L, std::atol(e)));   // (tests: many groups in small files)
         if (const char* e = std::getenv("SCG_DGZIP_MIN_MEMBER_CHUNKS")) min_member_chunks = static_cast<uint64_t>(std::max(0L, std::atol(e)));   // (tests: members of any size)
