@@ -271,6 +271,12 @@ struct scg_plan {
         }
         error_flag.alloc(sizeof(int32_t));
         HIP_CHECK(hipMemset(error_flag.p, 0, sizeof(int32_t)));
+        // hipMemset of device memory returns when the fill is ENQUEUED on the null stream, and the streams the kernels run on
+        // are non-blocking ones, which the null stream does not hold back: a counting kernel launched right behind this
+        // function (the first window of a file is inflated and scanned by the time the plan exists) added to counters and
+        // replicas that the fill then cleared -- every counter a few reads short, once in 30-70 calls of the bench's BGZF leg
+        // (tools/repro_bgzf_counts.py)
+        HIP_CHECK(hipStreamSynchronize(nullptr));
         // host copies are no longer needed
         for (auto& h : htab) { h = scg::HostIndex(); }
         hpairs = scg::HostPairTable();

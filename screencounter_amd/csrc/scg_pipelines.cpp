@@ -51,6 +51,7 @@ void count_single_end_file(scg_plan* P, const char* path, scg::FastqStream& fq, 
         if (!pf.unusual()) return;
         // start over with the reference-exact sequential reader
         if (P->n_counters) HIP_CHECK(hipMemset(P->counters, 0, static_cast<size_t>(P->n_counters) * sizeof(int32_t)));
+        HIP_CHECK(hipStreamSynchronize(nullptr));           // (the fill is only enqueued: scg_plan::upload)
         P->total = 0;
         if (restart) restart();
     }
@@ -938,6 +939,7 @@ void reset_plan(scg_plan* P) {
     DeviceGuard g(P->device);
     if (P->n_counters) HIP_CHECK(hipMemset(P->counters, 0, static_cast<size_t>(P->n_counters) * sizeof(int32_t)));
     if (P->replica_shift > 0) HIP_CHECK(hipMemset(P->replicas.p, 0, P->replicas.bytes));
+    HIP_CHECK(hipStreamSynchronize(nullptr));               // (the fills are only enqueued: scg_plan::upload)
     for (auto& kv : P->pair_stream) {                       // (sparse mode: batches in flight are let finish and dropped)
         if (kv.second.pending) { HIP_CHECK(hipEventSynchronize(kv.second.done)); kv.second.pending = 0; }
     }
@@ -1410,6 +1412,7 @@ void count_paired_host(scg_plan* P, const char* path1, const char* path2, scg::F
             return;
         }
         HIP_CHECK(hipMemset(P->counters, 0, static_cast<size_t>(P->n_counters) * sizeof(int32_t)));
+        HIP_CHECK(hipStreamSynchronize(nullptr));
         P->total = 0;
     }
     scg::ReadBatch b1, b2;
