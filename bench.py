@@ -403,21 +403,45 @@ def end_to_end(sc, synth, torch, np, w, plan, mates, args) -> dict:
             pools_c = [sc.prepare_pool(p) for p in w.pools]    # C string arrays built once (this mirror's marshalling, not the library's work)
 
             def timed(reps=3):
-                """Median of `reps` whole calls (the host side of a shared box is noisy: the spread is reported too)."""
-                dts = []
+                """Median of `reps` whole calls (the host side of a shared box is noisy: the spread is reported too).  Every
+                call must give the same counts."""
+                dts, seen = [], set()
                 for _ in range(reps):
                     t0 = time.perf_counter()
                     mapped, total = call(pools_c, w.mismatches)
                     dts.append(time.perf_counter() - t0)
+                    seen.add((mapped, total))
+                if len(seen) != 1:
+                    raise RuntimeError(f"calls on one file disagree: (mapped, total) = {sorted(seen)}")
                 dts.sort()
                 return dts[len(dts) // 2], dts[0], dts[-1], mapped, total
+
+            def resident_mapped(s):
+                """The same first `s` reads counted where they lie in HBM (the path `value` is measured on): what a file leg
+                must arrive at.  None for the paired entry."""
+                if w.entry == "single":
+                    plan = sc.Plan.single(w.template, w.strand, w.pools[0], w.mismatches, w.use_first)
+                elif w.entry == "combo":
+                    plan = sc.Plan.combo(w.template, w.strand, w.pools[0], w.pools[1], w.mismatches, w.use_first)
+                else:
+                    return None
+                with plan:
+                    plan.count(mates[0][: s * L], fixed_len=L, n_reads=s)
+                    out = plan.read() if w.entry == "single" else plan.read_combo()
+                return int(np.asarray(out[0] if w.entry == "single" else out[1]).astype(np.int64).sum())
+
+            def checked(leg, s, mapped):
+                want = resident_mapped(s)
+                if want is not None and want != mapped:
+                    raise RuntimeError(f"{leg}: {mapped} mapped reads, {want} on the same reads resident in HBM")
+                return want is not None
 
             dt, lo, hi, mapped, total = timed(5)
             res["fastq_file"] = {"value": round(total / dt / 1e6, 2), "unit": unit, "fastq_gbs": round(size / dt / 1e9, 2),
                                  "range": [round(total / hi / 1e6, 2), round(total / lo / 1e6, 2)],
                                  "sample": f"first {s2} of the stream as plain 4-line FASTQ on tmpfs ({size / 1e9:.2f} GB), "
                                            f"one {('scg_count_' + w.entry + '_barcodes')} call incl. library build, median of 5 calls",
-                                 "total": int(total), "mapped": mapped}
+                                 "total": int(total), "mapped": mapped, "equals_resident_counts": checked("fastq_file", s2, mapped)}
             if w.entry != "dual":
                 # the same reads as BGZF (blocked gzip as written by bgzip): members inflated in parallel by the host threads
                 s3 = min(s2, 16_000_000)
@@ -433,7 +457,7 @@ def end_to_end(sc, synth, torch, np, w, plan, mates, args) -> dict:
                 res["fastq_bgzf"] = {"value": round(total / dt / 1e6, 2), "unit": unit, "compressed_gbs": round(gsize / dt / 1e9, 2),
                                      "range": [round(total / hi / 1e6, 2), round(total / lo / 1e6, 2)],
                                      "sample": f"first {s3} of the stream as BGZF-compressed FASTQ on tmpfs ({gsize / 1e9:.2f} GB compressed), median of 3 calls",
-                                     "total": int(total), "mapped": mapped}
+                                     "total": int(total), "mapped": mapped, "equals_resident_counts": checked("fastq_bgzf", s3, mapped)}
                 # ... and as an ordinary single-member gzip file (one zlib stream, level 4, as `gzip` or a sequencer's software
                 # writes it): decoded by all host threads at once (csrc/scg_pgzip.h)
                 s4 = min(s2, 8_000_000)
@@ -456,7 +480,7 @@ def end_to_end(sc, synth, torch, np, w, plan, mates, args) -> dict:
                 res["fastq_gzip"] = {"value": round(total / dt / 1e6, 2), "unit": unit, "range": [round(total / hi / 1e6, 2), round(total / lo / 1e6, 2)],
                                      "sample": f"first {s4} of the stream as one gzip member on tmpfs ({os.path.getsize(gz1) / 1e9:.2f} GB compressed), "
                                                "decoded in chunks on the device (csrc/scg_dgzip.cpp), median of 3 calls",
-                                     "total": int(total), "mapped": mapped}
+                                     "total": int(total), "mapped": mapped, "equals_resident_counts": checked("fastq_gzip", s4, mapped)}
         finally:
             shutil.rmtree(d, ignore_errors=True)
     return res
