@@ -1,5 +1,6 @@
 """GPU box: the BGZF file-level call over and over on one file; every call's counts against the first call's (and the
-expected number of mapped reads).  usage: python3 tools/repro_bgzf_counts.py [calls] ; settings through the environment."""
+expected number of mapped reads).  usage: python3 tools/repro_bgzf_counts.py [calls] ; settings through the environment (FORM=plain: the same reads as a plain
+FASTQ file)."""
 import os
 import sys
 
@@ -11,13 +12,15 @@ from screencounter_amd import synth
 CALLS = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 N = 16_000_000
 w = synth.workload(2, n_reads=N)
-p = "/dev/shm/scg_repro.fastq.gz"
+FORM = os.environ.get("FORM", "bgzf")            # bgzf | plain
+p = "/dev/shm/scg_repro.fastq.gz" if FORM == "bgzf" else "/dev/shm/scg_repro.fastq"
 if not os.path.exists(p):
     dw = synth.DeviceWorkload(w, "cuda:0")
     reads = dw.generate(N).cpu().numpy()
     synth.reads_to_fastq("/dev/shm/scg_repro.fastq", reads, w.read_len)
-    synth.fastq_to_bgzf("/dev/shm/scg_repro.fastq", p, workers=16)
-    os.remove("/dev/shm/scg_repro.fastq")
+    if FORM == "bgzf":
+        synth.fastq_to_bgzf("/dev/shm/scg_repro.fastq", p, workers=16)
+        os.remove("/dev/shm/scg_repro.fastq")
 pool = sc.prepare_pool(w.pools[0]) if hasattr(sc, "prepare_pool") else w.pools[0]
 first = None
 bad = 0
